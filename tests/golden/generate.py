@@ -1,0 +1,506 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the development container.
+
+Imports the *unmodified* reference from /root/reference (through the import
+shims in oracle/ref_shims, because `gym`/`cv2` are not installed), drives it
+and the oracle restatement with identical seeded inputs, asserts they agree
+bit-for-bit, and writes the reference's outputs as small fixtures into this
+directory.  The fixtures are data only (inputs are re-derived from
+tests/golden/streams.py seeds); nothing of the reference travels.
+
+    python tests/golden/generate.py
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle", "ref_shims"),
+                "/root/reference"]
+
+from tests.golden.streams import (  # noqa: E402
+    StreamSpec, vector_steps, as_reference_samples, scalar_kind)
+from oracle import replay as orc  # noqa: E402
+from oracle import qmath  # noqa: E402
+from oracle.sumtree import SumTree  # noqa: E402
+
+from rltime.history.replay_history import ReplayHistoryBuffer  # noqa: E402
+from rltime.history.prioritized_replay_history import (  # noqa: E402
+    PrioritizedReplayHistoryBuffer)
+from rltime.history.data_structures.segment_tree import (  # noqa: E402
+    SumSegmentTree)
+from rltime.general.backend import StateStore  # noqa: E402
+from rltime.training.torch.dqn import DQN  # noqa: E402
+from rltime.training.torch.iqn import IQN  # noqa: E402
+from rltime.general.value_log import ValueLog  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+def deep_equal(a, b, path=""):
+    if isinstance(a, dict):
+        assert isinstance(b, dict) and a.keys() == b.keys(), path
+        for k in a:
+            deep_equal(a[k], b[k], path + "/" + str(k))
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            deep_equal(x, y, path + "/%d" % i)
+    else:
+        a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        b = b.numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+        assert a.dtype == b.dtype, (path, a.dtype, b.dtype)
+        assert a.shape == b.shape, (path, a.shape, b.shape)
+        assert np.array_equal(a, b), path
+
+
+def flatten(prefix, tree, out):
+    if isinstance(tree, dict):
+        for k, v in tree.items():
+            flatten(prefix + "." + k if prefix else k, v, out)
+    else:
+        out[prefix] = tree.numpy() if isinstance(tree, torch.Tensor) \
+            else np.asarray(tree)
+
+
+def tree_dump(tree_nodes, capacity):
+    leaves = tree_nodes[capacity:2 * capacity]
+    return (np.array([float(v) for v in leaves], dtype=np.float64),
+            np.array([scalar_kind(v) for v in leaves], dtype=np.uint8))
+
+
+# --------------------------------------------------------------------------
+# Replay scenarios
+# --------------------------------------------------------------------------
+SCENARIOS = {
+    "uniform_t1": dict(
+        mode="uniform",
+        spec=dict(seed=11, num_envs=3, frame_shape=(2, 3, 3), lstm_units=0,
+                  n_actions=4, done_prob=0.1),
+        hist=dict(size=40, train_frequency=4, nstep_target=1, nstep_train=1,
+                  prefix_steps=0),
+        gamma=0.99,
+        script=[("feed", 8), ("draw", 8, 101, None), ("feed", 9),
+                ("draw", 8, 102, None), ("feed", 4), ("draw", 8, 103, None)]),
+    "uniform_seq": dict(
+        mode="uniform",
+        spec=dict(seed=12, num_envs=4, frame_shape=(2, 3, 3), lstm_units=3,
+                  n_actions=5, done_prob=0.15),
+        hist=dict(size=64, train_frequency=4, nstep_target=3, nstep_train=4,
+                  prefix_steps=2),
+        gamma=0.9,
+        script=[("feed", 3), ("draw", 6, 200, None), ("feed", 9),
+                ("draw", 6, 201, None), ("feed", 10), ("draw", 6, 202, None),
+                ("draw", 6, 203, None)]),
+    "uniform_seq_noxing": dict(
+        mode="uniform",
+        spec=dict(seed=13, num_envs=2, frame_shape=(1, 2, 2), lstm_units=0,
+                  n_actions=3, done_prob=0.2),
+        hist=dict(size=48, train_frequency=4, nstep_target=2, nstep_train=5,
+                  prefix_steps=0, avoid_episode_crossing=True),
+        gamma=0.95,
+        script=[("feed", 20), ("draw", 10, 300, None), ("feed", 7),
+                ("draw", 10, 301, None)]),
+    "per_t1": dict(
+        mode="per",
+        spec=dict(seed=14, num_envs=4, frame_shape=(2, 3, 3), lstm_units=0,
+                  n_actions=4, done_prob=0.1),
+        hist=dict(size=32, train_frequency=4, nstep_target=3, nstep_train=1,
+                  prefix_steps=0, alpha=0.6, beta=0.4, beta_anneal=True),
+        gamma=0.99,
+        script=[("feed", 2), ("draw", 8, 400, 0.0), ("feed", 4),
+                ("draw", 8, 401, 0.1), ("losses", 501),
+                ("draw", 8, 402, 0.2), ("losses", 502), ("feed", 5),
+                ("draw", 8, 403, 0.5), ("losses", 503), ("feed", 3),
+                ("draw", 8, 404, 0.9), ("losses", 504),
+                ("draw", 8, 405, 1.0)]),
+    "per_seq": dict(
+        mode="per",
+        spec=dict(seed=15, num_envs=4, frame_shape=(2, 3, 3), lstm_units=3,
+                  n_actions=6, done_prob=0.12),
+        hist=dict(size=64, train_frequency=4, nstep_target=2, nstep_train=4,
+                  prefix_steps=2, alpha=0.9, beta=0.6, max_weight_factor=0.9),
+        gamma=0.99,
+        script=[("feed", 6), ("draw", 5, 600, 0.0), ("feed", 6),
+                ("draw", 5, 601, 0.05), ("losses", 701),
+                ("draw", 5, 602, 0.1), ("losses", 702), ("feed", 7),
+                ("draw", 5, 603, 0.3), ("losses", 703), ("feed", 9),
+                ("draw", 5, 604, 0.6), ("losses", 704), ("feed", 5),
+                ("losses", 705), ("draw", 5, 605, 0.95)]),
+    "per_seq_global": dict(
+        mode="per",
+        spec=dict(seed=16, num_envs=3, frame_shape=(1, 2, 2), lstm_units=2,
+                  n_actions=3, done_prob=0.1),
+        hist=dict(size=60, train_frequency=4, nstep_target=2, nstep_train=6,
+                  prefix_steps=3, alpha=0.7, beta=0.5, overlap=4,
+                  max_weight_factor=0.8, global_importance_scaling=True,
+                  beta_anneal=0.9),
+        gamma=0.97,
+        script=[("feed", 17), ("draw", 4, 800, 0.3), ("losses", 801),
+                ("feed", 10), ("draw", 4, 802, 0.6), ("losses", 803),
+                ("feed", 6), ("draw", 4, 804, 0.8)]),
+}
+
+
+def run_replay_scenario(name, cfg):
+    spec = StreamSpec(**cfg["spec"])
+    gamma = cfg["gamma"]
+    per = cfg["mode"] == "per"
+
+    ref_cls = PrioritizedReplayHistoryBuffer if per else ReplayHistoryBuffer
+    orc_cls = orc.OraclePrioritizedReplay if per else orc.OracleReplay
+
+    def ref_discount(nstep, reward, policy_output):   # multi_step_trainer.py:72-73
+        return (gamma ** nstep) * reward
+
+    ref = ref_cls(**cfg["hist"], discount_function=ref_discount,
+                  state_store=StateStore("cpu"))
+    mine = orc_cls(**cfg["hist"], discount_function=orc.make_discount(gamma))
+
+    out = {}
+    step_no = 0
+    rnd = 0
+    last_ref_batch = None
+    for op in cfg["script"]:
+        if op[0] == "feed":
+            for step in vector_steps(spec, op[1], start_step=step_no):
+                ref.update(as_reference_samples(spec, step))
+                mine.update(as_reference_samples(spec, step))
+            step_no += op[1]
+            assert ref.train_quota == mine.train_quota
+            continue
+        tag = "r%d" % rnd
+        rnd += 1
+        if op[0] == "draw":
+            _, B, seed, progress = op
+            random.seed(seed); np.random.seed(seed)
+            feed_ref = ref.needed_feed_count(B, spec.num_envs)
+            got_ref = ref.get_train_data(B, train_progress=progress)
+            random.seed(seed); np.random.seed(seed)
+            feed_mine = mine.needed_feed_count(B, spec.num_envs)
+            got_mine = mine.get_train_data(B, train_progress=progress)
+            assert feed_ref == feed_mine
+            out[tag + ".op"] = np.array("draw")
+            out[tag + ".seed"] = np.array(seed)
+            out[tag + ".mbatch"] = np.array(B)
+            out[tag + ".progress"] = np.array(
+                -1.0 if progress is None else progress)
+            out[tag + ".steps_fed"] = np.array(step_no)
+            out[tag + ".feed_count"] = np.array(
+                -1 if feed_ref is None else feed_ref)
+            out[tag + ".quota_after"] = np.array(ref.train_quota)
+            out[tag + ".is_none"] = np.array(got_ref is None)
+            assert (got_ref is None) == (got_mine is None)
+            if got_ref is not None:
+                deep_equal(got_ref, got_mine, tag)
+                flat = {}
+                flatten("", got_ref, flat)
+                for k, v in flat.items():
+                    out[tag + ".batch." + k] = v
+                out[tag + ".windows"] = np.array(
+                    mine.last_windows, dtype=np.int64)
+                if per:
+                    out[tag + ".uniforms"] = np.array(mine.last_uniforms)
+                    out[tag + ".slots"] = np.array(
+                        mine.last_slots, dtype=np.int64)
+                else:
+                    out[tag + ".picks"] = np.array(
+                        mine.last_picks, dtype=np.int64)
+                last_ref_batch = got_ref
+        elif op[0] == "losses":
+            seed = op[1]
+            P = cfg["hist"]["prefix_steps"]
+            idx = last_ref_batch["extra_data"]["loss_indices"][P:]
+            idx = idx.reshape(-1, 2)
+            rng = np.random.RandomState(seed)
+            losses = (rng.randn(idx.shape[0]) * 0.7).astype(np.float32)
+            ref.update_losses(idx, losses)
+            mine.update_losses(idx, losses)
+            out[tag + ".op"] = np.array("losses")
+            out[tag + ".indices"] = idx
+            out[tag + ".losses"] = losses
+            out[tag + ".steps_fed"] = np.array(step_no)
+        if per:
+            # full priority state after every op
+            cap = ref._it_sum._capacity
+            rv, rk = tree_dump(ref._it_sum._value, cap)
+            mv, mk = tree_dump(mine.tree.nodes, cap)
+            assert np.array_equal(rv, mv) and np.array_equal(rk, mk), tag
+            all_ref = [float(v) for v in ref._it_sum._value[1:]]
+            all_mine = [float(v) for v in mine.tree.nodes[1:]]
+            assert all_ref == all_mine
+            assert list(ref._free_indexes) == list(mine.free_slots)
+            out[tag + ".leaf_val"] = rv
+            out[tag + ".leaf_kind"] = rk
+            out[tag + ".node_val"] = np.array(
+                [float(v) for v in ref._it_sum._value], dtype=np.float64)
+            out[tag + ".node_kind"] = np.array(
+                [scalar_kind(v) for v in ref._it_sum._value], dtype=np.uint8)
+            out[tag + ".free_slots"] = np.array(
+                list(ref._free_indexes), dtype=np.int64)
+            slot_env = np.full(len(ref._index_data), -1, dtype=np.int64)
+            slot_base = np.full(len(ref._index_data), -1, dtype=np.int64)
+            for s, rec in enumerate(ref._index_data):
+                if rec is not None:
+                    slot_env[s] = rec["env_id"]
+                    slot_base[s] = rec["env_buffer_offset"]
+            out[tag + ".slot_env"] = slot_env
+            out[tag + ".slot_base"] = slot_base
+            envs = sorted(ref._env_sample_offsets)
+            out[tag + ".env_first"] = np.array(
+                [ref._env_sample_offsets[e] for e in envs], dtype=np.int64)
+            if ref._it_min is not None:
+                out[tag + ".min_val"] = np.array(
+                    [float(v) for v in ref._it_min._value[cap:2 * cap]])
+    out["rounds"] = np.array(rnd)
+    out["config"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(HERE, "replay_%s.npz" % name), **out)
+    print("replay scenario %-20s rounds=%d  keys=%d" % (name, rnd, len(out)))
+
+
+# --------------------------------------------------------------------------
+# Bare tree: leaves + uniforms -> indices in the three precision regimes
+# --------------------------------------------------------------------------
+def run_tree_cases():
+    out = {}
+    rng = np.random.RandomState(77)
+    cases = {}
+    # (a) nstep_train==1 regime: Python 1.0 leaves and float32 leaves
+    cap = 64
+    vals = []
+    for i in range(cap):
+        r = rng.rand()
+        if i >= 50:
+            vals.append(0.0)                 # never-used leaf (neutral)
+        elif r < 0.3:
+            vals.append(1.0)                 # fresh sample: 1.0 ** alpha
+        elif r < 0.4:
+            vals.append(0)                   # evicted leaf (python int)
+        else:
+            vals.append(np.float32(abs(rng.randn()) + 1e-6) ** 0.6)
+    cases["f32_regime"] = (cap, vals)
+    # (b) nothing updated yet: all weak Python floats
+    cases["weak_regime"] = (32, [1.0] * 20 + [0.0] * 12)
+    # (c) nstep_train>1 regime: float32 / float64 leaves mixed
+    cap = 128
+    vals = []
+    for i in range(cap):
+        r = rng.rand()
+        if i >= 100:
+            vals.append(0.0)
+        elif r < 0.1:
+            vals.append(0)
+        elif r < 0.5:
+            vals.append(np.float64(abs(rng.randn()) + 0.1) ** 0.9)
+        else:
+            vals.append(np.float32(abs(rng.randn()) + 0.1) ** 0.9)
+    cases["mixed_regime"] = (cap, vals)
+    # (d) a large f32 tree (2^14) to exercise deep descents
+    cap = 1 << 14
+    vals = [np.float32(abs(v) + 1e-6) ** 0.6 for v in rng.randn(cap)]
+    cases["f32_large"] = (cap, vals)
+
+    for name, (cap, vals) in cases.items():
+        ref = SumSegmentTree(cap)
+        mine = SumTree(cap)
+        for i, v in enumerate(vals):
+            ref[i] = v
+            mine.set_leaf(i, v)
+        for B in (8, 32):
+            random.seed(1234 + B)
+            us = [random.random() for _ in range(B)]
+            total = ref.sum()
+            seg = total / B
+            idx_ref, idx_mine = [], []
+            for i, u in enumerate(us):
+                idx_ref.append(ref.find_prefixsum_idx(u * seg + i * seg))
+                idx_mine.append(mine.descend(u * seg + i * seg))
+            assert idx_ref == idx_mine
+            out["%s.B%d.uniforms" % (name, B)] = np.array(us)
+            out["%s.B%d.index" % (name, B)] = np.array(idx_ref, dtype=np.int64)
+        out[name + ".capacity"] = np.array(cap)
+        out[name + ".leaf_val"] = np.array([float(v) for v in vals])
+        out[name + ".leaf_kind"] = np.array(
+            [scalar_kind(v) for v in vals], dtype=np.uint8)
+        out[name + ".node_val"] = np.array([float(v) for v in ref._value])
+        out[name + ".node_kind"] = np.array(
+            [scalar_kind(v) for v in ref._value], dtype=np.uint8)
+    out["cases"] = np.array(json.dumps(sorted(cases)))
+    np.savez_compressed(os.path.join(HERE, "tree_cases.npz"), **out)
+    print("tree cases: %s" % ", ".join(sorted(cases)))
+
+
+# --------------------------------------------------------------------------
+# Target / loss arithmetic through the reference trainer classes with stub
+# policies
+# --------------------------------------------------------------------------
+class _StubPolicy:
+    """Returns canned tensors from predict(); records nothing else."""
+
+    def __init__(self, outputs):
+        self.outputs = list(outputs)
+        self.calls = 0
+
+    def predict(self, x, timesteps):
+        r = self.outputs[self.calls % len(self.outputs)]
+        self.calls += 1
+        return r
+
+    def make_tensor(self, x, non_blocking=False):
+        from rltime.models.torch.utils import make_tensor
+        return make_tensor(x, "cpu")
+
+    def zero_grad(self):
+        pass
+
+
+class _NullHistory:
+    def __init__(self):
+        self.got = None
+
+    def update_losses(self, indices, losses):
+        self.got = (np.array(indices), np.array(losses))
+
+
+def make_trainer(cls, gamma, vf_eps, double_q, kappa=1.0, batch_mode="mean",
+                 time_mode=None, loss_mode="huber"):
+    t = cls.__new__(cls)
+    t.gamma = gamma
+    t.vf_scale_epsilon = vf_eps
+    t.double_q = double_q
+    t.loss_mode = loss_mode
+    t.huber_kappa = kappa
+    t.loss_aggregation = t._get_aggregator(batch_mode)
+    t.loss_timestep_aggregation = \
+        t._get_aggregator(time_mode) if time_mode else None
+    t.value_log = ValueLog()
+    t.history_buffer = _NullHistory()
+    return t
+
+
+def run_qmath_cases():
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    # --- value rescaling grid (torch_trainer.py:46-78)
+    grid = torch.cat([torch.linspace(-300, 300, 241),
+                      torch.tensor([-1e-3, 0.0, 1e-3, 1e4, -1e4])])
+    for eps in (1e-3, 1e-2):
+        t = make_trainer(DQN, 0.99, eps, False)
+        out["vf.eps%g.x" % eps] = grid.numpy()
+        out["vf.eps%g.scale" % eps] = t._vf_scale(grid).numpy()
+        out["vf.eps%g.unscale" % eps] = t._vf_unscale(grid).numpy()
+        assert torch.equal(t._vf_scale(grid), qmath.vf_scale(grid, eps))
+        assert torch.equal(t._vf_unscale(grid), qmath.vf_unscale(grid, eps))
+
+    T, B, A, N = 3, 4, 5, 8
+    M = T * B
+    returns = (torch.randn(M, generator=g).double() * 2).numpy()     # f64 like history
+    nsteps = torch.randint(1, 4, (M,), generator=g).numpy()           # i64
+    masks = (torch.rand(M, generator=g) > 0.25).long().numpy()        # i64
+    out["tg.returns"] = returns
+    out["tg.nsteps"] = nsteps
+    out["tg.masks"] = masks
+    q_t = torch.randn(M, A, generator=g) * 3
+    q_o = torch.randn(M, A, generator=g) * 3
+    z_t = torch.randn(M, N, A, generator=g) * 3
+    z_o = torch.randn(M, N, A, generator=g) * 3
+    out["tg.q_target"] = q_t.numpy(); out["tg.q_online"] = q_o.numpy()
+    out["tg.z_target"] = z_t.numpy(); out["tg.z_online"] = z_o.numpy()
+    f32 = lambda a: torch.from_numpy(np.asarray(a).astype("float32"))  # noqa: E731
+    for vf_eps in (None, 1e-3):
+        for dq in (False, True):
+            tag = "tg.vf%s.dq%d" % ("none" if vf_eps is None else "1e-3", dq)
+            # DQN
+            t = make_trainer(DQN, 0.97, vf_eps, dq)
+            t.target_policy = _StubPolicy([q_t])
+            t.policy = _StubPolicy([q_o])
+            y = t.calc_target_values(returns, {}, masks, nsteps, 1)
+            mine = qmath.nstep_target(
+                qmath.dqn_bootstrap(q_t, q_o if dq else q_t),
+                f32(returns), f32(masks), f32(nsteps), 0.97, vf_eps)
+            assert torch.equal(y, mine), tag
+            out[tag + ".dqn"] = y.numpy()
+            # IQN: target net forward, then selection net forward (iqn.py:18,32)
+            z_sel = torch.randn(M, N, A, generator=g) * 3
+            t = make_trainer(IQN, 0.97, vf_eps, dq)
+            if dq:
+                t.target_policy = _StubPolicy([(z_t, None)])
+                t.policy = _StubPolicy([(z_sel, None)])
+            else:
+                t.target_policy = _StubPolicy([(z_t, None), (z_sel, None)])
+                t.policy = _StubPolicy([(z_o, None)])
+            y = t.calc_target_values(returns, {}, masks, nsteps, 1)
+            mine = qmath.nstep_target(
+                qmath.iqn_bootstrap(z_t, z_sel),
+                f32(returns), f32(masks), f32(nsteps), 0.97, vf_eps)
+            assert torch.equal(y, mine), tag
+            out[tag + ".z_select"] = z_sel.numpy()
+            out[tag + ".iqn"] = y.numpy()
+
+    # --- losses (dqn.py:132-172, iqn.py:54-129)
+    actions = torch.randint(0, A, (M,), generator=g).numpy()             # i64
+    weights = torch.rand(M, generator=g).double().numpy()                 # f64
+    loss_idx = np.stack([np.arange(M) % B, np.arange(M) + 100], 1)
+    y_dqn = torch.randn(M, generator=g) * 2
+    y_iqn = torch.randn(M, N, generator=g) * 2
+    taus = torch.rand(M * N, generator=g)
+    out["ls.actions"] = actions; out["ls.weights"] = weights
+    out["ls.q"] = q_o.numpy(); out["ls.z"] = z_o.numpy()
+    out["ls.y_dqn"] = y_dqn.numpy(); out["ls.y_iqn"] = y_iqn.numpy()
+    out["ls.taus"] = taus.numpy()
+    out["ls.timesteps"] = np.array(T)
+    combos = [("mean", None), ("sum", None), ("mean", "mean"),
+              ("sum", "mean"), ("mean", "sum")]
+    for bm, tm in combos:
+        for use_w in (False, True):
+            for kappa in (1.0, 0.5):
+                tag = "ls.%s.%s.w%d.k%g" % (bm, tm, use_w, kappa)
+                extra = {"loss_indices": loss_idx}
+                if use_w:
+                    extra["importance_weights"] = weights
+                w_t = f32(weights) if use_w else None
+                for mode in ("huber", "mse"):
+                    q = q_o.clone().requires_grad_(True)
+                    t = make_trainer(DQN, 0.97, None, False, kappa, bm, tm,
+                                     loss_mode=mode)
+                    t.policy = _StubPolicy([q])
+                    t._compute_grads({}, y_dqn, {"actions": actions}, extra, T)
+                    q2 = q_o.clone().requires_grad_(True)
+                    l2, rep2 = qmath.dqn_loss(
+                        q2, torch.from_numpy(actions), y_dqn, w_t, kappa, mode,
+                        T, bm, tm)
+                    l2.backward()
+                    assert torch.equal(q.grad, q2.grad), tag
+                    assert np.array_equal(t.history_buffer.got[1], rep2.numpy())
+                    out[tag + ".dqn_%s.loss" % mode] = l2.detach().numpy()
+                    out[tag + ".dqn_%s.grad" % mode] = q.grad.numpy()
+                    out[tag + ".dqn_%s.report" % mode] = t.history_buffer.got[1]
+                z = z_o.clone().requires_grad_(True)
+                t = make_trainer(IQN, 0.97, None, False, kappa, bm, tm)
+                t.policy = _StubPolicy([(z, taus)])
+                t._compute_grads({}, y_iqn, {"actions": actions}, extra, T)
+                z2 = z_o.clone().requires_grad_(True)
+                l2, rep2 = qmath.iqn_loss(
+                    z2, taus, torch.from_numpy(actions), y_iqn, w_t, kappa,
+                    T, bm, tm)
+                l2.backward()
+                assert torch.equal(z.grad, z2.grad), tag
+                assert np.array_equal(t.history_buffer.got[1], rep2.numpy())
+                out[tag + ".iqn.loss"] = l2.detach().numpy()
+                out[tag + ".iqn.grad"] = z.grad.numpy()
+                out[tag + ".iqn.report"] = t.history_buffer.got[1]
+    np.savez_compressed(os.path.join(HERE, "qmath_cases.npz"), **out)
+    print("qmath cases: %d arrays" % len(out))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    run_tree_cases()
+    for name, cfg in SCENARIOS.items():
+        run_replay_scenario(name, cfg)
+    run_qmath_cases()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,89 @@
+"""Deterministic synthetic actor streams shared by the golden generator, the
+oracle tests and the HIP parity tests.
+
+A *stream* is what a synchronous vectorised actor (reference
+rltime/acting/actor.py:97-149) hands to ``History.update`` per vector step: one
+transition per env, iteration-major / env-minor.  Frames carry their identity
+(env, per-env offset) in their bytes so a gather that picks the wrong row,
+the wrong ring slot or the wrong time-major position is caught.
+"""
+import numpy as np
+
+
+class StreamSpec:
+    def __init__(self, seed, num_envs, frame_shape=(2, 3, 3), lstm_units=0,
+                 n_actions=4, done_prob=0.1, fractional_rewards=True,
+                 env_base=0):
+        self.seed = seed
+        self.num_envs = num_envs
+        self.frame_shape = tuple(frame_shape)
+        self.lstm_units = lstm_units
+        self.n_actions = n_actions
+        self.done_prob = done_prob
+        self.fractional_rewards = fractional_rewards
+        self.env_base = env_base
+
+
+def frame_for(env, offset, shape):
+    """u8 frame whose bytes encode (env, offset)."""
+    n = int(np.prod(shape))
+    k = np.arange(n, dtype=np.int64)
+    v = (env * 131 + offset * 7 + k * 29 + (offset >> 8) * 3) % 251
+    return v.astype(np.uint8).reshape(shape)
+
+
+def vector_steps(spec, count, start_step=0):
+    """Yield ``count`` vector steps as dicts of (E, ...) arrays.  Step ``s`` of
+    env ``e`` is transition offset ``s`` of that env."""
+    E = spec.num_envs
+    palette = np.array([-1.0, 0.0, 0.0, 0.0, 1.0, 0.5, 0.25, 2.0]) \
+        if spec.fractional_rewards else np.array([-1.0, 0.0, 0.0, 1.0])
+    for s in range(start_step, start_step + count):
+        rng = np.random.RandomState((spec.seed * 1000003 + s) % (2 ** 31))
+        out = {
+            "frames": np.stack([
+                frame_for(spec.env_base + e, s, spec.frame_shape)
+                for e in range(E)]),
+            "rewards": palette[rng.randint(0, len(palette), size=E)],
+            "dones": rng.rand(E) < spec.done_prob,
+            "actions": rng.randint(0, spec.n_actions, size=E),
+            "qvalues": rng.randn(E, spec.n_actions).astype(np.float32),
+        }
+        if spec.lstm_units:
+            out["hx"] = rng.randn(E, spec.lstm_units).astype(np.float32)
+            out["cx"] = rng.randn(E, spec.lstm_units).astype(np.float32)
+            # initials of state t is the done of the transition producing it
+            # (reference actor.py:128)
+            out["initials"] = out["dones"].astype(np.float32)
+        yield out
+
+
+def as_reference_samples(spec, step):
+    """One vector step -> the list of per-env sample dicts the reference actor
+    would emit (acting_interface.py:83-90, actor.py:132-145)."""
+    samples = []
+    for e in range(spec.num_envs):
+        state = {"x": step["frames"][e]}
+        if spec.lstm_units:
+            state["layer1_state"] = {
+                "hx": step["hx"][e], "cx": step["cx"][e],
+                "initials": step["initials"][e]}
+        samples.append({
+            "policy_output": {"actions": step["actions"][e],
+                              "qvalues": step["qvalues"][e]},
+            "next_state": state,
+            "reward": step["rewards"][e],      # np.float64 scalar, as np.stack(rews)[i]
+            "done": step["dones"][e],          # np.bool_
+            "info": {},
+            "env_id": spec.env_base + e,
+        })
+    return samples
+
+
+def scalar_kind(v):
+    """0 = weak Python scalar (float/int), 1 = np.float32, 2 = np.float64."""
+    if isinstance(v, np.float32):
+        return 1
+    if isinstance(v, np.floating):
+        return 2
+    return 0
