@@ -1,0 +1,247 @@
+/* mirl.h — C-ABI of librltime_hip.so: the MI355X (gfx950) backend for rltime's
+ * Q-learning hot path.
+ *
+ * The reference (opherlieber/rltime) is pure Python and has no FFI; the
+ * boundary this library sits behind is the reference's Python plugin API
+ * (SURVEY.md section 8b).  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference root).  The Python
+ * mirror of those classes lives in rltime_amd/ and binds this header with
+ * ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 (MIRL_OK) or a negative error code; the text of
+ *     the last error on the calling thread is mirl_last_error().  Nothing
+ *     aborts.  MIRL_NEED_MORE (1) is the one non-error positive status: it is
+ *     the reference's `get_train_data(...) -> None` ("feed more samples").
+ *   - pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - all device work is enqueued on the caller's `stream` (a hipStream_t
+ *     passed as void*; NULL = the null stream) and nothing synchronises the
+ *     host: an ingest / sample / gather / update_losses chain is fully
+ *     asynchronous.
+ *   - one caller thread per handle (the reference's History is
+ *     single-threaded: history.py, cyclic_array.py:8).
+ */
+#ifndef MIRL_H
+#define MIRL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRL_OK 0
+#define MIRL_NEED_MORE 1
+#define MIRL_ERR_ARG (-1)
+#define MIRL_ERR_HIP (-2)
+#define MIRL_ERR_STATE (-3)   /* violates a reference assert (e.g. buffer full but no batch) */
+#define MIRL_ERR_NOGPU (-4)
+
+#define MIRL_MODE_UNIFORM 0
+#define MIRL_MODE_PER 1
+
+typedef struct mirl_replay mirl_replay;
+
+/* Constructor arguments of
+ *   History.__init__                        rltime/history/history.py:17-59
+ *   ReplayHistoryBuffer.__init__            rltime/history/replay_history.py:14-60
+ *   PrioritizedReplayHistoryBuffer.__init__ rltime/history/prioritized_replay_history.py:41-134
+ * plus the shapes of one stored transition (the reference learns those from the
+ * first sample dict; a device-resident SoA store needs them up front).        */
+typedef struct mirl_replay_config {
+  int64_t size;             /* replay_history.py:14  `size` (transitions, all envs) */
+  int32_t num_envs;         /* envs owned by this shard, ids env_base .. env_base+num_envs-1 */
+  int32_t env_base;
+  int32_t frame_bytes;      /* bytes of state["x"] (u8 observation, e.g. 4*84*84)   */
+  int32_t extra_f32;        /* floats of the tuple-observation extra features (0 = none) */
+  int32_t state_f32;        /* floats of recurrent state per transition (hx|cx per layer) */
+  int32_t has_initials;     /* store the per-state `initials` flag (lstm.py:131-161) */
+  int32_t policy_f32;       /* floats of policy_output kept besides the action (qvalues), 0 = drop */
+  int32_t nstep_train;      /* history.py:25  */
+  int32_t prefix_steps;     /* history.py:30  */
+  int32_t nstep_target;     /* history.py:22  */
+  double  gamma;            /* multi_step_trainer.py:70-74 discount closure */
+  int32_t mode;             /* MIRL_MODE_* */
+  int32_t train_frequency;  /* replay_history.py:21 (0 = free running) */
+  int32_t avoid_episode_crossing; /* replay_history.py:40 */
+  int32_t overlap;          /* prioritized_replay_history.py:56; INT32_MIN = default nstep_train/2 */
+  double  alpha, beta, eps, max_weight_factor; /* :47-75 */
+  int32_t beta_anneal_mode; /* 0 = off, 1 = anneal to 1.0 (True), 2 = anneal to beta_anneal_to */
+  double  beta_anneal_to;
+  int32_t global_importance_scaling; /* :76 */
+  int32_t env_ring_slack;   /* extra ring slots per env beyond ceil(size/num_envs)+1 */
+  int32_t device;           /* HIP device ordinal */
+} mirl_replay_config;
+
+/* One vector step handed to History.update: `count` transitions, transition k
+ * belongs to env `env_ids_host[k]` (NULL = env_base+k, i.e. the synchronous
+ * actor's env-minor order, actor.py:132-145).  An env may appear at most once
+ * per call.  All payload arrays are device arrays with leading dimension
+ * `count`; optional ones may be NULL when the config says 0.                  */
+typedef struct mirl_ingest {
+  int32_t count;
+  const int32_t* env_ids_host;
+  const uint8_t* frames;    /* [count][frame_bytes]   next_state["x"]            */
+  const float*   extra;     /* [count][extra_f32]                                */
+  const float*   state;     /* [count][state_f32]     next_state recurrent state */
+  const float*   initials;  /* [count]                                           */
+  const int32_t* actions;   /* [count]                policy_output["actions"]   */
+  const float*   policy;    /* [count][policy_f32]    policy_output["qvalues"]   */
+  const float*   rewards;   /* [count]                                           */
+  const uint8_t* dones;     /* [count]                                           */
+} mirl_ingest;
+
+/* Output of one get_train_data call (history.py:203-286 _make_train_batch),
+ * time-major.  R = rows of the stacked state block:
+ *   overlapped layout (nstep_target < L, no episode-crossing shift): R = L + n,
+ *     states = rows [0, L), target_states = rows [n, L+n)   (history.py:245-265)
+ *   separate layout: R = 2L, states = rows [0, L), target_states = rows [L, 2L)
+ * with L = prefix_steps + nstep_train.  mirl_replay_state_rows() tells which.
+ * dtypes are the ones the trainer sees after make_tensor
+ * (models/torch/utils.py:95-123): u8 stays, everything else float32; the two
+ * integer fields the trainer re-casts with .long() are emitted as int64.      */
+typedef struct mirl_batch {
+  uint8_t* frames;        /* [R][B][frame_bytes]                       */
+  float*   extra;         /* [R][B][extra_f32]      or NULL            */
+  float*   state;         /* [R][B][state_f32]      or NULL            */
+  float*   initials;      /* [R][B]                 or NULL            */
+  float*   returns;       /* [L][B]   n-step discounted return          */
+  float*   nsteps;        /* [L][B]                                     */
+  float*   masks;         /* [L][B]   target_masks                      */
+  int64_t* actions;       /* [L][B]                                     */
+  float*   policy;        /* [L][B][policy_f32]     or NULL            */
+  float*   weights;       /* [L][B]   importance weights (PER) or NULL  */
+  int64_t* loss_indices;  /* [L][B][2] (env_id, env offset); (-1,-1) on prefix rows; PER or NULL */
+} mirl_batch;
+
+const char* mirl_last_error(void);
+int mirl_device_count(void);
+
+/* ---- replay handle -------------------------------------------------------- */
+int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** out);
+int mirl_replay_destroy(mirl_replay* h);
+
+/* History.update (history.py:123-176) + _sample_added hooks
+ * (replay_history.py:77-91, prioritized_replay_history.py:136-172) and the
+ * per-env split of Actor.get_samples (actor.py:132-145), as one batched
+ * device write per vector step.                                               */
+int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream);
+
+/* needed_feed_count (replay_history.py:62-75).  *out = -1 for None.           */
+int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_envs, int64_t* out);
+
+/* The sampling half of get_train_data (replay_history.py:173-184 quota,
+ * :93-140 uniform choice, prioritized_replay_history.py:232-241 stratified
+ * descent, :286-329 + :347-354 importance weights).
+ *   rng_host: uniform mode — int64[mbatch] results of np.random.choice(total, mbatch)
+ *             PER mode     — double[mbatch] results of random.random()
+ *             NULL         — draw on the device (Philox4x32-10, key = seed, step counter)
+ * Outputs (device): slot[mbatch] (PER tree index, or the flat choice),
+ * env[mbatch] (LOCAL env index, 0-based), start[mbatch] (absolute per-env offset of
+ * the first transition of the window, prefix included), weight[mbatch]
+ * (normalised importance weight; 1.0 in uniform mode).
+ * Returns MIRL_NEED_MORE for the reference's `None`.                          */
+int mirl_replay_sample(mirl_replay* h, int32_t mbatch, double train_progress,
+                       const void* rng_host, uint64_t seed,
+                       int32_t* slot, int32_t* env, int64_t* start, float* weight,
+                       void* stream);
+/* uniform mode helper for the host RNG path: np.random.choice's `a` argument. */
+int mirl_replay_uniform_total(mirl_replay* h, int64_t* total);
+
+/* Rows of the state block for this handle's configuration and whether it is
+ * the overlapped layout.                                                      */
+int mirl_replay_state_rows(mirl_replay* h, int32_t* rows, int32_t* overlapped);
+
+/* The assembly half of get_train_data: _make_sample_range + _update_nstep
+ * (history.py:71-108,178-201), _make_train_batch + StateStore.stack
+ * (history.py:203-286, general/backend.py:112-153).                           */
+int mirl_replay_gather(mirl_replay* h, int32_t mbatch, const int32_t* env,
+                       const int64_t* start, const float* weight,
+                       const mirl_batch* out, void* stream);
+
+/* update_losses (prioritized_replay_history.py:243-279) + _recalc_weighted_priority
+ * (:174-208).  indices = int64[count][2] (env_id, offset) exactly as emitted in
+ * mirl_batch.loss_indices; rows with env_id < 0 are ignored.                   */
+int mirl_replay_update_losses(mirl_replay* h, int64_t count, const int64_t* indices,
+                              const float* losses, void* stream);
+
+/* ---- introspection / test hooks (host results; these DO synchronise) ------- */
+int mirl_replay_stats(mirl_replay* h, int64_t* total_items, int64_t* active_sequences,
+                      int64_t* train_quota, int64_t* tree_capacity, int64_t* n_slots);
+int mirl_replay_env_meta(mirl_replay* h, int64_t* first_host, int64_t* count_host);
+int mirl_replay_free_slots(mirl_replay* h, int32_t* slots_host, int64_t* n);
+int mirl_replay_slot_table(mirl_replay* h, int32_t* slot_env_host, int64_t* slot_base_host);
+int mirl_replay_tree_nodes(mirl_replay* h, double* value_host, uint8_t* kind_host, double* min_host);
+/* overwrite leaves [0, n) (value, kind 0/1/2) and rebuild every inner node     */
+int mirl_replay_tree_set_leaves(mirl_replay* h, int64_t n, const double* value_host,
+                                const uint8_t* kind_host, void* stream);
+/* stratified descent only: idx_host[mbatch] for the given uniforms             */
+int mirl_replay_tree_find(mirl_replay* h, int32_t mbatch, const double* uniforms_host,
+                          int64_t* idx_host, void* stream);
+int mirl_replay_losses_peek(mirl_replay* h, int32_t env_local, int64_t offset, int32_t n, float* out_host);
+
+/* ---- target / loss arithmetic (stateless) ---------------------------------
+ * DQN: _get_bootstrap_target_value (training/torch/dqn.py:52-71) + calc_target_values
+ * tail (torch_trainer.py:124-147, _vf_scale/_vf_unscale :46-78).
+ * q_target, q_select: [M][A]; returns/nsteps/masks: [M]; targets out: [M].
+ * vf_eps <= 0 disables value rescaling.                                        */
+int mirl_q_target_dqn(int64_t M, int32_t A, const float* q_target, const float* q_select,
+                      const float* returns, const float* nsteps, const float* masks,
+                      double gamma, double vf_eps, float* targets, void* stream);
+/* IQN: training/torch/iqn.py:36-52 + the same tail.  z_target [M][Nt][A],
+ * z_select [M][Ns][A] -> targets [M][Nt].                                      */
+int mirl_q_target_iqn(int64_t M, int32_t Nt, int32_t Ns, int32_t A,
+                      const float* z_target, const float* z_select,
+                      const float* returns, const float* nsteps, const float* masks,
+                      double gamma, double vf_eps, float* targets, void* stream);
+
+/* DQN._compute_grads loss (training/torch/dqn.py:141-161; _calc_loss :98-114,
+ * importance weights :83-96, aggregation :120-130), forward and analytic
+ * backward in one pass.  row_scale = d(loss)/d(row loss) of the requested
+ * aggregation.  mode: 0 = huber, 1 = mse.  weights may be NULL.
+ * Outputs: row_loss[M] (weighted per-row loss; loss = row_scale * sum),
+ * dq[M][A] = d loss / d q, td[M] = signed td report.                           */
+int mirl_loss_dqn(int64_t M, int32_t A, const float* q, const int64_t* actions,
+                  const float* targets, const float* weights, double kappa, int32_t mode,
+                  double row_scale, float* row_loss, float* dq, float* td, void* stream);
+/* IQN._compute_grads loss (training/torch/iqn.py:77-120).  z [M][N][A],
+ * taus [M][N], targets [M][Nt].  Outputs: row_loss[M], dz[M][N][A],
+ * abs_td[M] (mean |td| report, iqn.py:112).                                    */
+int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const float* z,
+                  const float* taus, const int64_t* actions, const float* targets,
+                  const float* weights, double kappa, double row_scale,
+                  float* row_loss, float* dz, float* abs_td, void* stream);
+
+/* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
+int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
+
+/* ---- host-only hooks (no GPU needed; used by the CPU test-suite) ----------
+ * A bookkeeping-only replay (rings, FIFO, free list, activation) that records
+ * the device plan it would issue.                                             */
+typedef struct mirl_book mirl_book;
+int mirl_book_create(const mirl_replay_config* cfg, mirl_book** out);
+int mirl_book_destroy(mirl_book* b);
+int mirl_book_ingest(mirl_book* b, int32_t count, const int32_t* env_ids_host);
+int mirl_book_stats(mirl_book* b, int64_t* total_items, int64_t* active_sequences,
+                    int64_t* train_quota, int64_t* tree_capacity, int64_t* n_slots);
+int mirl_book_env_meta(mirl_book* b, int64_t* first_host, int64_t* count_host);
+int mirl_book_free_slots(mirl_book* b, int32_t* slots_host, int64_t* n);
+int mirl_book_slot_table(mirl_book* b, int32_t* slot_env_host, int64_t* slot_base_host);
+int mirl_book_needed_feed_count(mirl_book* b, int32_t mbatch, int32_t num_envs, int64_t* out);
+int mirl_book_charge_quota(mirl_book* b, int32_t mbatch);
+int mirl_book_uniform_total(mirl_book* b, int64_t* total);
+int mirl_book_uniform_map(mirl_book* b, int32_t mbatch, const int64_t* picks_host,
+                          int32_t* env_host, int64_t* start_host);
+/* np_emul.h on the host: build the tagged heap from leaves, run descents, and
+ * evaluate one sequence priority — compared with the golden tree fixtures.     */
+int mirl_emul_build_tree(int64_t capacity, const double* leaf_value, const uint8_t* leaf_kind,
+                         double* node_value, uint8_t* node_kind);
+int mirl_emul_find(int64_t capacity, const double* node_value, const uint8_t* node_kind,
+                   int32_t mbatch, const double* uniforms, int64_t* idx);
+int mirl_emul_seq_priority(int32_t nstep_train, double alpha, double max_weight_factor,
+                           const float* loss_slots, double* value, uint8_t* kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRL_H */

@@ -1,0 +1,169 @@
+"""ctypes binding of librltime_hip.so (include/mirl.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises — there is no Python/torch fallback for any op it exports.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librltime_hip.so")
+
+MIRL_OK = 0
+MIRL_NEED_MORE = 1
+MODE_UNIFORM = 0
+MODE_PER = 1
+INT32_MIN = -2 ** 31
+
+
+class MirlError(RuntimeError):
+    pass
+
+
+class ReplayConfig(C.Structure):
+    _fields_ = [
+        ("size", C.c_int64),
+        ("num_envs", C.c_int32),
+        ("env_base", C.c_int32),
+        ("frame_bytes", C.c_int32),
+        ("extra_f32", C.c_int32),
+        ("state_f32", C.c_int32),
+        ("has_initials", C.c_int32),
+        ("policy_f32", C.c_int32),
+        ("nstep_train", C.c_int32),
+        ("prefix_steps", C.c_int32),
+        ("nstep_target", C.c_int32),
+        ("gamma", C.c_double),
+        ("mode", C.c_int32),
+        ("train_frequency", C.c_int32),
+        ("avoid_episode_crossing", C.c_int32),
+        ("overlap", C.c_int32),
+        ("alpha", C.c_double),
+        ("beta", C.c_double),
+        ("eps", C.c_double),
+        ("max_weight_factor", C.c_double),
+        ("beta_anneal_mode", C.c_int32),
+        ("beta_anneal_to", C.c_double),
+        ("global_importance_scaling", C.c_int32),
+        ("env_ring_slack", C.c_int32),
+        ("device", C.c_int32),
+    ]
+
+
+class Ingest(C.Structure):
+    _fields_ = [
+        ("count", C.c_int32),
+        ("env_ids_host", C.c_void_p),
+        ("frames", C.c_void_p),
+        ("extra", C.c_void_p),
+        ("state", C.c_void_p),
+        ("initials", C.c_void_p),
+        ("actions", C.c_void_p),
+        ("policy", C.c_void_p),
+        ("rewards", C.c_void_p),
+        ("dones", C.c_void_p),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("frames", C.c_void_p),
+        ("extra", C.c_void_p),
+        ("state", C.c_void_p),
+        ("initials", C.c_void_p),
+        ("returns", C.c_void_p),
+        ("nsteps", C.c_void_p),
+        ("masks", C.c_void_p),
+        ("actions", C.c_void_p),
+        ("policy", C.c_void_p),
+        ("weights", C.c_void_p),
+        ("loss_indices", C.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise MirlError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (rltime_amd/csrc/build.sh). rltime_amd has no CPU "
+            "fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.mirl_last_error.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+_vp, _i32, _i64, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
+_P = C.POINTER
+
+_SIGNATURES = {
+    "mirl_device_count": [],
+    "mirl_replay_create": [_P(ReplayConfig), _P(_vp)],
+    "mirl_replay_destroy": [_vp],
+    "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
+    "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
+    "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp],
+    "mirl_replay_uniform_total": [_vp, _P(_i64)],
+    "mirl_replay_state_rows": [_vp, _P(_i32), _P(_i32)],
+    "mirl_replay_gather": [_vp, _i32, _vp, _vp, _vp, _P(Batch), _vp],
+    "mirl_replay_update_losses": [_vp, _i64, _vp, _vp, _vp],
+    "mirl_replay_stats": [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)],
+    "mirl_replay_env_meta": [_vp, _vp, _vp],
+    "mirl_replay_free_slots": [_vp, _vp, _P(_i64)],
+    "mirl_replay_slot_table": [_vp, _vp, _vp],
+    "mirl_replay_tree_nodes": [_vp, _vp, _vp, _vp],
+    "mirl_replay_tree_set_leaves": [_vp, _i64, _vp, _vp, _vp],
+    "mirl_replay_tree_find": [_vp, _i32, _vp, _vp, _vp],
+    "mirl_replay_losses_peek": [_vp, _i32, _i64, _i32, _vp],
+    "mirl_q_target_dqn": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
+    "mirl_q_target_iqn": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp],
+    "mirl_loss_dqn": [_i64, _i32, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _vp, _vp, _vp, _vp],
+    "mirl_loss_iqn": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp],
+    "mirl_copy_bytes": [_vp, _vp, _i64, _vp],
+    "mirl_book_create": [_P(ReplayConfig), _P(_vp)],
+    "mirl_book_destroy": [_vp],
+    "mirl_book_ingest": [_vp, _i32, _vp],
+    "mirl_book_stats": [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)],
+    "mirl_book_env_meta": [_vp, _vp, _vp],
+    "mirl_book_free_slots": [_vp, _vp, _P(_i64)],
+    "mirl_book_slot_table": [_vp, _vp, _vp],
+    "mirl_book_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
+    "mirl_book_charge_quota": [_vp, _i32],
+    "mirl_book_uniform_total": [_vp, _P(_i64)],
+    "mirl_book_uniform_map": [_vp, _i32, _vp, _vp, _vp],
+    "mirl_emul_build_tree": [_i64, _vp, _vp, _vp, _vp],
+    "mirl_emul_find": [_i64, _vp, _vp, _i32, _vp, _vp],
+    "mirl_emul_seq_priority": [_i32, _f64, _f64, _vp, _P(_f64), _P(C.c_uint8)],
+}
+
+for _name, _args in _SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+
+
+def last_error():
+    return (lib.mirl_last_error() or b"").decode()
+
+
+def check(rc, what=""):
+    """Raise on error codes; pass MIRL_OK / MIRL_NEED_MORE through."""
+    if rc < 0:
+        raise MirlError("%s failed (%d): %s" % (what or "mirl call", rc, last_error()))
+    return rc
+
+
+def device_count():
+    return lib.mirl_device_count()
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise MirlError(
+            "librltime_hip: no HIP device visible. The rltime_amd hot path runs "
+            "only on an AMD GPU (MI355X / gfx950); there is no CPU fallback.")
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)

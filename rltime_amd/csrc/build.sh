@@ -1,0 +1,11 @@
+#!/bin/bash
+# Build librltime_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../librltime_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+"$HIPCC" $FLAGS -c "$HERE/replay.hip" -o "$HERE/replay.o"
+"$HIPCC" $FLAGS -c "$HERE/qmath.hip" -o "$HERE/qmath.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,202 @@
+// qmath.hip — fused Q-learning target and loss kernels for gfx950.
+//
+// All four kernels are single-pass and HBM-bound: each network output element is
+// read once, nothing of size (M, N', N) is ever materialised (the reference's
+// IQN loss builds ~6 such temporaries, training/torch/iqn.py:85-104).
+//
+//   k_target_dqn   dqn.py:52-71 (double-Q select) + torch_trainer.py:124-147
+//   k_target_iqn   iqn.py:36-52 (argmax of the quantile mean) + the same tail
+//   k_loss_dqn     dqn.py:141-161 forward + analytic backward
+//   k_loss_iqn     iqn.py:77-120 pairwise quantile-Huber forward + backward
+//
+// Floating point, fp32 like the reference (the h^-1 of value rescaling in fp64
+// as torch_trainer.py:59-61 does).  Parity bar: 1e-4 against oracle/qmath.py.
+#include "common.hpp"
+
+namespace mirl {
+
+// torch_trainer.py:46-52
+__device__ __forceinline__ float vf_scale(float x, float eps) {
+  float s = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+  return s * (sqrtf(fabsf(x) + 1.f) - 1.f) + eps * x;
+}
+// torch_trainer.py:54-78 (float64 inside, float32 out)
+__device__ __forceinline__ float vf_unscale(float y, double eps) {
+  double a = fabs((double)y);
+  double x = a / eps - (1.0 / (2.0 * (eps * eps))) * sqrt(4.0 * eps * a + (2.0 * eps + 1.0) * (2.0 * eps + 1.0)) +
+             (2.0 * eps + 1.0) / (2.0 * (eps * eps));
+  double s = y > 0.f ? 1.0 : (y < 0.f ? -1.0 : 0.0);
+  return (float)(x * s);
+}
+// torch_trainer.py:144-147: h(ret + gamma**n * h^-1(v) * mask)
+__device__ __forceinline__ float finish_target(float v, float ret, float disc, float mask, double vf_eps) {
+  if (vf_eps > 0.0) v = vf_unscale(v, vf_eps);
+  float y = ret + disc * v * mask;
+  if (vf_eps > 0.0) y = vf_scale(y, (float)vf_eps);
+  return y;
+}
+
+__global__ void __launch_bounds__(256)
+k_target_dqn(int64_t M, int A, const float* __restrict__ qt, const float* __restrict__ qs,
+             const float* __restrict__ returns, const float* __restrict__ nsteps, const float* __restrict__ masks,
+             float gamma, double vf_eps, float* __restrict__ out) {
+  int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float* s = qs + m * A;
+  int best = 0; float bv = s[0];
+  for (int a = 1; a < A; ++a) { float v = s[a]; if (v > bv) { bv = v; best = a; } }   // first maximum, like torch.argmax
+  float v = qt[m * A + best];
+  out[m] = finish_target(v, returns[m], powf(gamma, nsteps[m]), masks[m], vf_eps);
+}
+
+// One wavefront per transition.  Phase 1: lanes stride over the (Ns x A)
+// selection block, each lane owning a fixed action (lane % A when A divides
+// 64 evenly is not guaranteed, so lanes own element e -> action e % A and the
+// per-action sums are combined through LDS).  Phase 2: first-max argmax.
+// Phase 3: lanes < Nt pick the target quantile of that action and finish.
+__global__ void __launch_bounds__(256)
+k_target_iqn(int64_t M, int Nt, int Ns, int A, const float* __restrict__ zt, const float* __restrict__ zs,
+             const float* __restrict__ returns, const float* __restrict__ nsteps, const float* __restrict__ masks,
+             float gamma, double vf_eps, float* __restrict__ out) {
+  extern __shared__ float lds[];                 // [4 waves][A] action sums
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  float* acc = lds + wave * A;
+  for (int a = lane; a < A; a += 64) acc[a] = 0.f;
+  __syncthreads();
+  if (m < M) {
+    const float* s = zs + m * (int64_t)Ns * A;
+    // lane a (< A) sums its action over the Ns quantiles in order: every load
+    // instruction reads A consecutive floats of one quantile row.
+    for (int a = lane; a < A; a += 64) {
+      float sum = 0.f;
+      for (int n = 0; n < Ns; ++n) sum += s[n * A + a];
+      acc[a] = sum / (float)Ns;
+    }
+  }
+  __syncthreads();
+  if (m >= M) return;
+  int best = 0; float bv = acc[0];
+  for (int a = 1; a < A; ++a) { float v = acc[a]; if (v > bv) { bv = v; best = a; } }
+  const float ret = returns[m], mask = masks[m], disc = powf(gamma, nsteps[m]);
+  const float* t = zt + m * (int64_t)Nt * A;
+  for (int i = lane; i < Nt; i += 64) out[m * Nt + i] = finish_target(t[i * A + best], ret, disc, mask, vf_eps);
+}
+
+// dqn.py:105-111 and its derivative
+__device__ __forceinline__ void huber_pair(float e, float kappa, float& val, float& grad) {
+  float a = fabsf(e);
+  if (a <= kappa) { val = 0.5f * e * e; grad = e; }
+  else { val = kappa * (a - 0.5f * kappa); grad = e > 0.f ? kappa : -kappa; }
+}
+
+__global__ void __launch_bounds__(256)
+k_loss_dqn(int64_t M, int A, const float* __restrict__ q, const int64_t* __restrict__ actions,
+           const float* __restrict__ targets, const float* __restrict__ weights, float kappa, int mode,
+           float row_scale, float* __restrict__ row_loss, float* __restrict__ dq, float* __restrict__ td_out) {
+  int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  int a = (int)actions[m];
+  float td = q[m * A + a] - targets[m];               // dqn.py:151
+  float val, grad;
+  if (mode == 1) { val = td * td; grad = 2.f * td; } else huber_pair(td, kappa, val, grad);
+  float w = weights ? weights[m] : 1.f;
+  row_loss[m] = val * w;
+  td_out[m] = td;                                      // dqn.py:167 signed td report
+  float g = grad * w * row_scale;
+  for (int k = 0; k < A; ++k) dq[m * A + k] = (k == a) ? g : 0.f;
+}
+
+// One wavefront per transition; lane j owns online quantile j (theta_j, tau_j)
+// and walks the Nt targets, which are broadcast from LDS.  Per pair (i, j):
+//   td = y_i - theta_j ; rho = |tau_j - 1{td<0}| * huber(td) / kappa
+//   row = mean_i sum_j rho ; report = mean_ij |td| ; d row / d theta_j = -(1/Nt) sum_i |..| huber'(td)/kappa
+__global__ void __launch_bounds__(256)
+k_loss_iqn(int64_t M, int N, int Nt, int A, const float* __restrict__ z, const float* __restrict__ taus,
+           const int64_t* __restrict__ actions, const float* __restrict__ targets, const float* __restrict__ weights,
+           float kappa, float row_scale, float* __restrict__ row_loss, float* __restrict__ dz,
+           float* __restrict__ abs_td) {
+  extern __shared__ float lds[];                 // [4 waves][Nt targets + N grads]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  float* y = lds + wave * (Nt + N);
+  float* gsh = y + Nt;
+  const bool live = m < M;
+  if (live) for (int i = lane; i < Nt; i += 64) y[i] = targets[m * Nt + i];
+  __syncthreads();
+  const int a = live ? (int)actions[m] : 0;
+  const float w = (live && weights) ? weights[m] : 1.f;
+  const float* zr = z + (live ? m : 0) * (int64_t)N * A;
+  float loss_sum = 0.f, abs_sum = 0.f;
+  if (live) {
+    for (int j = lane; j < N; j += 64) {
+      const float theta = zr[j * A + a], tau = taus[m * N + j];
+      float lj = 0.f, aj = 0.f, gj = 0.f;
+      for (int i = 0; i < Nt; ++i) {
+        float td = y[i] - theta;                     // iqn.py:85-86
+        float val, grad;
+        huber_pair(td, kappa, val, grad);
+        float pen = fabsf(tau - (td < 0.f ? 1.f : 0.f));   // iqn.py:98-99 (indicator detached)
+        lj += pen * val / kappa;                     // iqn.py:100
+        gj -= pen * grad / kappa;                    // d td / d theta = -1
+        aj += fabsf(td);
+      }
+      loss_sum += lj; abs_sum += aj;
+      gsh[j] = gj * (w * row_scale / (float)Nt);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { loss_sum += __shfl_xor(loss_sum, o); abs_sum += __shfl_xor(abs_sum, o); }
+  __syncthreads();                                   // gsh[] written by lane j, read by every lane below
+  if (!live) return;
+  if (lane == 0) {
+    row_loss[m] = (loss_sum / (float)Nt) * w;      // iqn.py:102-104, then importance weight (:118)
+    abs_td[m] = abs_sum / ((float)Nt * (float)N);  // iqn.py:112
+  }
+  // dense gradient row: coalesced (N*A contiguous floats), zero off the acted action
+  float* g = dz + m * (int64_t)N * A;
+  for (int e = lane; e < N * A; e += 64) { int j = e / A, k = e - j * A; g[e] = (k == a) ? gsh[j] : 0.f; }
+}
+
+}  // namespace mirl
+
+using namespace mirl;
+
+extern "C" int mirl_q_target_dqn(int64_t M, int32_t A, const float* q_target, const float* q_select, const float* returns,
+                                 const float* nsteps, const float* masks, double gamma, double vf_eps, float* targets, void* stream) {
+  if (M <= 0 || A <= 0 || !q_target || !q_select || !returns || !nsteps || !masks || !targets) return fail(MIRL_ERR_ARG, "bad q_target_dqn arguments");
+  hipLaunchKernelGGL(k_target_dqn, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, q_target, q_select,
+                     returns, nsteps, masks, (float)gamma, vf_eps, targets);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_q_target_iqn(int64_t M, int32_t Nt, int32_t Ns, int32_t A, const float* z_target, const float* z_select,
+                                 const float* returns, const float* nsteps, const float* masks, double gamma, double vf_eps,
+                                 float* targets, void* stream) {
+  if (M <= 0 || A <= 0 || Nt <= 0 || Ns <= 0 || !z_target || !z_select || !returns || !nsteps || !masks || !targets) return fail(MIRL_ERR_ARG, "bad q_target_iqn arguments");
+  size_t lds = sizeof(float) * 4 * (size_t)A;
+  hipLaunchKernelGGL(k_target_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)Nt, (int)Ns, (int)A,
+                     z_target, z_select, returns, nsteps, masks, (float)gamma, vf_eps, targets);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_loss_dqn(int64_t M, int32_t A, const float* q, const int64_t* actions, const float* targets, const float* weights,
+                             double kappa, int32_t mode, double row_scale, float* row_loss, float* dq, float* td, void* stream) {
+  if (M <= 0 || A <= 0 || !q || !actions || !targets || !row_loss || !dq || !td) return fail(MIRL_ERR_ARG, "bad loss_dqn arguments");
+  hipLaunchKernelGGL(k_loss_dqn, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, q, actions, targets, weights,
+                     (float)kappa, (int)mode, (float)row_scale, row_loss, dq, td);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const float* z, const float* taus, const int64_t* actions,
+                             const float* targets, const float* weights, double kappa, double row_scale, float* row_loss, float* dz,
+                             float* abs_td, void* stream) {
+  if (M <= 0 || A <= 0 || N <= 0 || Nt <= 0 || !z || !taus || !actions || !targets || !row_loss || !dz || !abs_td) return fail(MIRL_ERR_ARG, "bad loss_iqn arguments");
+  size_t lds = sizeof(float) * 4 * (size_t)(Nt + N);
+  hipLaunchKernelGGL(k_loss_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)N, (int)Nt, (int)A, z, taus,
+                     actions, targets, weights, (float)kappa, (float)row_scale, row_loss, dz, abs_td);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}

@@ -1,0 +1,948 @@
+// replay.hip — device-resident replay shard for gfx950 (MI355X).
+//
+// Storage is struct-of-arrays in HBM, one ring of C slots per env:
+//     frames  u8  [E][C][Fp]   next_state["x"] of every transition (Fp = F padded to 16 B)
+//     extra   f32 [E][C][X]    tuple-observation extra features
+//     state   f32 [E][C][S]    stored recurrent state (hx|cx per layer)
+//     initials/rewards f32, actions i32, dones u8, policy f32 [E][C][A]
+//     loss f32, prio_index i32, stamp u64          (prioritized replay only)
+// Transition `off` of env `e` lives in slot off % C.  Its *state* is the
+// next_state of transition off-1 (history.py:167; the first ever transition
+// of an env reuses its own, :163), so one extra slot per env keeps the
+// predecessor of the oldest live transition alive and nothing is stored twice.
+//
+// Kernels (all HBM- or latency-bound; no MFMA — there is no contraction here):
+//   k_scatter_rows    ingest: [K][row] dense -> ring slots            (a1, a16)
+//   k_ingest_scalars  ingest: per-transition scalars + PER init       (a1, a2)
+//   k_plan_apply      ingest: host plan -> tables, leaves, dirty list (a2)
+//   k_tree_fix        re-sum ancestors of dirty leaves, level by level (a3)
+//   k_per_sample      LDS-staged stratified descent + IS weights      (a3, a4, a8)
+//   k_uniform_sample  flat choice -> (env, start) (+ episode refine)  (a5)
+//   k_gather_rows     time-major state-block gather, 16 B/lane        (a7)
+//   k_gather_scalars  n-step scan + per-step scalars                  (a6, a7)
+//   k_loss_stamp / k_loss_write / k_recalc_flagged                    (a9)
+// Row labels are SURVEY.md section 8(a).
+#include "common.hpp"
+#include "book.hpp"
+#include "np_emul.h"
+
+#include <mutex>
+#include <cstring>
+#include <cmath>
+#include <cstdlib>
+
+namespace mirl {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Dev {                 // passed by value to kernels
+  int32_t E, F, Fp, X, S, A, has_init, per;
+  int32_t T, P, N, L, gap, env_base, log2cap, avoid_xing;
+  int64_t C, cap, n_slots;
+  uint8_t* frames; float* extra; float* state; float* initials;
+  int32_t* actions; float* policy; float* rewards; uint8_t* dones;
+  float* loss; int32_t* prio_index; unsigned long long* stamp;
+  double* tv; uint8_t* tk; double* tmin;
+  int32_t* slot_env; int64_t* slot_base; uint8_t* flag;
+  int32_t* dirty; int32_t* dirty_count;
+  int64_t* first; int64_t* count;
+  const double* gpow;        // gamma ** k, k < N, computed by the host libm like Python's float.__pow__
+  double alpha, mwf, eps;
+};
+
+__device__ __forceinline__ int64_t slot_of(const Dev& d, int32_t e, int64_t off) {
+  return (int64_t)e * d.C + off % d.C;
+}
+
+// ---------------------------------------------------------------------------
+// ingest
+// ---------------------------------------------------------------------------
+// Copy K dense rows into ring slots.  One block column per row, 16 B per lane
+// when the geometry allows, else a byte loop.
+__global__ void __launch_bounds__(256)
+k_scatter_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+               const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
+               int64_t C, int32_t row_bytes, int64_t dst_stride, int vec) {
+  const int k = blockIdx.y;
+  const int64_t slot = (int64_t)s_env[k] * C + s_off[k] % C;
+  const uint8_t* s = src + (int64_t)k * row_bytes;
+  uint8_t* t = dst + slot * dst_stride;
+  if (vec) {
+    const int n = row_bytes >> 4;
+    const u32x4* s4 = (const u32x4*)s;
+    u32x4* t4 = (u32x4*)t;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) t4[c] = s4[c];
+  } else {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < row_bytes; c += gridDim.x * 256) t[c] = s[c];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_ingest_scalars(Dev d, int K, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
+                 const float* __restrict__ initials, const int32_t* __restrict__ actions,
+                 const float* __restrict__ rewards, const uint8_t* __restrict__ dones) {
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  int64_t sl = slot_of(d, s_env[k], s_off[k]);
+  if (d.has_init) d.initials[sl] = initials[k];
+  d.actions[sl] = actions[k];
+  d.rewards[sl] = rewards[k];
+  d.dones[sl] = dones[k] ? 1 : 0;
+  if (d.per) {
+    d.loss[sl] = MIRL_LOSS_FRESH;     // sample['loss'] = self._max_loss (python 1.0), prioritized_replay_history.py:141
+    d.prio_index[sl] = -1;
+    d.stamp[sl] = 0ull;
+  }
+}
+
+struct LossGet {
+  const float* loss; int64_t base_slot; int64_t C; int64_t ring0; int64_t off;
+  __device__ float operator()(int t) const { return loss[ring0 + (off + t) % C]; }
+};
+
+__device__ __forceinline__ TV priority_of(const Dev& d, int32_t e, int64_t base) {
+  LossGet g{d.loss, 0, d.C, (int64_t)e * d.C, base};
+  PrioParams p{d.T, d.alpha, d.mwf};
+  return seq_priority(g, p);
+}
+
+// Apply one ingest plan (book.hpp): table writes, env mirrors, leaf ops.
+__global__ void __launch_bounds__(256)
+k_plan_apply(Dev d, int n_table, const TableOp* __restrict__ tops, int n_env, const EnvOp* __restrict__ eops,
+             int n_leaf, const LeafOp* __restrict__ lops) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_table) d.prio_index[slot_of(d, tops[i].env, tops[i].off)] = tops[i].value;
+  if (i < n_env) { d.first[eops[i].env] = eops[i].first; d.count[eops[i].env] = eops[i].count; }
+  if (i < n_leaf) {
+    LeafOp op = lops[i];
+    int64_t leaf = d.cap + op.slot;
+    if (op.activate) {
+      d.slot_env[op.slot] = op.env; d.slot_base[op.slot] = op.base;
+      TV p = priority_of(d, op.env, op.base);
+      d.tv[leaf] = p.v; d.tk[leaf] = p.k;
+      if (d.tmin) d.tmin[leaf] = p.v;
+    } else {                         // prioritized_replay_history.py:223-227
+      d.slot_env[op.slot] = -1; d.slot_base[op.slot] = -1;
+      d.tv[leaf] = 0.0; d.tk[leaf] = KW;
+      if (d.tmin) d.tmin[leaf] = INFINITY;
+    }
+    int at = atomicAdd(d.dirty_count, 1);
+    d.dirty[at] = op.slot;
+  }
+}
+
+// Re-derive every ancestor of the dirty leaves from its two children, one tree
+// level per barrier (segment_tree.py:91-97; the result depends only on the
+// leaves, so the batch order is irrelevant).  Single workgroup: the tree is
+// latency-bound, not bandwidth-bound.
+__global__ void __launch_bounds__(1024)
+k_tree_fix(Dev d) {
+  const int n = *d.dirty_count;
+  for (int lvl = d.log2cap - 1; lvl >= 0; --lvl) {
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      int64_t node = (d.cap + d.dirty[i]) >> (d.log2cap - lvl);
+      TV a{d.tv[2 * node], d.tk[2 * node]}, b{d.tv[2 * node + 1], d.tk[2 * node + 1]};
+      TV r = tadd(a, b);
+      d.tv[node] = r.v; d.tk[node] = r.k;
+      if (d.tmin) { double x = d.tmin[2 * node], y = d.tmin[2 * node + 1]; d.tmin[node] = y < x ? y : x; }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *d.dirty_count = 0;
+}
+
+// full rebuild of one level (test hook mirl_replay_tree_set_leaves)
+__global__ void k_tree_level(Dev d, int64_t lo, int64_t hi) {
+  int64_t node = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node >= hi) return;
+  TV a{d.tv[2 * node], d.tk[2 * node]}, b{d.tv[2 * node + 1], d.tk[2 * node + 1]};
+  TV r = tadd(a, b);
+  d.tv[node] = r.v; d.tk[node] = r.k;
+  if (d.tmin) { double x = d.tmin[2 * node], y = d.tmin[2 * node + 1]; d.tmin[node] = y < x ? y : x; }
+}
+__global__ void k_set_leaves(Dev d, int64_t n, const double* v, const uint8_t* k) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  d.tv[d.cap + i] = v[i]; d.tk[d.cap + i] = k[i];
+  if (d.tmin) d.tmin[d.cap + i] = (v[i] == 0.0) ? INFINITY : v[i];
+}
+
+// ---------------------------------------------------------------------------
+// sampling
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) for the device-RNG mode.
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ double philox_u53(uint64_t seed, uint64_t call, uint32_t lane) {
+  uint32_t c[4] = {lane, (uint32_t)call, (uint32_t)(call >> 32), 0x52544D45u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  // 53-bit uniform in [0,1) like MT19937's genrand_res53
+  return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// _refine_sample_range (replay_history.py:142-171) on absolute offsets.
+__device__ __forceinline__ int64_t refine_start(const Dev& d, int32_t e, int64_t start) {
+  if (!d.avoid_xing) return start;
+  const int amount = d.L;
+  const int64_t first = d.first[e], cnt = d.count[e];
+  for (int k = 0; k < amount - 1; ++k) {
+    if (d.dones[slot_of(d, e, start + k)]) {
+      if (2 * k < amount) {                 // index < amount / 2
+        int64_t s = start - (amount - k - 1);
+        start = s > first ? s : first;      // max(pos - (...), 0)
+      } else {
+        int64_t s = start + k + 1, hi = cnt - amount;
+        start = s < hi ? s : hi;            // min(pos + k + 1, len - amount)
+      }
+      break;
+    }
+  }
+  return start;
+}
+
+#define MIRL_LDS_NODES 2048
+// One workgroup: the top 11 levels of the heap are staged in LDS, every lane
+// runs one stratified query (prioritized_replay_history.py:232-241) with the
+// exact promotion arithmetic of np_emul.h, then the importance weights
+// (:327, :347-354) with a wavefront-shuffle max.
+__global__ void __launch_bounds__(1024)
+k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, uint64_t call,
+             double active, double beta, int global_scale,
+             int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out, int64_t* __restrict__ start_out,
+             float* __restrict__ w_out, double* __restrict__ w_tmp) {
+  __shared__ double s_tv[MIRL_LDS_NODES];
+  __shared__ uint8_t s_tk[MIRL_LDS_NODES];
+  __shared__ double s_red[16];
+  const int64_t staged = 2 * d.cap < MIRL_LDS_NODES ? 2 * d.cap : MIRL_LDS_NODES;
+  for (int i = threadIdx.x; i < staged; i += 1024) { s_tv[i] = d.tv[i]; s_tk[i] = d.tk[i]; }
+  __syncthreads();
+  const TV total{s_tv[1], s_tk[1]};
+  double local_max = 0.0;
+  for (int i = threadIdx.x; i < B; i += 1024) {
+    double u = uniforms ? uniforms[i] : philox_u53(seed, call, (uint32_t)i);
+    TV mass = stratum_mass(total, B, i, u);
+    int64_t pos = 1;
+    while (pos < d.cap) {
+      int64_t c = 2 * pos;
+      TV left;
+      if (c < staged) { left.v = s_tv[c]; left.k = s_tk[c]; } else { left.v = d.tv[c]; left.k = d.tk[c]; }
+      if (tgreater(left, mass)) pos = c; else { mass = tsub(mass, left); pos = c + 1; }
+    }
+    int32_t idx = (int32_t)(pos - d.cap);
+    slot_out[i] = idx;
+    int32_t e = d.slot_env[idx];
+    int64_t start = d.slot_base[idx] - d.P;
+    if (e >= 0) start = refine_start(d, e, start);
+    env_out[i] = e; start_out[i] = start;
+    // weight = ((leaf / p_sum) * total_items) ** (-beta)
+    double w = pow((d.tv[pos] / total.v) * active, -beta);
+    w_tmp[i] = w;
+    local_max = w > local_max ? w : local_max;
+  }
+  // batch max: wavefront shuffle reduction, then 16 partials through LDS
+  for (int o = 32; o > 0; o >>= 1) { double x = __shfl_xor(local_max, o); local_max = x > local_max ? x : local_max; }
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = local_max;
+  __syncthreads();
+  double top = s_red[0];
+  for (int k = 1; k < 16; ++k) top = s_red[k] > top ? s_red[k] : top;
+  if (global_scale) top = pow((d.tmin[1] / total.v) * active, -beta);   // :350-351
+  for (int i = threadIdx.x; i < B; i += 1024) w_out[i] = (float)(w_tmp[i] / top);
+}
+
+// test hook: descent only
+__global__ void k_tree_find(Dev d, int B, const double* __restrict__ uniforms, int64_t* __restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  TV total{d.tv[1], d.tk[1]};
+  idx[i] = tagged_descend(d.tv, d.tk, d.cap, stratum_mass(total, B, i, uniforms[i]));
+}
+
+// Uniform replay (replay_history.py:118-134): flat choice -> (env, start) by a
+// binary search over the per-env cumulative availability the host uploaded.
+__global__ void __launch_bounds__(256)
+k_uniform_sample(Dev d, int B, const int64_t* __restrict__ picks, uint64_t seed, uint64_t call,
+                 int n_cum, const int64_t* __restrict__ cum, const int32_t* __restrict__ cum_env,
+                 int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out,
+                 int64_t* __restrict__ start_out, float* __restrict__ w_out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  const int64_t total = cum[n_cum - 1];
+  int64_t p;
+  if (picks) p = picks[i];
+  else { p = (int64_t)(philox_u53(seed, call, (uint32_t)i) * (double)total); if (p >= total) p = total - 1; }
+  int lo = 0, hi = n_cum - 1;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (p < cum[mid]) hi = mid; else lo = mid + 1; }
+  int32_t e = cum_env[lo];
+  int64_t before = lo ? cum[lo - 1] : 0;
+  int64_t start = refine_start(d, e, d.first[e] + (p - before));
+  slot_out[i] = (int32_t)p; env_out[i] = e; start_out[i] = start; w_out[i] = 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// gather
+// ---------------------------------------------------------------------------
+// Source ring offset of state-block row r for the window starting at `start`.
+__device__ __forceinline__ int64_t row_src_off(const Dev& d, int overlapped, int r, int32_t e, int64_t start) {
+  int64_t o;
+  if (overlapped || r < d.L) {
+    o = start + r;                       // state of transition o == next_state of o-1
+    return o > 0 ? o - 1 : 0;            // history.py:163 first-ever sample
+  }
+  o = start + (r - d.L);                 // target state of transition o
+  int64_t avail = d.count[e] - o;        // history.py:83 end = min(index+n, len)
+  int64_t ns = avail < d.N ? avail : d.N;
+  return o + ns - 1;
+}
+
+// out[r][b][:] = ring[env[b]][src(r, b)][:] for one leaf of the state pytree.
+// One workgroup per (r, b) row: the source is a contiguous ring slot, the
+// destination a contiguous row of the time-major batch, 16 B per lane, four
+// independent loads in flight per lane before the first store.
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_gather_rows(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
+              const int32_t* __restrict__ env, const int64_t* __restrict__ start,
+              int B, int overlapped, int32_t row_bytes, int64_t ring_stride, int vec) {
+  const int64_t rb = blockIdx.x;
+  const int r = (int)(rb / B), b = (int)(rb % B);
+  int32_t e = env[b];
+  if (e < 0 || e >= d.E) e = 0;          // inactive slot (reference would assert); stay in bounds
+  const int64_t src_off = row_src_off(d, overlapped, r, e, start[b]);
+  const uint8_t* s = ring + ((int64_t)e * d.C + src_off % d.C) * ring_stride;
+  uint8_t* t = out + rb * (int64_t)row_bytes;
+  if (vec) {
+    const int n = row_bytes >> 4;
+    const u32x4* s4 = (const u32x4*)s;
+    u32x4* t4 = (u32x4*)t;
+    int c = threadIdx.x;
+    for (; c + 768 < n; c += 1024) {
+      u32x4 v0, v1, v2, v3;
+      if (NT) {
+        v0 = __builtin_nontemporal_load(s4 + c); v1 = __builtin_nontemporal_load(s4 + c + 256);
+        v2 = __builtin_nontemporal_load(s4 + c + 512); v3 = __builtin_nontemporal_load(s4 + c + 768);
+        __builtin_nontemporal_store(v0, t4 + c); __builtin_nontemporal_store(v1, t4 + c + 256);
+        __builtin_nontemporal_store(v2, t4 + c + 512); __builtin_nontemporal_store(v3, t4 + c + 768);
+      } else {
+        v0 = s4[c]; v1 = s4[c + 256]; v2 = s4[c + 512]; v3 = s4[c + 768];
+        t4[c] = v0; t4[c + 256] = v1; t4[c + 512] = v2; t4[c + 768] = v3;
+      }
+    }
+    for (; c < n; c += 256) {
+      if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + c), t4 + c);
+      else t4[c] = s4[c];
+    }
+  } else {
+    for (int c = threadIdx.x; c < row_bytes; c += 256) t[c] = s[c];
+  }
+}
+
+// Per-step scalars of the batch.  One lane per (t, b):
+//   _update_nstep (history.py:71-108): forward scan over <= n rewards / dones,
+//   return accumulated in float64 with gamma**k from the host libm (the Python
+//   float arithmetic of multi_step_trainer.py:72-73), two roundings per term;
+//   actions, stored policy outputs, importance weights, loss indices
+//   (prioritized_replay_history.py:329-338) and the `initials` rows.
+__global__ void __launch_bounds__(256)
+k_gather_scalars(Dev d, int B, int R, int overlapped, const int32_t* __restrict__ env,
+                 const int64_t* __restrict__ start, const float* __restrict__ weight, mirl_batch o) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int rows = R > d.L ? R : d.L;
+  if (i >= (int64_t)rows * B) return;
+  const int r = (int)(i / B), b = (int)(i % B);
+  int32_t e = env[b];
+  if (e < 0 || e >= d.E) e = 0;
+  const int64_t s0 = start[b];
+  if (r < R && o.initials) {
+    int64_t src = row_src_off(d, overlapped, r, e, s0);
+    o.initials[i] = d.initials[slot_of(d, e, src)];
+  }
+  if (r >= d.L) return;
+  const int64_t off = s0 + r;
+  const int64_t sl = slot_of(d, e, off);
+  double ret = (double)d.rewards[sl];              // history.py:146 float(reward)
+  int mask = d.dones[sl] ? 0 : 1;                  // :147
+  int ns = 1;
+  const int64_t cnt = d.count[e];
+  for (int k = 1; k < d.N && off + k < cnt; ++k) {
+    int64_t sj = slot_of(d, e, off + k);
+    if (mask) {                                    // :87-90
+      double term = d.gpow[k] * (double)d.rewards[sj];
+      ret = ret + term;
+    }
+    ++ns;                                          // :98
+    if (d.dones[sj]) mask = 0;                     // :104-108
+  }
+  o.returns[i] = (float)ret;
+  o.nsteps[i] = (float)ns;
+  o.masks[i] = (float)mask;
+  o.actions[i] = (int64_t)d.actions[sl];
+  if (o.policy) for (int a = 0; a < d.A; ++a) o.policy[i * d.A + a] = d.policy[sl * d.A + a];
+  if (o.weights) o.weights[i] = weight[b];
+  if (o.loss_indices) {
+    if (r < d.P) { o.loss_indices[2 * i] = -1; o.loss_indices[2 * i + 1] = -1; }
+    else { o.loss_indices[2 * i] = (int64_t)(e + d.env_base); o.loss_indices[2 * i + 1] = off; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// update_losses (prioritized_replay_history.py:243-279)
+// ---------------------------------------------------------------------------
+// The reference walks (index, loss) pairs in order, so when a transition occurs
+// twice the LAST pair wins.  Pass 1 elects that winner per transition with a
+// 64-bit atomicMax of (call epoch << 32 | pair index); pass 2 lets only the
+// winner write, and every pair marks the overlapped sequences it touches.
+__global__ void __launch_bounds__(256)
+k_loss_stamp(Dev d, int64_t n, const int64_t* __restrict__ idx, uint64_t epoch) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t env_id = idx[2 * i], off = idx[2 * i + 1];
+  if (env_id < 0) return;
+  int32_t e = (int32_t)(env_id - d.env_base);
+  if (e < 0 || e >= d.E || off < d.first[e] || off >= d.count[e]) return;   // :254 evicted meanwhile
+  atomicMax(&d.stamp[slot_of(d, e, off)], (unsigned long long)((epoch << 32) | (uint64_t)i));
+}
+__global__ void __launch_bounds__(256)
+k_loss_write(Dev d, int64_t n, const int64_t* __restrict__ idx, const float* __restrict__ losses, uint64_t epoch) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int64_t env_id = idx[2 * i], off = idx[2 * i + 1];
+  if (env_id < 0) return;
+  int32_t e = (int32_t)(env_id - d.env_base);
+  if (e < 0 || e >= d.E) return;
+  const int64_t first = d.first[e];
+  if (off < first || off >= d.count[e]) return;
+  int64_t sl = slot_of(d, e, off);
+  if (d.stamp[sl] == (unsigned long long)((epoch << 32) | (uint64_t)i))
+    d.loss[sl] = fabsf(losses[i]) + (float)d.eps;          // :263 abs(np.float32) + eps -> float32
+  int64_t base = off - off % d.gap;                        // :267-274
+  while (base + d.T > off && base >= first) {
+    int32_t s = d.prio_index[slot_of(d, e, base)];
+    if (s >= 0) d.flag[s] = 1;
+    base -= d.gap;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_recalc_flagged(Dev d) {
+  int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= d.n_slots || !d.flag[s]) return;
+  d.flag[s] = 0;
+  int32_t e = d.slot_env[s];
+  if (e < 0) return;
+  TV p = priority_of(d, e, d.slot_base[s]);
+  d.tv[d.cap + s] = p.v; d.tk[d.cap + s] = p.k;
+  if (d.tmin) d.tmin[d.cap + s] = p.v;
+  int at = atomicAdd(d.dirty_count, 1);
+  d.dirty[at] = (int32_t)s;
+}
+
+__global__ void k_copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace mirl
+
+// ===========================================================================
+// C-ABI
+// ===========================================================================
+using namespace mirl;
+
+namespace mirl {
+std::string& last_error_ref() { static thread_local std::string e; return e; }
+}
+
+struct mirl_replay {
+  Book book;
+  Dev d;
+  StagingRing staging;
+  Plan plan;
+  int overlapped = 0, rows = 0;
+  uint64_t epoch = 1, sample_calls = 0;
+  double* w_tmp = nullptr; int64_t w_tmp_cap = 0;
+  std::vector<void*> allocs;
+  double* gpow_dev = nullptr;
+  int gather_nt = 0;
+};
+
+extern "C" const char* mirl_last_error(void) { return last_error_ref().c_str(); }
+
+extern "C" int mirl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+template <class T>
+static int dev_alloc(mirl_replay* h, T** p, size_t count, int fill_byte = 0) {
+  size_t bytes = count * sizeof(T);
+  if (!bytes) { *p = nullptr; return MIRL_OK; }
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) return fail(MIRL_ERR_HIP, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  h->allocs.push_back((void*)*p);
+  MIRL_HIP(hipMemset(*p, fill_byte, bytes));
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_destroy(mirl_replay* h) {
+  if (!h) return MIRL_OK;
+  (void)hipDeviceSynchronize();
+  h->staging.destroy();
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** out) {
+  if (!cfg || !out) return fail(MIRL_ERR_ARG, "null argument");
+  if (mirl_device_count() <= 0) return fail(MIRL_ERR_NOGPU, "no HIP device visible: librltime_hip needs an AMD GPU (there is no CPU fallback)");
+  if (cfg->frame_bytes <= 0) return fail(MIRL_ERR_ARG, "frame_bytes must be > 0");
+  MIRL_HIP(hipSetDevice(cfg->device));
+  mirl_replay* h = new mirl_replay();
+  int rc = h->book.init(*cfg);
+  if (rc) { last_error_ref() = h->book.err; delete h; return rc; }
+  rc = h->staging.init();
+  if (rc) { delete h; return rc; }
+  Book& bk = h->book;
+  Dev& d = h->d;
+  memset(&d, 0, sizeof(d));
+  d.E = bk.E; d.F = cfg->frame_bytes; d.Fp = (int32_t)align_up((size_t)cfg->frame_bytes, 16);
+  d.X = cfg->extra_f32; d.S = cfg->state_f32; d.A = cfg->policy_f32; d.has_init = cfg->has_initials;
+  d.per = bk.per; d.T = bk.T; d.P = bk.P; d.N = bk.N; d.L = bk.L; d.gap = bk.gap; d.env_base = cfg->env_base;
+  d.avoid_xing = cfg->avoid_episode_crossing; d.C = bk.C; d.cap = bk.tree_cap; d.n_slots = bk.n_slots;
+  d.alpha = cfg->alpha; d.mwf = cfg->max_weight_factor; d.eps = cfg->eps;
+  int lg = 0; while ((1LL << lg) < d.cap) ++lg; d.log2cap = lg;
+  const size_t slots = (size_t)d.E * (size_t)d.C;
+#define TRY(x) do { int _r = (x); if (_r) { mirl_replay_destroy(h); return _r; } } while (0)
+  TRY(dev_alloc(h, &d.frames, slots * (size_t)d.Fp));
+  TRY(dev_alloc(h, &d.extra, slots * (size_t)d.X));
+  TRY(dev_alloc(h, &d.state, slots * (size_t)d.S));
+  if (d.has_init) TRY(dev_alloc(h, &d.initials, slots));
+  TRY(dev_alloc(h, &d.actions, slots));
+  TRY(dev_alloc(h, &d.policy, slots * (size_t)d.A));
+  TRY(dev_alloc(h, &d.rewards, slots));
+  TRY(dev_alloc(h, &d.dones, slots));
+  TRY(dev_alloc(h, &d.first, (size_t)d.E));
+  TRY(dev_alloc(h, &d.count, (size_t)d.E));
+  {
+    std::vector<double> g((size_t)d.N);
+    for (int k = 0; k < d.N; ++k) g[(size_t)k] = pow(cfg->gamma, (double)k);   // float.__pow__ -> libm pow
+    TRY(dev_alloc(h, &h->gpow_dev, (size_t)d.N));
+    hipError_t e = hipMemcpy(h->gpow_dev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { mirl_replay_destroy(h); return fail(MIRL_ERR_HIP, hipGetErrorString(e)); }
+    d.gpow = h->gpow_dev;
+  }
+  if (d.per) {
+    TRY(dev_alloc(h, &d.loss, slots));
+    TRY(dev_alloc(h, &d.prio_index, slots, 0xFF));
+    TRY(dev_alloc(h, &d.stamp, slots));
+    TRY(dev_alloc(h, &d.tv, (size_t)(2 * d.cap)));          // neutral 0.0 (python float) == all-zero bytes, kind KW == 0
+    TRY(dev_alloc(h, &d.tk, (size_t)(2 * d.cap)));
+    if (cfg->global_importance_scaling) {
+      TRY(dev_alloc(h, &d.tmin, (size_t)(2 * d.cap)));
+      std::vector<double> inf((size_t)(2 * d.cap), INFINITY);
+      hipError_t e = hipMemcpy(d.tmin, inf.data(), inf.size() * sizeof(double), hipMemcpyHostToDevice);
+      if (e != hipSuccess) { mirl_replay_destroy(h); return fail(MIRL_ERR_HIP, hipGetErrorString(e)); }
+    }
+    TRY(dev_alloc(h, &d.slot_env, (size_t)d.n_slots, 0xFF));
+    TRY(dev_alloc(h, &d.slot_base, (size_t)d.n_slots, 0xFF));
+    TRY(dev_alloc(h, &d.flag, (size_t)d.n_slots));
+    TRY(dev_alloc(h, &d.dirty, (size_t)d.n_slots + 16));
+    TRY(dev_alloc(h, &d.dirty_count, 1));
+  }
+#undef TRY
+  // history.py:245-246: overlapped stacking iff nstep_target < L and every
+  // sampled step has its full n-step; the latter can only fail when windows
+  // are shifted to the ring end by avoid_episode_crossing.
+  h->overlapped = (bk.N < bk.L && !cfg->avoid_episode_crossing) ? 1 : 0;
+  h->rows = h->overlapped ? bk.L + bk.N : 2 * bk.L;
+  const char* nt = getenv("MIRL_GATHER_NT");
+  h->gather_nt = nt ? atoi(nt) : 0;
+  MIRL_HIP(hipDeviceSynchronize());
+  *out = h;
+  return MIRL_OK;
+}
+
+static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s_env, const int64_t* s_off,
+                   int K, int32_t row_bytes, int64_t stride, hipStream_t st) {
+  if (!row_bytes || !src) return MIRL_OK;
+  int vec = (row_bytes % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)src) % 16 == 0);
+  int chunks = vec ? row_bytes / 16 : row_bytes;
+  int gx = (chunks + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_scatter_rows, dim3(gx, K), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)ring, s_env, s_off,
+                     h->d.C, row_bytes, stride, vec);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream) {
+  if (!h || !in || in->count <= 0) return fail(MIRL_ERR_ARG, "bad ingest arguments");
+  hipStream_t st = (hipStream_t)stream;
+  Dev& d = h->d;
+  const int K = in->count;
+  if (!in->frames || !in->actions || !in->rewards || !in->dones) return fail(MIRL_ERR_ARG, "frames/actions/rewards/dones are required");
+  if ((d.X && !in->extra) || (d.S && !in->state) || (d.has_init && !in->initials) || (d.A && !in->policy))
+    return fail(MIRL_ERR_ARG, "a configured payload array is NULL");
+  int rc = h->book.ingest(K, in->env_ids_host, h->plan);
+  if (rc) { last_error_ref() = h->book.err; return rc; }
+  Plan& p = h->plan;
+  // pack the plan: [sample_env i32][sample_off i64][table][env][leaf]
+  size_t o_env = 0, o_off = align_up(o_env + sizeof(int32_t) * K, 16), o_tab = align_up(o_off + sizeof(int64_t) * K, 16);
+  size_t o_eop = align_up(o_tab + sizeof(TableOp) * p.table_ops.size(), 16);
+  size_t o_lop = align_up(o_eop + sizeof(EnvOp) * p.env_ops.size(), 16);
+  size_t total = align_up(o_lop + sizeof(LeafOp) * p.leaf_ops.size(), 16);
+  char *hb, *db;
+  rc = h->staging.acquire(total, &hb, &db); if (rc) return rc;
+  memcpy(hb + o_env, p.sample_env.data(), sizeof(int32_t) * K);
+  memcpy(hb + o_off, p.sample_off.data(), sizeof(int64_t) * K);
+  if (!p.table_ops.empty()) memcpy(hb + o_tab, p.table_ops.data(), sizeof(TableOp) * p.table_ops.size());
+  if (!p.env_ops.empty()) memcpy(hb + o_eop, p.env_ops.data(), sizeof(EnvOp) * p.env_ops.size());
+  if (!p.leaf_ops.empty()) memcpy(hb + o_lop, p.leaf_ops.data(), sizeof(LeafOp) * p.leaf_ops.size());
+  rc = h->staging.upload(total, st); if (rc) return rc;
+  const int32_t* s_env = (const int32_t*)(db + o_env);
+  const int64_t* s_off = (const int64_t*)(db + o_off);
+  rc = scatter(h, in->frames, d.frames, s_env, s_off, K, d.F, d.Fp, st); if (rc) return rc;
+  rc = scatter(h, in->extra, d.extra, s_env, s_off, K, d.X * 4, (int64_t)d.X * 4, st); if (rc) return rc;
+  rc = scatter(h, in->state, d.state, s_env, s_off, K, d.S * 4, (int64_t)d.S * 4, st); if (rc) return rc;
+  rc = scatter(h, in->policy, d.policy, s_env, s_off, K, d.A * 4, (int64_t)d.A * 4, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_ingest_scalars, dim3((K + 255) / 256), dim3(256), 0, st, d, K, s_env, s_off,
+                     in->initials, in->actions, in->rewards, in->dones);
+  MIRL_LAUNCH_CHECK();
+  int nt = (int)p.table_ops.size(), ne = (int)p.env_ops.size(), nl = d.per ? (int)p.leaf_ops.size() : 0;
+  if (!d.per) nt = 0;
+  int nmax = nt > ne ? nt : ne; nmax = nl > nmax ? nl : nmax;
+  if (nmax) {
+    hipLaunchKernelGGL(k_plan_apply, dim3((nmax + 255) / 256), dim3(256), 0, st, d, nt, (const TableOp*)(db + o_tab),
+                       ne, (const EnvOp*)(db + o_eop), nl, (const LeafOp*)(db + o_lop));
+    MIRL_LAUNCH_CHECK();
+  }
+  if (nl) { hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d); MIRL_LAUNCH_CHECK(); }
+  return h->staging.mark(st);
+}
+
+extern "C" int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_envs, int64_t* out) {
+  if (!h || !out) return fail(MIRL_ERR_ARG, "null argument");
+  *out = h->book.needed_feed_count(mbatch, num_envs);
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_uniform_total(mirl_replay* h, int64_t* total) {
+  if (!h || !total) return fail(MIRL_ERR_ARG, "null argument");
+  *total = h->book.uniform_total();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_state_rows(mirl_replay* h, int32_t* rows, int32_t* overlapped) {
+  if (!h) return fail(MIRL_ERR_ARG, "null argument");
+  if (rows) *rows = h->rows;
+  if (overlapped) *overlapped = h->overlapped;
+  return MIRL_OK;
+}
+
+static double anneal_beta(const mirl_replay_config& c, double progress) {
+  // general/utils.py:85-103 anneal_value(beta, progress, beta_anneal, 1.0)
+  if (progress > 1.0) progress = 1.0;
+  if (c.beta_anneal_mode == 0) return c.beta;
+  double target = c.beta_anneal_mode == 1 ? 1.0 : c.beta_anneal_to;
+  return c.beta + (target - c.beta) * progress;
+}
+
+extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progress, const void* rng_host, uint64_t seed,
+                                  int32_t* slot, int32_t* env, int64_t* start, float* weight, void* stream) {
+  if (!h || B <= 0 || !slot || !env || !start || !weight) return fail(MIRL_ERR_ARG, "bad sample arguments");
+  hipStream_t st = (hipStream_t)stream;
+  Book& bk = h->book;
+  Dev& d = h->d;
+  int rc = bk.charge_quota(B);                       // replay_history.py:176-181 (even when None is returned)
+  if (rc) { last_error_ref() = bk.err; return rc; }
+  ++h->sample_calls;
+  if (d.per) {
+    if (train_progress < 0) return fail(MIRL_ERR_ARG, "train_progress must be >= 0 (general/utils.py:97)");
+    if (bk.active < B) {                             // prioritized_replay_history.py:295-299
+      if (bk.total_items() >= bk.cfg.size) return fail(MIRL_ERR_STATE, "buffer full but fewer sequences than mbatch (prioritized_replay_history.py:298)");
+      return MIRL_NEED_MORE;
+    }
+    const double* u_dev = nullptr;
+    if (rng_host) {
+      char *hb, *db;
+      rc = h->staging.acquire(sizeof(double) * B, &hb, &db); if (rc) return rc;
+      memcpy(hb, rng_host, sizeof(double) * B);
+      rc = h->staging.upload(sizeof(double) * B, st); if (rc) return rc;
+      u_dev = (const double*)db;
+    }
+    if (h->w_tmp_cap < B) {
+      double* p = nullptr;
+      MIRL_HIP(hipMalloc((void**)&p, sizeof(double) * (size_t)B));
+      h->allocs.push_back(p); h->w_tmp = p; h->w_tmp_cap = B;
+    }
+    double beta = anneal_beta(bk.cfg, train_progress);
+    hipLaunchKernelGGL(k_per_sample, dim3(1), dim3(1024), 0, st, d, (int)B, u_dev, seed, h->sample_calls,
+                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, weight, h->w_tmp);
+    MIRL_LAUNCH_CHECK();
+    if (rng_host) return h->staging.mark(st);
+    return MIRL_OK;
+  }
+  // uniform
+  std::vector<int64_t> cum; std::vector<int32_t> envs;
+  int64_t tot = 0;
+  for (int32_t e : bk.env_order) { int64_t a = (bk.count[e] - bk.first[e]) - (bk.L + bk.N - 1); if (a > 0) { tot += a; cum.push_back(tot); envs.push_back(e); } }
+  if (tot < B) {                                       // replay_history.py:110-114
+    if (bk.total_items() >= bk.cfg.size) return fail(MIRL_ERR_STATE, "buffer full but not enough start positions (replay_history.py:113)");
+    return MIRL_NEED_MORE;
+  }
+  size_t nc = cum.size();
+  size_t o_cum = 0, o_env = align_up(o_cum + sizeof(int64_t) * nc, 16), o_pick = align_up(o_env + sizeof(int32_t) * nc, 16);
+  size_t total = o_pick + (rng_host ? sizeof(int64_t) * (size_t)B : 0);
+  char *hb, *db;
+  rc = h->staging.acquire(total, &hb, &db); if (rc) return rc;
+  memcpy(hb + o_cum, cum.data(), sizeof(int64_t) * nc);
+  memcpy(hb + o_env, envs.data(), sizeof(int32_t) * nc);
+  if (rng_host) {
+    const int64_t* picks = (const int64_t*)rng_host;
+    for (int i = 0; i < B; ++i) if (picks[i] < 0 || picks[i] >= tot) return fail(MIRL_ERR_ARG, "uniform pick out of range");
+    memcpy(hb + o_pick, picks, sizeof(int64_t) * (size_t)B);
+  }
+  rc = h->staging.upload(total, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_uniform_sample, dim3((B + 255) / 256), dim3(256), 0, st, d, (int)B,
+                     rng_host ? (const int64_t*)(db + o_pick) : (const int64_t*)nullptr, seed, h->sample_calls,
+                     (int)nc, (const int64_t*)(db + o_cum), (const int32_t*)(db + o_env), slot, env, start, weight);
+  MIRL_LAUNCH_CHECK();
+  return h->staging.mark(st);
+}
+
+static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_t* env, const int64_t* start,
+                       int B, int32_t row_bytes, int64_t ring_stride, hipStream_t st) {
+  if (!row_bytes || !out) return MIRL_OK;
+  int vec = (row_bytes % 16 == 0) && (ring_stride % 16 == 0) && (((uintptr_t)out) % 16 == 0);
+  int64_t blocks = (int64_t)h->rows * B;
+  if (h->gather_nt)
+    hipLaunchKernelGGL(k_gather_rows<1>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                       env, start, B, h->overlapped, row_bytes, ring_stride, vec);
+  else
+    hipLaunchKernelGGL(k_gather_rows<0>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                       env, start, B, h->overlapped, row_bytes, ring_stride, vec);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env, const int64_t* start, const float* weight,
+                                  const mirl_batch* out, void* stream) {
+  if (!h || B <= 0 || !env || !start || !out) return fail(MIRL_ERR_ARG, "bad gather arguments");
+  if (!out->frames || !out->returns || !out->nsteps || !out->masks || !out->actions) return fail(MIRL_ERR_ARG, "frames/returns/nsteps/masks/actions outputs are required");
+  if (out->weights && !weight) return fail(MIRL_ERR_ARG, "weights output requested without a weight input");
+  hipStream_t st = (hipStream_t)stream;
+  Dev& d = h->d;
+  int rc;
+  rc = gather_leaf(h, d.frames, out->frames, env, start, B, d.F, d.Fp, st); if (rc) return rc;
+  rc = gather_leaf(h, d.extra, out->extra, env, start, B, d.X * 4, (int64_t)d.X * 4, st); if (rc) return rc;
+  rc = gather_leaf(h, d.state, out->state, env, start, B, d.S * 4, (int64_t)d.S * 4, st); if (rc) return rc;
+  mirl_batch o = *out;
+  if (!d.has_init) o.initials = nullptr;
+  if (!d.A) o.policy = nullptr;
+  int rows = h->rows > d.L ? h->rows : d.L;
+  int64_t n = (int64_t)rows * B;
+  hipLaunchKernelGGL(k_gather_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, (int)B, h->rows, h->overlapped,
+                     env, start, weight, o);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_update_losses(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, void* stream) {
+  if (!h) return fail(MIRL_ERR_ARG, "null handle");
+  if (!h->d.per || count <= 0) return MIRL_OK;           // history.py:332-335 no-op for non-prioritized buffers
+  if (!indices || !losses) return fail(MIRL_ERR_ARG, "null indices/losses");
+  if (count >= (1LL << 32)) return fail(MIRL_ERR_ARG, "too many loss rows");
+  hipStream_t st = (hipStream_t)stream;
+  Dev& d = h->d;
+  uint64_t epoch = h->epoch++;
+  unsigned g = (unsigned)((count + 255) / 256);
+  hipLaunchKernelGGL(k_loss_stamp, dim3(g), dim3(256), 0, st, d, count, indices, epoch);
+  MIRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_loss_write, dim3(g), dim3(256), 0, st, d, count, indices, losses, epoch);
+  MIRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_recalc_flagged, dim3((unsigned)((d.n_slots + 255) / 256)), dim3(256), 0, st, d);
+  MIRL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+// ---- introspection ---------------------------------------------------------
+extern "C" int mirl_replay_stats(mirl_replay* h, int64_t* total_items, int64_t* active, int64_t* quota, int64_t* cap, int64_t* n_slots) {
+  if (!h) return fail(MIRL_ERR_ARG, "null handle");
+  if (total_items) *total_items = h->book.total_items();
+  if (active) *active = h->book.active;
+  if (quota) *quota = h->book.quota;
+  if (cap) *cap = h->book.tree_cap;
+  if (n_slots) *n_slots = h->book.n_slots;
+  return MIRL_OK;
+}
+extern "C" int mirl_replay_env_meta(mirl_replay* h, int64_t* first_host, int64_t* count_host) {
+  if (!h) return fail(MIRL_ERR_ARG, "null handle");
+  // read back the DEVICE mirrors so tests see what the kernels see
+  MIRL_HIP(hipDeviceSynchronize());
+  if (first_host) MIRL_HIP(hipMemcpy(first_host, h->d.first, sizeof(int64_t) * h->d.E, hipMemcpyDeviceToHost));
+  if (count_host) MIRL_HIP(hipMemcpy(count_host, h->d.count, sizeof(int64_t) * h->d.E, hipMemcpyDeviceToHost));
+  return MIRL_OK;
+}
+extern "C" int mirl_replay_free_slots(mirl_replay* h, int32_t* slots_host, int64_t* n) {
+  if (!h || !n) return fail(MIRL_ERR_ARG, "null argument");
+  *n = h->book.free_slots.size();
+  if (slots_host) for (int64_t i = 0; i < *n; ++i) slots_host[i] = h->book.free_slots.at(i);
+  return MIRL_OK;
+}
+extern "C" int mirl_replay_slot_table(mirl_replay* h, int32_t* slot_env_host, int64_t* slot_base_host) {
+  if (!h || !h->d.per) return fail(MIRL_ERR_ARG, "not a prioritized replay");
+  MIRL_HIP(hipDeviceSynchronize());
+  if (slot_env_host) MIRL_HIP(hipMemcpy(slot_env_host, h->d.slot_env, sizeof(int32_t) * h->d.n_slots, hipMemcpyDeviceToHost));
+  if (slot_base_host) MIRL_HIP(hipMemcpy(slot_base_host, h->d.slot_base, sizeof(int64_t) * h->d.n_slots, hipMemcpyDeviceToHost));
+  return MIRL_OK;
+}
+extern "C" int mirl_replay_tree_nodes(mirl_replay* h, double* value_host, uint8_t* kind_host, double* min_host) {
+  if (!h || !h->d.per) return fail(MIRL_ERR_ARG, "not a prioritized replay");
+  MIRL_HIP(hipDeviceSynchronize());
+  size_t n = (size_t)(2 * h->d.cap);
+  if (value_host) MIRL_HIP(hipMemcpy(value_host, h->d.tv, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (kind_host) MIRL_HIP(hipMemcpy(kind_host, h->d.tk, n, hipMemcpyDeviceToHost));
+  if (min_host && h->d.tmin) MIRL_HIP(hipMemcpy(min_host, h->d.tmin, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return MIRL_OK;
+}
+extern "C" int mirl_replay_tree_set_leaves(mirl_replay* h, int64_t n, const double* value_host, const uint8_t* kind_host, void* stream) {
+  if (!h || !h->d.per || n < 0 || n > h->d.cap) return fail(MIRL_ERR_ARG, "bad tree_set_leaves arguments");
+  hipStream_t st = (hipStream_t)stream;
+  size_t o_k = align_up(sizeof(double) * (size_t)n, 16);
+  char *hb, *db;
+  int rc = h->staging.acquire(o_k + (size_t)n, &hb, &db); if (rc) return rc;
+  memcpy(hb, value_host, sizeof(double) * (size_t)n);
+  memcpy(hb + o_k, kind_host, (size_t)n);
+  rc = h->staging.upload(o_k + (size_t)n, st); if (rc) return rc;
+  if (n) { hipLaunchKernelGGL(k_set_leaves, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->d, n, (const double*)db, (const uint8_t*)(db + o_k)); MIRL_LAUNCH_CHECK(); }
+  for (int lvl = h->d.log2cap - 1; lvl >= 0; --lvl) {
+    int64_t lo = 1LL << lvl, hi = 2LL << lvl;
+    hipLaunchKernelGGL(k_tree_level, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, st, h->d, lo, hi);
+    MIRL_LAUNCH_CHECK();
+  }
+  return h->staging.mark(st);
+}
+extern "C" int mirl_replay_tree_find(mirl_replay* h, int32_t B, const double* uniforms_host, int64_t* idx_host, void* stream) {
+  if (!h || !h->d.per || B <= 0) return fail(MIRL_ERR_ARG, "bad tree_find arguments");
+  hipStream_t st = (hipStream_t)stream;
+  size_t o_i = align_up(sizeof(double) * (size_t)B, 16);
+  char *hb, *db;
+  int rc = h->staging.acquire(o_i + sizeof(int64_t) * (size_t)B, &hb, &db); if (rc) return rc;
+  memcpy(hb, uniforms_host, sizeof(double) * (size_t)B);
+  rc = h->staging.upload(sizeof(double) * (size_t)B, st); if (rc) return rc;
+  hipLaunchKernelGGL(k_tree_find, dim3((B + 255) / 256), dim3(256), 0, st, h->d, (int)B, (const double*)db, (int64_t*)(db + o_i));
+  MIRL_LAUNCH_CHECK();
+  MIRL_HIP(hipMemcpyAsync(idx_host, db + o_i, sizeof(int64_t) * (size_t)B, hipMemcpyDeviceToHost, st));
+  MIRL_HIP(hipStreamSynchronize(st));
+  return h->staging.mark(st);
+}
+extern "C" int mirl_replay_losses_peek(mirl_replay* h, int32_t env_local, int64_t offset, int32_t n, float* out_host) {
+  if (!h || !h->d.per || env_local < 0 || env_local >= h->d.E || n <= 0) return fail(MIRL_ERR_ARG, "bad losses_peek arguments");
+  MIRL_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < n; ++i) {
+    int64_t sl = (int64_t)env_local * h->d.C + (offset + i) % h->d.C;
+    MIRL_HIP(hipMemcpy(out_host + i, h->d.loss + sl, sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return MIRL_OK;
+}
+
+extern "C" int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
+  if (!dst || !src || bytes <= 0 || (bytes % 16) || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return fail(MIRL_ERR_ARG, "copy needs 16-byte aligned pointers and size");
+  hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, bytes / 16);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+// ---- host-only hooks ---------------------------------------------------------
+struct mirl_book { Book book; Plan plan; };
+
+extern "C" int mirl_book_create(const mirl_replay_config* cfg, mirl_book** out) {
+  if (!cfg || !out) return fail(MIRL_ERR_ARG, "null argument");
+  mirl_book* b = new mirl_book();
+  int rc = b->book.init(*cfg);
+  if (rc) { last_error_ref() = b->book.err; delete b; return rc; }
+  *out = b;
+  return MIRL_OK;
+}
+extern "C" int mirl_book_destroy(mirl_book* b) { delete b; return MIRL_OK; }
+extern "C" int mirl_book_ingest(mirl_book* b, int32_t count, const int32_t* env_ids_host) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  int rc = b->book.ingest(count, env_ids_host, b->plan);
+  if (rc) last_error_ref() = b->book.err;
+  return rc;
+}
+extern "C" int mirl_book_stats(mirl_book* b, int64_t* total_items, int64_t* active, int64_t* quota, int64_t* cap, int64_t* n_slots) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  if (total_items) *total_items = b->book.total_items();
+  if (active) *active = b->book.active;
+  if (quota) *quota = b->book.quota;
+  if (cap) *cap = b->book.tree_cap;
+  if (n_slots) *n_slots = b->book.n_slots;
+  return MIRL_OK;
+}
+extern "C" int mirl_book_env_meta(mirl_book* b, int64_t* first_host, int64_t* count_host) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  for (int e = 0; e < b->book.E; ++e) { if (first_host) first_host[e] = b->book.first[e]; if (count_host) count_host[e] = b->book.count[e]; }
+  return MIRL_OK;
+}
+extern "C" int mirl_book_free_slots(mirl_book* b, int32_t* slots_host, int64_t* n) {
+  if (!b || !n) return fail(MIRL_ERR_ARG, "null argument");
+  *n = b->book.free_slots.size();
+  if (slots_host) for (int64_t i = 0; i < *n; ++i) slots_host[i] = b->book.free_slots.at(i);
+  return MIRL_OK;
+}
+extern "C" int mirl_book_slot_table(mirl_book* b, int32_t* slot_env_host, int64_t* slot_base_host) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  for (int64_t i = 0; i < b->book.n_slots; ++i) { if (slot_env_host) slot_env_host[i] = b->book.slot_env[(size_t)i]; if (slot_base_host) slot_base_host[i] = b->book.slot_base[(size_t)i]; }
+  return MIRL_OK;
+}
+extern "C" int mirl_book_needed_feed_count(mirl_book* b, int32_t mbatch, int32_t num_envs, int64_t* out) {
+  if (!b || !out) return fail(MIRL_ERR_ARG, "null argument");
+  *out = b->book.needed_feed_count(mbatch, num_envs);
+  return MIRL_OK;
+}
+extern "C" int mirl_book_charge_quota(mirl_book* b, int32_t mbatch) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  int rc = b->book.charge_quota(mbatch);
+  if (rc) last_error_ref() = b->book.err;
+  return rc;
+}
+extern "C" int mirl_book_uniform_total(mirl_book* b, int64_t* total) {
+  if (!b || !total) return fail(MIRL_ERR_ARG, "null argument");
+  *total = b->book.uniform_total();
+  return MIRL_OK;
+}
+extern "C" int mirl_book_uniform_map(mirl_book* b, int32_t mbatch, const int64_t* picks_host, int32_t* env_host, int64_t* start_host) {
+  if (!b) return fail(MIRL_ERR_ARG, "null handle");
+  return b->book.uniform_map(mbatch, picks_host, env_host, start_host);
+}
+
+extern "C" int mirl_emul_build_tree(int64_t cap, const double* lv, const uint8_t* lk, double* nv, uint8_t* nk) {
+  for (int64_t i = 0; i < cap; ++i) { nv[cap + i] = lv[i]; nk[cap + i] = lk[i]; }
+  nv[0] = 0; nk[0] = 0;
+  for (int64_t node = cap - 1; node >= 1; --node) {
+    TV a{nv[2 * node], nk[2 * node]}, b{nv[2 * node + 1], nk[2 * node + 1]};
+    TV r = tadd(a, b);
+    nv[node] = r.v; nk[node] = r.k;
+  }
+  return MIRL_OK;
+}
+extern "C" int mirl_emul_find(int64_t cap, const double* nv, const uint8_t* nk, int32_t B, const double* u, int64_t* idx) {
+  TV total{nv[1], nk[1]};
+  for (int i = 0; i < B; ++i) idx[i] = tagged_descend(nv, nk, cap, stratum_mass(total, B, i, u[i]));
+  return MIRL_OK;
+}
+extern "C" int mirl_emul_seq_priority(int32_t T, double alpha, double mwf, const float* loss_slots, double* value, uint8_t* kind) {
+  PrioParams p{T, alpha, mwf};
+  auto g = [&](int t) -> float { return loss_slots[t]; };
+  TV r = seq_priority(g, p);
+  *value = r.v; *kind = r.k;
+  return MIRL_OK;
+}

@@ -1,0 +1,484 @@
+"""Device-resident replay history buffers with the reference's plugin API.
+
+Mirrors (same constructor arguments, method names, return structure and error
+behaviour; paths relative to the reference root):
+
+  * rltime/history/history.py:8-335                      History
+  * rltime/history/replay_history.py:6-184               ReplayHistoryBuffer
+  * rltime/history/prioritized_replay_history.py:10-356  PrioritizedReplayHistoryBuffer
+
+but every transition lives in HBM inside a ``librltime_hip`` replay shard and
+``update`` / ``get_train_data`` / ``update_losses`` only enqueue HIP kernels on
+the current stream (include/mirl.h).  Nothing here computes on the host: there
+is no CPU fallback, and construction fails loudly without a GPU.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * batches are torch tensors already on the device with the dtypes the trainer
+    would see after ``make_tensor`` (models/torch/utils.py:95-123): uint8 frames,
+    everything else float32, except ``actions`` / ``loss_indices`` (int64);
+  * ``update`` wants whole vector steps (one transition per env), which is what
+    the synchronous actor emits (acting/actor.py:97-149);
+  * ``state_store`` is accepted and ignored: the replay *is* the device store
+    the reference's StateStore hook was meant for (history.py:34-37).
+"""
+import ctypes as C
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import lib, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+class _Layout:
+    """Shape of one stored ``next_state`` pytree (sequential.py:128-146:
+    {"x": obs | tuple(obs, extra...), "layer{i}_state": {} | {hx, cx, initials}})."""
+
+    def __init__(self, state):
+        x = state["x"]
+        if isinstance(x, (tuple, list)):
+            self.tuple_obs = True
+            self.frame_shape = tuple(x[0].shape)
+            self.extra_shapes = [tuple(np.shape(v)) for v in x[1:]]
+        else:
+            self.tuple_obs = False
+            self.frame_shape = tuple(x.shape)
+            self.extra_shapes = []
+        self.frame_bytes = int(np.prod(self.frame_shape))
+        self.extra_sizes = [int(np.prod(s)) for s in self.extra_shapes]
+        self.extra_f32 = sum(self.extra_sizes)
+        self.layer_keys = [k for k in state if k != "x"]
+        self.recurrent = []      # (key, [(name, size), ...])
+        self.has_initials = False
+        self.state_f32 = 0
+        for k in self.layer_keys:
+            sub = state[k]
+            if not sub:
+                continue
+            fields = []
+            for name, v in sub.items():
+                if name == "initials":
+                    self.has_initials = True
+                    continue
+                n = int(np.prod(np.shape(v)))
+                fields.append((name, n, tuple(np.shape(v))))
+                self.state_f32 += n
+            self.recurrent.append((k, fields))
+
+
+class History:
+    """history.py:8-59 — argument handling shared by the device buffers."""
+
+    def __init__(self, nstep_target, nstep_train, prefix_steps=0,
+                 discount_function=None, state_store=None, gamma=None):
+        self.nstep_target = nstep_target
+        self.nstep_train = nstep_train
+        self.prefix_steps = prefix_steps
+        assert (nstep_target == 1 or discount_function is not None
+                or gamma is not None), \
+            "History buffer must get a 'discount_function' for nstep_target>1"
+        self.discount_function = discount_function
+        if gamma is None:
+            gamma = getattr(discount_function, "gamma", None)
+        if gamma is None:
+            if nstep_target > 1:
+                raise ValueError(
+                    "the device replay evaluates the n-step return on the GPU "
+                    "and needs the discount as a number: pass gamma=... or a "
+                    "discount_function carrying a .gamma attribute "
+                    "(rltime_amd trainers do)")
+            gamma = 1.0
+        self.gamma = float(gamma)
+        self.state_store = state_store
+
+
+class ReplayHistoryBuffer(History):
+    """replay_history.py:6-184 on the device.  Uniform sampling."""
+
+    _MODE = _lib.MODE_UNIFORM
+
+    def __init__(self, size, train_frequency, avoid_episode_crossing=False,
+                 num_envs=None, env_base=None, device=None, device_rng=False,
+                 keep_policy_outputs=True, env_ring_slack=0, **kwargs):
+        super().__init__(**kwargs)
+        _lib.require_gpu()
+        self.size = size
+        self.train_frequency = train_frequency
+        self.avoid_episode_crossing = avoid_episode_crossing
+        self._num_envs = num_envs
+        self._env_base = env_base
+        self._device_index = torch.cuda.current_device() if device is None \
+            else torch.device(device).index
+        self.device = torch.device("cuda", self._device_index)
+        self._device_rng = device_rng
+        self._keep_policy = keep_policy_outputs
+        self._slack = env_ring_slack
+        self._h = None
+        self._layout = None
+        self._seed = 0x5EED
+        self._policy_f32 = 0
+
+    # -- lifetime ----------------------------------------------------------
+    def _per_config(self, cfg):
+        pass
+
+    def _create(self, layout, num_envs, env_base, policy_f32):
+        self._layout = layout
+        self._num_envs = num_envs
+        self._env_base = env_base
+        self._policy_f32 = policy_f32
+        cfg = _lib.ReplayConfig(
+            size=self.size, num_envs=num_envs, env_base=env_base,
+            frame_bytes=layout.frame_bytes, extra_f32=layout.extra_f32,
+            state_f32=layout.state_f32, has_initials=int(layout.has_initials),
+            policy_f32=policy_f32, nstep_train=self.nstep_train,
+            prefix_steps=self.prefix_steps, nstep_target=self.nstep_target,
+            gamma=self.gamma, mode=self._MODE,
+            train_frequency=int(self.train_frequency or 0),
+            avoid_episode_crossing=int(bool(self.avoid_episode_crossing)),
+            overlap=_lib.INT32_MIN, alpha=0.6, beta=0.4, eps=1e-6,
+            max_weight_factor=0.9, beta_anneal_mode=0, beta_anneal_to=1.0,
+            global_importance_scaling=0, env_ring_slack=self._slack,
+            device=self._device_index)
+        self._per_config(cfg)
+        h = C.c_void_p()
+        check(lib.mirl_replay_create(C.byref(cfg), C.byref(h)), "mirl_replay_create")
+        self._h = h
+        rows, ov = C.c_int32(), C.c_int32()
+        check(lib.mirl_replay_state_rows(h, C.byref(rows), C.byref(ov)))
+        self._rows, self._overlapped = rows.value, bool(ov.value)
+
+    def close(self):
+        if self._h is not None:
+            lib.mirl_replay_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ingest --------------------------------------------------------------
+    def update(self, new_samples):
+        """history.py:123-176.  ``new_samples`` is the list of per-env sample
+        dicts the actor emits (acting_interface.py:83-90); it is regrouped into
+        vector steps and written with one batched device copy each."""
+        samples = list(new_samples)
+        i = 0
+        while i < len(samples):
+            seen = set()
+            j = i
+            while j < len(samples) and samples[j]["env_id"] not in seen:
+                seen.add(samples[j]["env_id"])
+                j += 1
+            self._update_vector_step(samples[i:j])
+            i = j
+        return {}
+
+    def _update_vector_step(self, chunk):
+        first = chunk[0]["next_state"]
+        if self._h is None:
+            layout = _Layout(first)
+            ids = sorted(s["env_id"] for s in chunk)
+            base = ids[0] if self._env_base is None else self._env_base
+            n = (ids[-1] - base + 1) if self._num_envs is None else self._num_envs
+            qv = chunk[0]["policy_output"].get("qvalues")
+            pf = int(np.prod(np.shape(qv))) if (qv is not None and self._keep_policy) else 0
+            self._create(layout, n, base, pf)
+        lay = self._layout
+        env_ids = np.array([s["env_id"] for s in chunk], dtype=np.int32)
+
+        def stack(getter, dtype):
+            return torch.from_numpy(np.ascontiguousarray(
+                np.stack([np.asarray(getter(s)) for s in chunk]).astype(dtype, copy=False)))
+
+        def obs(s):
+            x = s["next_state"]["x"]
+            return x[0] if lay.tuple_obs else x
+
+        fields = {"frames": stack(obs, np.uint8)}
+        if lay.extra_f32:
+            fields["extra"] = stack(lambda s: np.concatenate(
+                [np.asarray(v, dtype=np.float32).reshape(-1)
+                 for v in s["next_state"]["x"][1:]]), np.float32)
+        if lay.state_f32:
+            fields["state"] = stack(lambda s: np.concatenate(
+                [np.asarray(s["next_state"][k][name], dtype=np.float32).reshape(-1)
+                 for k, fl in lay.recurrent for name, _, _ in fl]), np.float32)
+        if lay.has_initials:
+            key = lay.recurrent[0][0] if lay.recurrent else lay.layer_keys[0]
+            fields["initials"] = stack(
+                lambda s: s["next_state"][key]["initials"], np.float32)
+        fields["actions"] = stack(lambda s: s["policy_output"]["actions"], np.int32)
+        if self._policy_f32:
+            fields["policy"] = stack(
+                lambda s: np.asarray(s["policy_output"]["qvalues"]).reshape(-1), np.float32)
+        fields["rewards"] = stack(lambda s: s["reward"], np.float32)
+        fields["dones"] = stack(lambda s: s["done"], np.uint8)
+        dev = {k: v.to(self.device, non_blocking=False) for k, v in fields.items()}
+        self.update_batch(env_ids=env_ids, **dev)
+
+    def update_batch(self, frames, actions, rewards, dones, extra=None, state=None,
+                     initials=None, policy=None, env_ids=None):
+        """Fast path: one vector step of device tensors with leading dim K
+        (frames u8 [K, ...], actions i32 [K], rewards f32 [K], dones u8 [K],
+        extra/state/policy f32 [K, n], initials f32 [K]).  ``env_ids`` (host
+        int32 array) defaults to env_base .. env_base+K-1."""
+        if self._h is None:
+            raise _lib.MirlError(
+                "update_batch before the shard exists: call configure() first")
+        K = int(frames.shape[0])
+        keep = [frames, actions, rewards, dones, extra, state, initials, policy]
+        for t in keep:
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous()
+        assert frames.dtype == torch.uint8 and actions.dtype == torch.int32
+        assert rewards.dtype == torch.float32 and dones.dtype == torch.uint8
+        ids = None
+        if env_ids is not None:
+            ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        arg = _lib.Ingest(
+            count=K, env_ids_host=_lib.np_ptr(ids) if ids is not None else None,
+            frames=_ptr(frames), extra=_ptr(extra), state=_ptr(state),
+            initials=_ptr(initials), actions=_ptr(actions), policy=_ptr(policy),
+            rewards=_ptr(rewards), dones=_ptr(dones))
+        check(lib.mirl_replay_ingest(self._h, C.byref(arg), _stream()), "mirl_replay_ingest")
+        # the kernels read the payload asynchronously: tie its lifetime to the stream
+        s = torch.cuda.current_stream()
+        for t in keep:
+            if t is not None:
+                t.record_stream(s)
+
+    def configure(self, example_state, num_envs, env_base=0, policy_f32=0):
+        """Create the shard up-front from one example ``next_state`` pytree
+        (the reference learns shapes from the first sample; the fast path needs
+        them before the first update_batch)."""
+        if self._h is None:
+            self._create(_Layout(example_state), num_envs, env_base, policy_f32)
+
+    # -- sampling --------------------------------------------------------------
+    def needed_feed_count(self, mbatch_size, num_envs):
+        """replay_history.py:62-75."""
+        if self._h is None:
+            if not self.train_frequency:
+                return 0
+            return num_envs       # quota is 0 -> max(int(0), num_envs)
+        out = C.c_int64()
+        check(lib.mirl_replay_needed_feed_count(self._h, mbatch_size, num_envs, C.byref(out)))
+        return None if out.value < 0 else out.value
+
+    def _draw_host_rng(self, mbatch):
+        """replay_history.py:118 — np.random.choice(total_available, mbatch),
+        only evaluated when there are enough start positions (:110-114)."""
+        total = C.c_int64()
+        check(lib.mirl_replay_uniform_total(self._h, C.byref(total)))
+        if total.value < mbatch:
+            return None
+        return np.ascontiguousarray(np.random.choice(total.value, mbatch), dtype=np.int64)
+
+    def get_train_data(self, mbatch_size, train_progress=None):
+        """replay_history.py:173-184 -> history.py:203-286.  Returns None when
+        more samples must be fed first."""
+        if self._h is None:
+            return None
+        B = mbatch_size
+        rng = None if self._device_rng else self._draw_host_rng(B)
+        dev = self.device
+        slot = torch.empty(B, dtype=torch.int32, device=dev)
+        env = torch.empty(B, dtype=torch.int32, device=dev)
+        start = torch.empty(B, dtype=torch.int64, device=dev)
+        weight = torch.empty(B, dtype=torch.float32, device=dev)
+        self._seed += 1
+        rc = check(lib.mirl_replay_sample(
+            self._h, B, -1.0 if train_progress is None else float(train_progress),
+            _lib.np_ptr(rng) if rng is not None else None, self._seed,
+            _ptr(slot), _ptr(env), _ptr(start), _ptr(weight), _stream()),
+            "mirl_replay_sample")
+        if rc == _lib.MIRL_NEED_MORE:
+            return None
+        self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight}
+        return self._gather(B, env, start, weight)
+
+    def _gather(self, B, env, start, weight):
+        lay, dev = self._layout, self.device
+        L = self.nstep_train + self.prefix_steps
+        R = self._rows
+        per = self._MODE == _lib.MODE_PER
+        frames = torch.empty((R, B) + lay.frame_shape, dtype=torch.uint8, device=dev)
+        extra = torch.empty((R, B, lay.extra_f32), dtype=torch.float32, device=dev) \
+            if lay.extra_f32 else None
+        state = torch.empty((R, B, lay.state_f32), dtype=torch.float32, device=dev) \
+            if lay.state_f32 else None
+        initials = torch.empty((R, B), dtype=torch.float32, device=dev) \
+            if lay.has_initials else None
+        returns = torch.empty((L, B), dtype=torch.float32, device=dev)
+        nsteps = torch.empty((L, B), dtype=torch.float32, device=dev)
+        masks = torch.empty((L, B), dtype=torch.float32, device=dev)
+        actions = torch.empty((L, B), dtype=torch.int64, device=dev)
+        policy = torch.empty((L, B, self._policy_f32), dtype=torch.float32, device=dev) \
+            if self._policy_f32 else None
+        weights = torch.empty((L, B), dtype=torch.float32, device=dev) if per else None
+        loss_idx = torch.empty((L, B, 2), dtype=torch.int64, device=dev) if per else None
+        out = _lib.Batch(
+            frames=_ptr(frames), extra=_ptr(extra), state=_ptr(state),
+            initials=_ptr(initials), returns=_ptr(returns), nsteps=_ptr(nsteps),
+            masks=_ptr(masks), actions=_ptr(actions), policy=_ptr(policy),
+            weights=_ptr(weights), loss_indices=_ptr(loss_idx))
+        check(lib.mirl_replay_gather(
+            self._h, B, _ptr(env), _ptr(start), _ptr(weight), C.byref(out), _stream()),
+            "mirl_replay_gather")
+
+        if self._overlapped:
+            n = self.nstep_target
+            cut_s = lambda t: t[:L]           # noqa: E731  history.py:262-263
+            cut_t = lambda t: t[n:]           # noqa: E731  history.py:264-265
+        else:
+            cut_s = lambda t: t[:L]           # noqa: E731
+            cut_t = lambda t: t[L:]           # noqa: E731
+
+        def build(cut):
+            x = cut(frames)
+            if lay.tuple_obs:
+                parts, at = [x], 0
+                for size, shape in zip(lay.extra_sizes, lay.extra_shapes):
+                    e = cut(extra)[..., at:at + size]
+                    parts.append(e.reshape(e.shape[:2] + shape))
+                    at += size
+                x = tuple(parts)
+            tree = {"x": x}
+            at = 0
+            rec = dict(lay.recurrent)
+            for k in lay.layer_keys:
+                if k not in rec:
+                    tree[k] = {}
+                    continue
+                sub = {}
+                for name, size, shape in rec[k]:
+                    v = cut(state)[..., at:at + size]
+                    sub[name] = v.reshape(v.shape[:2] + shape) if shape != (size,) else v
+                    at += size
+                if lay.has_initials:
+                    sub["initials"] = cut(initials)
+                tree[k] = sub
+            return tree
+
+        batch = {
+            "returns": returns, "nsteps": nsteps, "target_masks": masks,
+            "policy_outputs": {"actions": actions},
+            "states": build(cut_s), "target_states": build(cut_t),
+        }
+        if policy is not None:
+            batch["policy_outputs"]["qvalues"] = policy
+        batch["extra_data"] = {"importance_weights": weights,
+                               "loss_indices": loss_idx} if per else {}
+        return batch
+
+    def update_losses(self, indices, losses):
+        """history.py:332-335 — nothing to do for uniform replay."""
+
+    # -- introspection (tests / logging) ----------------------------------------
+    def stats(self):
+        v = [C.c_int64() for _ in range(5)]
+        check(lib.mirl_replay_stats(self._h, *[C.byref(x) for x in v]))
+        keys = ("total_items", "active_sequences", "train_quota",
+                "tree_capacity", "n_slots")
+        return dict(zip(keys, (x.value for x in v)))
+
+    @property
+    def train_quota(self):
+        return self.stats()["train_quota"] if self._h is not None else 0
+
+
+class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
+    """prioritized_replay_history.py:10-356 on the device: sum-tree (and
+    min-tree) in HBM, stratified descent with the reference's exact NumPy-2
+    scalar promotion (csrc/np_emul.h), overlapped-sequence priorities."""
+
+    _MODE = _lib.MODE_PER
+
+    def __init__(self, alpha=0.6, beta=0.4, beta_anneal=False, eps=1e-6,
+                 overlap=None, max_weight_factor=0.9,
+                 global_importance_scaling=False, **kwargs):
+        super().__init__(**kwargs)
+        self._alpha, self._beta, self._beta_anneal = alpha, beta, beta_anneal
+        self._eps, self._overlap = eps, overlap
+        self._max_weight_factor = max_weight_factor
+        self._global_importance_scaling = global_importance_scaling
+        if overlap is not None and overlap >= 0:
+            assert overlap < self.nstep_train, "Overlap must be < nstep_train"
+
+    def _per_config(self, cfg):
+        cfg.alpha, cfg.beta, cfg.eps = self._alpha, self._beta, self._eps
+        cfg.max_weight_factor = self._max_weight_factor
+        cfg.overlap = _lib.INT32_MIN if self._overlap is None else int(self._overlap)
+        cfg.global_importance_scaling = int(bool(self._global_importance_scaling))
+        if self._beta_anneal is False or self._beta_anneal is None:
+            cfg.beta_anneal_mode = 0
+        elif self._beta_anneal is True:
+            cfg.beta_anneal_mode = 1
+        else:
+            cfg.beta_anneal_mode, cfg.beta_anneal_to = 2, float(self._beta_anneal)
+
+    def _draw_host_rng(self, mbatch):
+        """prioritized_replay_history.py:238 — random.random() once per stratum,
+        consumed even when the call then returns None (:284 precedes :295)."""
+        return np.array([random.random() for _ in range(mbatch)], dtype=np.float64)
+
+    def update_losses(self, indices, losses):
+        """prioritized_replay_history.py:243-279.  ``indices`` (M, 2) int64 and
+        ``losses`` (M,) float32; device tensors stay on the device (no host
+        round trip), numpy arrays are uploaded."""
+        if self._h is None:
+            return
+        if not isinstance(indices, torch.Tensor):
+            indices = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int64))
+        if not isinstance(losses, torch.Tensor):
+            losses = torch.from_numpy(np.ascontiguousarray(losses, dtype=np.float32))
+        indices = indices.to(self.device, torch.int64).reshape(-1, 2).contiguous()
+        losses = losses.detach().to(self.device, torch.float32).reshape(-1).contiguous()
+        assert indices.shape[0] == losses.shape[0]
+        check(lib.mirl_replay_update_losses(
+            self._h, losses.shape[0], _ptr(indices), _ptr(losses), _stream()),
+            "mirl_replay_update_losses")
+        s = torch.cuda.current_stream()
+        indices.record_stream(s)
+        losses.record_stream(s)
+
+    # -- test hooks ----------------------------------------------------------------
+    def tree_nodes(self):
+        cap = self.stats()["tree_capacity"]
+        v = np.zeros(2 * cap, dtype=np.float64)
+        k = np.zeros(2 * cap, dtype=np.uint8)
+        m = np.zeros(2 * cap, dtype=np.float64)
+        check(lib.mirl_replay_tree_nodes(self._h, _lib.np_ptr(v), _lib.np_ptr(k), _lib.np_ptr(m)))
+        return v, k, m
+
+    def free_slots(self):
+        n = C.c_int64()
+        check(lib.mirl_replay_free_slots(self._h, None, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(lib.mirl_replay_free_slots(self._h, _lib.np_ptr(out), C.byref(n)))
+        return out[:n.value]
+
+    def slot_table(self):
+        n = self.stats()["n_slots"]
+        e = np.zeros(n, dtype=np.int32)
+        b = np.zeros(n, dtype=np.int64)
+        check(lib.mirl_replay_slot_table(self._h, _lib.np_ptr(e), _lib.np_ptr(b)))
+        return e, b
+
+    def env_meta(self):
+        f = np.zeros(self._num_envs, dtype=np.int64)
+        c = np.zeros(self._num_envs, dtype=np.int64)
+        check(lib.mirl_replay_env_meta(self._h, _lib.np_ptr(f), _lib.np_ptr(c)))
+        return f, c
