@@ -6,6 +6,11 @@ raises — there is no Python/torch fallback for any op it exports.
 import ctypes as C
 import os
 
+# torch must load ITS bundled HIP runtime (libamdhip64.so.7) before our library
+# is dlopen'ed: both carry the same SONAME, the first one loaded wins for the
+# whole process, and torch cannot see the GPU through the system copy.
+import torch  # noqa: F401  (order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librltime_hip.so")
 

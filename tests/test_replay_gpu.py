@@ -1,0 +1,211 @@
+"""GPU parity: the HIP replay shard (through the C-ABI, via the reference-API
+classes in rltime_amd.history) against the golden vectors of the unmodified
+reference and against the oracle on larger seeded streams.
+
+Bars: bit-exact for frames / recurrent state / actions / nsteps / masks /
+returns / loss indices / sampled windows / tree kinds / free-list order;
+importance weights rtol 2e-6; leaf priorities <= 1 ulp (pow)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests import scenario
+from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(cfg, gamma):
+    from rltime_amd.history import ReplayHistoryBuffer, PrioritizedReplayHistoryBuffer
+    cls = PrioritizedReplayHistoryBuffer if cfg["mode"] == "per" else ReplayHistoryBuffer
+    return cls(**cfg["hist"], gamma=gamma)
+
+
+def _per_state(buf):
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    if not isinstance(buf, PrioritizedReplayHistoryBuffer) or buf._h is None:
+        return None
+    v, k, _ = buf.tree_nodes()
+    cap = len(v) // 2
+    se, sb = buf.slot_table()
+    first, _ = buf.env_meta()
+    se = se.astype(np.int64)
+    se[se >= 0] += buf._env_base
+    return {"leaf_val": v[cap:], "leaf_kind": k[cap:], "leaf_exact": False,
+            "free_slots": buf.free_slots().astype(np.int64),
+            "slot_env": se, "slot_base": sb, "env_first": first}
+
+
+def _check_windows(tag, buf, gold, last_batch):
+    if str(gold[tag + ".op"]) != "draw" or bool(gold[tag + ".is_none"]):
+        return
+    win = gold[tag + ".windows"]
+    env = buf.last_sample["env"].cpu().numpy().astype(np.int64) + buf._env_base
+    start = buf.last_sample["start"].cpu().numpy()
+    first = np.zeros(buf._num_envs, dtype=np.int64)
+    from rltime_amd._lib import lib, check, np_ptr
+    check(lib.mirl_replay_env_meta(buf._h, np_ptr(first), None))
+    assert np.array_equal(env, win[:, 0]), tag
+    assert np.array_equal(start - first[env - buf._env_base], win[:, 1]), tag
+    if (tag + ".slots") in gold.files:
+        assert np.array_equal(buf.last_sample["slot"].cpu().numpy(), gold[tag + ".slots"]), tag
+
+
+@pytest.mark.parametrize("name", scenario.SCENARIOS)
+def test_golden_scenarios(name):
+    scenario.run(name, _make, exact_dtypes=False, per_state=_per_state,
+                 on_round=_check_windows)
+
+
+def test_tree_cases_on_device():
+    """Injected leaves (value + scalar kind) -> every inner node and every
+    stratified index bit-identical to the reference's list-of-scalars tree."""
+    import json, os
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    from rltime_amd._lib import lib, check, np_ptr
+    d = np.load(os.path.join(scenario.GOLDEN, "tree_cases.npz"))
+    for case in json.loads(str(d["cases"])):
+        cap = int(d[case + ".capacity"])
+        buf = PrioritizedReplayHistoryBuffer(
+            size=cap, train_frequency=4, nstep_target=1, nstep_train=1, gamma=0.99)
+        buf.configure({"x": np.zeros((16,), np.uint8)}, num_envs=1)
+        lv = np.ascontiguousarray(d[case + ".leaf_val"])
+        lk = np.ascontiguousarray(d[case + ".leaf_kind"])
+        check(lib.mirl_replay_tree_set_leaves(buf._h, cap, np_ptr(lv), np_ptr(lk), None))
+        v, k, _ = buf.tree_nodes()
+        assert np.array_equal(v[1:], d[case + ".node_val"][1:]), case
+        assert np.array_equal(k[1:], d[case + ".node_kind"][1:]), case
+        for B in (8, 32):
+            us = np.ascontiguousarray(d["%s.B%d.uniforms" % (case, B)])
+            idx = np.zeros(B, dtype=np.int64)
+            check(lib.mirl_replay_tree_find(buf._h, B, np_ptr(us), np_ptr(idx), None))
+            assert np.array_equal(idx, d["%s.B%d.index" % (case, B)]), (case, B)
+        buf.close()
+
+
+def _run_pair(seed, E, steps_script, hist, gamma, per, spec_kw, B):
+    """Same seeded stream through the oracle and the HIP buffer."""
+    from oracle import replay as orc
+    from rltime_amd.history import ReplayHistoryBuffer, PrioritizedReplayHistoryBuffer
+    spec = StreamSpec(seed=seed, num_envs=E, **spec_kw)
+    o_cls = orc.OraclePrioritizedReplay if per else orc.OracleReplay
+    d_cls = PrioritizedReplayHistoryBuffer if per else ReplayHistoryBuffer
+    ora = o_cls(**hist, discount_function=orc.make_discount(gamma))
+    dev = d_cls(**hist, gamma=gamma)
+    step_no = 0
+    mism = {"leaf": 0, "leaves": 0, "draws": 0}
+    for op in steps_script:
+        if op[0] == "feed":
+            for st in vector_steps(spec, op[1], start_step=step_no):
+                ora.update(as_reference_samples(spec, st))
+                dev.update(as_reference_samples(spec, st))
+            step_no += op[1]
+            continue
+        s = op[1]
+        random.seed(s); np.random.seed(s)
+        a = ora.get_train_data(B, train_progress=op[2])
+        random.seed(s); np.random.seed(s)
+        b = dev.get_train_data(B, train_progress=op[2])
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        mism["draws"] += 1
+        fa = scenario.flatten("", a, {})
+        fb = {k: scenario.to_numpy(v) for k, v in scenario.flatten("", b, {}).items()}
+        assert set(fa) == set(fb)
+        for key, w in fa.items():
+            g = fb[key]
+            if key.endswith("importance_weights"):
+                np.testing.assert_allclose(g, w.astype(np.float32), rtol=scenario.WEIGHT_RTOL, err_msg=key)
+            elif key.endswith("actions") or key.endswith("loss_indices"):
+                assert np.array_equal(g, w), key
+            else:
+                assert np.array_equal(g, scenario.make_tensor_dtype(w)), key
+        if per:
+            P = hist["prefix_steps"]
+            idx = a["extra_data"]["loss_indices"][P:].reshape(-1, 2)
+            rng = np.random.RandomState(s + 7)
+            losses = (rng.randn(idx.shape[0]) * 0.8).astype(np.float32)
+            ora.update_losses(idx, losses)
+            # device path takes device tensors straight from the batch
+            dev.update_losses(b["extra_data"]["loss_indices"][P:].reshape(-1, 2),
+                              torch.from_numpy(losses).cuda())
+            v, k, _ = dev.tree_nodes()
+            cap = ora.tree.capacity
+            want = np.array([float(x) for x in ora.tree.nodes[cap:]])
+            from tests.golden.streams import scalar_kind
+            wk = np.array([scalar_kind(x) for x in ora.tree.nodes[cap:]], dtype=np.uint8)
+            assert np.array_equal(k[cap:], wk)
+            scenario.check_leaf_values(v[cap:], want, wk, "seed%d" % s, False)
+            mism["leaf"] += int(np.sum(v[cap:] != want))
+            mism["leaves"] += len(want)
+            assert np.array_equal(dev.free_slots(), np.array(list(ora.free_slots)))
+    dev.close()
+    return mism
+
+
+def test_uniform_stream_vs_oracle_atari_frames():
+    """84x84x4 frames, T=1 DQN shape, ring wrap and eviction."""
+    _run_pair(21, 8, [("feed", 40), ("draw", 1, None), ("feed", 200), ("draw", 2, None),
+                      ("feed", 77), ("draw", 3, None)],
+              dict(size=1024, train_frequency=0, nstep_target=1, nstep_train=1, prefix_steps=0),
+              0.99, False, dict(frame_shape=(4, 84, 84), n_actions=6, done_prob=0.01), 64)
+
+
+def test_per_sequences_vs_oracle_recurrent():
+    """R2D2-shaped: T=16, burn-in 8, n=2, overlap 8, LSTM state 2x32, eviction;
+    losses fed back 6 times.  Sampled windows must stay identical throughout."""
+    m = _run_pair(22, 6, [("feed", 60), ("draw", 11, 0.0), ("feed", 30), ("draw", 12, 0.2),
+                          ("draw", 13, 0.3), ("feed", 120), ("draw", 14, 0.5), ("feed", 45),
+                          ("draw", 15, 0.8), ("draw", 16, 1.0)],
+                  dict(size=900, train_frequency=4, nstep_target=2, nstep_train=16, prefix_steps=8,
+                       alpha=0.9, beta=0.6, max_weight_factor=0.9),
+                  0.997, True, dict(frame_shape=(1, 20, 20), lstm_units=32, n_actions=6, done_prob=0.03), 16)
+    assert m["draws"] == 6
+    print("PER leaves differing from the reference by 1 ulp: %d / %d" % (m["leaf"], m["leaves"]))
+
+
+def test_per_t1_vs_oracle_rainbow_shape():
+    """Rainbow-shaped: T=1, n=3, f32 tree regime, beta anneal, many updates."""
+    script = [("feed", 50)]
+    for i in range(12):
+        script += [("draw", 100 + i, i / 12.0), ("feed", 9)]
+    _run_pair(23, 16, script,
+              dict(size=2048, train_frequency=4, nstep_target=3, nstep_train=1, prefix_steps=0,
+                   alpha=0.6, beta=0.4, beta_anneal=True),
+              0.99, True, dict(frame_shape=(4, 21, 21), n_actions=6, done_prob=0.02), 128)
+
+
+def test_duplicate_loss_rows_last_wins():
+    """update_losses walks its rows in order (prioritized_replay_history.py:252):
+    a transition reported twice keeps the LAST loss."""
+    from oracle import replay as orc
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    spec = StreamSpec(seed=5, num_envs=2, frame_shape=(1, 4, 4), done_prob=0.0)
+    hist = dict(size=64, train_frequency=4, nstep_target=1, nstep_train=4, prefix_steps=0, alpha=0.7)
+    ora = orc.OraclePrioritizedReplay(**hist, discount_function=orc.make_discount(0.9))
+    dev = PrioritizedReplayHistoryBuffer(**hist, gamma=0.9)
+    for st in vector_steps(spec, 20):
+        ora.update(as_reference_samples(spec, st)); dev.update(as_reference_samples(spec, st))
+    idx = np.array([[0, 4], [0, 5], [0, 4], [1, 8], [0, 5], [0, 4], [-1, -1], [1, 9]], dtype=np.int64)
+    losses = np.array([0.5, -0.25, 2.0, 0.1, 3.5, -0.75, 9.0, 0.3], dtype=np.float32)
+    keep = idx[:, 0] >= 0
+    ora.update_losses(idx[keep], losses[keep])
+    dev.update_losses(idx, losses)
+    out = np.zeros(8, dtype=np.float32)
+    from rltime_amd._lib import lib, check, np_ptr
+    check(lib.mirl_replay_losses_peek(dev._h, 0, 2, 8, np_ptr(out)))
+    want = [ora.rings[0][o]['loss'] for o in range(2, 10)]
+    want = np.array([-1.0 if isinstance(w, float) else w for w in want], dtype=np.float32)
+    assert np.array_equal(out, want)
+    dev.close()
+
+
+def test_no_gpu_fallback_marker():
+    """The product never imports the oracle."""
+    import rltime_amd.history.replay_history as m
+    src = open(m.__file__).read()
+    assert "oracle" not in src
