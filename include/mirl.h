@@ -130,6 +130,11 @@ int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream);
 /* needed_feed_count (replay_history.py:62-75).  *out = -1 for None.           */
 int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_envs, int64_t* out);
 
+/* Overwrite the train quota (replay_history.py:60 `train_quota`): used when a
+ * pre-filled or restored buffer should start from a steady-state balance
+ * instead of owing `size * train_frequency` training.                        */
+int mirl_replay_set_train_quota(mirl_replay* h, int64_t quota);
+
 /* The sampling half of get_train_data (replay_history.py:173-184 quota,
  * :93-140 uniform choice, prioritized_replay_history.py:232-241 stratified
  * descent, :286-329 + :347-354 importance weights).
@@ -144,7 +149,12 @@ int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_en
 int mirl_replay_sample(mirl_replay* h, int32_t mbatch, double train_progress,
                        const void* rng_host, uint64_t seed,
                        int32_t* slot, int32_t* env, int64_t* start, float* weight,
-                       void* stream);
+                       double* stats, void* stream);
+/* `stats` (device, 2 doubles, may be NULL; PER only): [0] = sum of priorities of
+ * this shard's tree, [1] = the un-normalised batch-max weight that `weight` was
+ * divided by.  With the active-sequence count (mirl_replay_stats) this is what
+ * ranks exchange to turn shard-local importance weights into global ones
+ * (rltime_amd/parallel.py).                                                   */
 /* uniform mode helper for the host RNG path: np.random.choice's `a` argument. */
 int mirl_replay_uniform_total(mirl_replay* h, int64_t* total);
 
@@ -164,6 +174,11 @@ int mirl_replay_gather(mirl_replay* h, int32_t mbatch, const int32_t* env,
  * mirl_batch.loss_indices; rows with env_id < 0 are ignored.                   */
 int mirl_replay_update_losses(mirl_replay* h, int64_t count, const int64_t* indices,
                               const float* losses, void* stream);
+
+/* Per-kernel timing of the dominant kernel (the frame gather) with HIP events
+ * on the launch stream: enable, run, then read {launches, total ms}.  Reading
+ * synchronises the device.                                                    */
+int mirl_replay_profile(mirl_replay* h, int32_t enable, int64_t* launches, double* total_ms);
 
 /* ---- introspection / test hooks (host results; these DO synchronise) ------- */
 int mirl_replay_stats(mirl_replay* h, int64_t* total_items, int64_t* active_sequences,

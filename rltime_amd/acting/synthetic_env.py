@@ -1,0 +1,46 @@
+"""Synthetic vectorised Atari-shaped environment: i.i.d. uniform u8 frames
+(channel-first (4,84,84) like the reference's WindowedEnv output,
+env_wrappers/common.py:141-160), rewards in {-1,0,1} with p=(.1,.8,.1), done
+with p=0.002.  Real emulators are CPU code and out of
+scope; the benchmark contract is synthetic data of this shape."""
+import numpy as np
+import torch
+
+from rltime_amd.spaces import Box, Discrete
+
+
+class SyntheticAtariVecEnv:
+    def __init__(self, num_envs, frame_shape=(4, 84, 84), n_actions=6, done_prob=0.002,
+                 reward_probs=(0.1, 0.8, 0.1), device="cuda", seed=0, pool=8):
+        self.num_envs = num_envs
+        self.observation_space = Box(0, 255, frame_shape, np.uint8)
+        self.action_space = Discrete(n_actions)
+        self.device = torch.device(device)
+        self.done_prob = done_prob
+        self._g = torch.Generator(device=self.device).manual_seed(seed)
+        # a small pool of pre-generated frame batches keeps frame synthesis out
+        # of the timed region while every step still moves real bytes
+        self._pool = [torch.randint(0, 256, (num_envs,) + tuple(frame_shape), dtype=torch.uint8,
+                                    device=self.device, generator=self._g) for _ in range(pool)]
+        self._cum = torch.tensor(np.cumsum(reward_probs), device=self.device, dtype=torch.float32)
+        self._t = 0
+        self._ep_reward = torch.zeros(num_envs, device=self.device)
+        self._ep_len = torch.zeros(num_envs, device=self.device)
+
+    def reset(self):
+        return self._pool[0]
+
+    def step_device(self, actions):
+        self._t += 1
+        obs = self._pool[self._t % len(self._pool)]
+        u = torch.rand(2, self.num_envs, device=self.device, generator=self._g)
+        rewards = torch.bucketize(u[0], self._cum).clamp(max=2).float() - 1.0
+        dones = u[1] < self.done_prob
+        return obs, rewards, dones, None
+
+    def step(self, actions):
+        obs, rewards, dones, _ = self.step_device(torch.as_tensor(actions, device=self.device))
+        return obs, rewards.double().cpu().numpy(), dones.cpu().numpy(), [dict() for _ in range(self.num_envs)]
+
+    def close(self):
+        pass

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(1024)
 k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, uint64_t call,
              double active, double beta, int global_scale,
              int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out, int64_t* __restrict__ start_out,
-             float* __restrict__ w_out, double* __restrict__ w_tmp) {
+             float* __restrict__ w_out, double* __restrict__ w_tmp, double* __restrict__ stats) {
   __shared__ double s_tv[MIRL_LDS_NODES];
   __shared__ uint8_t s_tk[MIRL_LDS_NODES];
   __shared__ double s_red[16];
@@ -254,6 +254,7 @@ k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, u
   for (int k = 1; k < 16; ++k) top = s_red[k] > top ? s_red[k] : top;
   if (global_scale) top = pow((d.tmin[1] / total.v) * active, -beta);   // :350-351
   for (int i = threadIdx.x; i < B; i += 1024) w_out[i] = (float)(w_tmp[i] / top);
+  if (stats && threadIdx.x == 0) { stats[0] = total.v; stats[1] = top; }
 }
 
 // test hook: descent only
@@ -468,6 +469,8 @@ struct mirl_replay {
   std::vector<void*> allocs;
   double* gpow_dev = nullptr;
   int gather_nt = 0;
+  int prof = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
 
 extern "C" const char* mirl_last_error(void) { return last_error_ref().c_str(); }
@@ -631,6 +634,12 @@ extern "C" int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int
   return MIRL_OK;
 }
 
+extern "C" int mirl_replay_set_train_quota(mirl_replay* h, int64_t quota) {
+  if (!h) return fail(MIRL_ERR_ARG, "null handle");
+  h->book.quota = quota;
+  return MIRL_OK;
+}
+
 extern "C" int mirl_replay_uniform_total(mirl_replay* h, int64_t* total) {
   if (!h || !total) return fail(MIRL_ERR_ARG, "null argument");
   *total = h->book.uniform_total();
@@ -653,7 +662,7 @@ static double anneal_beta(const mirl_replay_config& c, double progress) {
 }
 
 extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progress, const void* rng_host, uint64_t seed,
-                                  int32_t* slot, int32_t* env, int64_t* start, float* weight, void* stream) {
+                                  int32_t* slot, int32_t* env, int64_t* start, float* weight, double* stats, void* stream) {
   if (!h || B <= 0 || !slot || !env || !start || !weight) return fail(MIRL_ERR_ARG, "bad sample arguments");
   hipStream_t st = (hipStream_t)stream;
   Book& bk = h->book;
@@ -682,7 +691,7 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
     }
     double beta = anneal_beta(bk.cfg, train_progress);
     hipLaunchKernelGGL(k_per_sample, dim3(1), dim3(1024), 0, st, d, (int)B, u_dev, seed, h->sample_calls,
-                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, weight, h->w_tmp);
+                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, weight, h->w_tmp, stats);
     MIRL_LAUNCH_CHECK();
     if (rng_host) return h->staging.mark(st);
     return MIRL_OK;
@@ -720,6 +729,9 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   if (!row_bytes || !out) return MIRL_OK;
   int vec = (row_bytes % 16 == 0) && (ring_stride % 16 == 0) && (((uintptr_t)out) % 16 == 0);
   int64_t blocks = (int64_t)h->rows * B;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = h->prof && ring == (const void*)h->d.frames;
+  if (timed) { MIRL_HIP(hipEventCreate(&e0)); MIRL_HIP(hipEventCreate(&e1)); MIRL_HIP(hipEventRecord(e0, st)); }
   if (h->gather_nt)
     hipLaunchKernelGGL(k_gather_rows<1>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);
@@ -727,6 +739,23 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
     hipLaunchKernelGGL(k_gather_rows<0>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);
   MIRL_LAUNCH_CHECK();
+  if (timed) { MIRL_HIP(hipEventRecord(e1, st)); h->prof_events.push_back(std::make_pair(e0, e1)); }
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_profile(mirl_replay* h, int32_t enable, int64_t* launches, double* total_ms) {
+  if (!h) return fail(MIRL_ERR_ARG, "null handle");
+  MIRL_HIP(hipDeviceSynchronize());
+  double tot = 0.0; int64_t n = 0;
+  for (auto& pr : h->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; ++n; }
+    (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+  }
+  h->prof_events.clear();
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = tot;
+  h->prof = enable;
   return MIRL_OK;
 }
 

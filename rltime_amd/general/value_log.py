@@ -12,6 +12,14 @@ class _Entry:
         self.best = None
 
     def add(self, v):
+        if hasattr(v, "detach") and getattr(v, "is_cuda", False):
+            # device scalar: accumulate on the device, resolve at get() time
+            v = v.detach().float()
+            if self.agg in ("mean", "sum") and not isinstance(self.scope, int):
+                self.dev_total = v if getattr(self, "dev_total", None) is None else self.dev_total + v
+                self.count += 1
+                return
+            v = v.item()
         v = float(v)
         if isinstance(self.scope, int):
             self.values.append(v)
@@ -34,12 +42,16 @@ class _Entry:
         else:
             if not self.count:
                 return None
+            if getattr(self, "dev_total", None) is not None:
+                self.total += float(self.dev_total.item())
+                self.dev_total = None
             r = {"mean": self.total / self.count, "sum": self.total, "max": self.best, "min": self.best}[self.agg]
         return round(r, self.precision) if self.precision is not None else r
 
     def reset_interval(self):
         if self.scope == "interval":
             self.total, self.count, self.best = 0.0, 0, None
+            self.dev_total = None
 
 
 class ValueLog:

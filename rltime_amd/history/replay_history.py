@@ -173,6 +173,19 @@ class ReplayHistoryBuffer(History):
         """history.py:123-176.  ``new_samples`` is the list of per-env sample
         dicts the actor emits (acting_interface.py:83-90); it is regrouped into
         vector steps and written with one batched device copy each."""
+        if hasattr(new_samples, "vector_steps"):        # acting_interface.DeviceSamples
+            if self._h is None:
+                pol = new_samples.vector_steps[0].get("policy")
+                pf = int(pol.shape[1]) if (pol is not None and self._keep_policy) else 0
+                self.configure(new_samples.example_state, new_samples.num_envs,
+                               new_samples.env_base, policy_f32=pf)
+            for step in new_samples.vector_steps:
+                self.update_batch(
+                    step["frames"], step["actions"], step["rewards"], step["dones"],
+                    extra=step.get("extra"), state=step.get("state"),
+                    initials=step.get("initials"),
+                    policy=step.get("policy") if self._policy_f32 else None)
+            return {}
         samples = list(new_samples)
         i = 0
         while i < len(samples):
@@ -277,6 +290,9 @@ class ReplayHistoryBuffer(History):
         check(lib.mirl_replay_needed_feed_count(self._h, mbatch_size, num_envs, C.byref(out)))
         return None if out.value < 0 else out.value
 
+    def _current_beta(self, train_progress):
+        return 0.0
+
     def _draw_host_rng(self, mbatch):
         """replay_history.py:118 — np.random.choice(total_available, mbatch),
         only evaluated when there are enough start positions (:110-114)."""
@@ -298,15 +314,18 @@ class ReplayHistoryBuffer(History):
         env = torch.empty(B, dtype=torch.int32, device=dev)
         start = torch.empty(B, dtype=torch.int64, device=dev)
         weight = torch.empty(B, dtype=torch.float32, device=dev)
+        stats = torch.zeros(2, dtype=torch.float64, device=dev)
         self._seed += 1
         rc = check(lib.mirl_replay_sample(
             self._h, B, -1.0 if train_progress is None else float(train_progress),
             _lib.np_ptr(rng) if rng is not None else None, self._seed,
-            _ptr(slot), _ptr(env), _ptr(start), _ptr(weight), _stream()),
+            _ptr(slot), _ptr(env), _ptr(start), _ptr(weight), _ptr(stats), _stream()),
             "mirl_replay_sample")
         if rc == _lib.MIRL_NEED_MORE:
             return None
-        self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight}
+        self.last_beta = self._current_beta(train_progress)
+        self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight,
+                            "stats": stats}
         return self._gather(B, env, start, weight)
 
     def _gather(self, B, env, start, weight):
@@ -394,9 +413,20 @@ class ReplayHistoryBuffer(History):
                 "tree_capacity", "n_slots")
         return dict(zip(keys, (x.value for x in v)))
 
+    def profile(self, enable):
+        """Frame-gather kernel timing (HIP events on the launch stream):
+        returns (launches, total_ms) accumulated since the last call."""
+        n, ms = C.c_int64(), C.c_double()
+        check(lib.mirl_replay_profile(self._h, int(enable), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     @property
     def train_quota(self):
         return self.stats()["train_quota"] if self._h is not None else 0
+
+    @train_quota.setter
+    def train_quota(self, value):
+        check(lib.mirl_replay_set_train_quota(self._h, int(value)))
 
 
 class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
@@ -428,6 +458,11 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
             cfg.beta_anneal_mode = 1
         else:
             cfg.beta_anneal_mode, cfg.beta_anneal_to = 2, float(self._beta_anneal)
+
+    def _current_beta(self, train_progress):
+        """prioritized_replay_history.py:287-288 (general/utils.py:85-103)."""
+        from rltime_amd.general.utils import anneal_value
+        return anneal_value(self._beta, train_progress or 0.0, self._beta_anneal, 1.0)
 
     def _draw_host_rng(self, mbatch):
         """prioritized_replay_history.py:238 — random.random() once per stratum,

@@ -1,0 +1,158 @@
+"""Model modules: CNN, LSTM, FC (reference rltime/models/torch/modules/
+{base,cnn,lstm,fc}.py).  Same constructor arguments and forward contracts; the
+dense contractions stay PyTorch-ROCm (MIOpen / rocBLAS / hipBLASLt -> MFMA).
+
+MI355X-first differences:
+  * LSTM keeps its running acting state on the device (the reference
+    round-trips it through numpy every acting step, lstm.py:145-147);
+  * the LSTM sequence forward hoists the input projection of all timesteps into
+    one GEMM and keeps only the recurrent GEMM in the time loop.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .utils import conv2d, conv_out_size, init_weight, linear
+
+
+class BaseModule(nn.Module):
+    """modules/base.py:4-13."""
+
+    def get_state(self, initials):
+        return {}
+
+    @staticmethod
+    def is_recurrent():
+        return False
+
+
+class CNN(BaseModule):
+    """modules/cnn.py:9-53: conv+ReLU stack on channel-first input; uint8 input
+    is converted and scaled (1/255) on the device."""
+
+    def __init__(self, inp_shape, layers, scale=1.0 / 255.0):
+        super().__init__()
+        self.scale = scale
+        self.layers = nn.ModuleList()
+        ch = inp_shape[0]
+        h, w = inp_shape[1:]
+        for spec in layers:
+            f, k, s = spec["filters"], spec["kernel"], spec["stride"]
+            self.layers.append(conv2d(ch, f, k, s))
+            h, w = conv_out_size(h, k, s), conv_out_size(w, k, s)
+            ch = f
+        self.out_shape = (ch, h, w)
+
+    def forward(self, x, **kwargs):
+        if self.scale:
+            x = x.float() * self.scale
+        for layer in self.layers:
+            x = F.relu(layer(x))
+        return x
+
+
+class FC(BaseModule):
+    """modules/fc.py:7-41."""
+
+    def __init__(self, inp_shape, fc_size, fc_count=1, batch_norm=False, activation="relu"):
+        super().__init__()
+        self.flat_size = int(np.prod(inp_shape))
+        self.layers = nn.ModuleList()
+        sz = self.flat_size
+        for _ in range(fc_count):
+            block = nn.ModuleList([linear(sz, fc_size)])
+            sz = fc_size
+            if batch_norm:
+                block.append(nn.BatchNorm1d(sz))
+            self.layers.append(block)
+        self.out_shape = (sz,)
+        self.activation = getattr(F, activation)
+
+    def forward(self, x, **kwargs):
+        x = x.reshape(-1, self.flat_size)
+        for block in self.layers:
+            for sub in block:
+                x = sub(x)
+            x = self.activation(x)
+        return x
+
+
+class LSTM(BaseModule):
+    """modules/lstm.py:8-161: LSTMCell time loop with per-step state reset on
+    `initials`, stored state taken from timestep 0 only, multi-sample (IQN before
+    the LSTM) repeat/merge modes."""
+
+    def __init__(self, inp_shape, num_units, multi_sample_merge_mode="inner"):
+        super().__init__()
+        self.inp_size = int(np.prod(inp_shape))
+        self.num_units = num_units
+        assert multi_sample_merge_mode in ("outer", "inner")
+        self.multi_sample_merge_mode = multi_sample_merge_mode
+        self.lstm_cell = nn.LSTMCell(input_size=self.inp_size, hidden_size=num_units)
+        self.out_shape = (num_units,)
+        self.last_state = None
+        init_weight(self.lstm_cell.weight_hh)
+        init_weight(self.lstm_cell.weight_ih)
+
+    def forward(self, x, hx, cx, initials, timesteps):
+        x = x.reshape(-1, self.inp_size)
+        assert hx.shape[1] == self.num_units and cx.shape[1] == self.num_units
+        assert x.shape[0] % hx.shape[0] == 0
+        multi = x.shape[0] // hx.shape[0]
+        batch = x.shape[0] // timesteps
+        # lstm.py:67-70: only the state stored with timestep 0 is consumed
+        hx = hx.reshape(timesteps, batch // multi, self.num_units)[0]
+        cx = cx.reshape(timesteps, batch // multi, self.num_units)[0]
+        assert initials.shape == ((batch * timesteps) // multi,)
+        if multi > 1:
+            initials = initials.repeat_interleave(multi, dim=0)
+        keep = (1 - initials).reshape(timesteps, batch, 1)
+        cell = self.lstm_cell
+        # one GEMM for the input projection of every timestep
+        gx = F.linear(x, cell.weight_ih, cell.bias_ih).reshape(timesteps, batch, -1)
+        out = []
+        inner = self.multi_sample_merge_mode == "inner"
+        for t in range(timesteps):
+            if multi > 1 and (t == 0 or inner):
+                hx = hx.repeat_interleave(multi, dim=0)
+                cx = cx.repeat_interleave(multi, dim=0)
+            hx = hx * keep[t]                     # lstm.py:95-97
+            cx = cx * keep[t]
+            gates = gx[t] + F.linear(hx, cell.weight_hh, cell.bias_hh)
+            i, f, g, o = gates.chunk(4, dim=1)    # torch.nn.LSTMCell gate order
+            cx = torch.sigmoid(f) * cx + torch.sigmoid(i) * torch.tanh(g)
+            hx = torch.sigmoid(o) * torch.tanh(cx)
+            out.append(hx)
+            if multi > 1 and (t == timesteps - 1 or inner):
+                hx = hx.reshape(-1, multi, hx.shape[-1]).mean(1)
+                cx = cx.reshape(-1, multi, cx.shape[-1]).mean(1)
+        self.last_state = (hx.detach(), cx.detach())      # lstm.py:120
+        return torch.cat(out)
+
+    @staticmethod
+    def is_recurrent():
+        return True
+
+    def get_state(self, initials):
+        """lstm.py:131-161: the state to store with the NEXT input — the last
+        output state, zeroed where a new episode starts, plus `initials`.
+        Stays on the model's device."""
+        dev = self.lstm_cell.weight_hh.device
+        if not isinstance(initials, torch.Tensor):
+            initials = torch.as_tensor(np.asarray(initials, dtype=np.float32))
+        initials = initials.to(dev, torch.float32)
+        n = initials.shape[0]
+        if self.last_state is None:
+            assert bool(torch.all(initials != 0)), "first call must be all-initial states"
+            z = torch.zeros((n, self.num_units), device=dev)
+            self.last_state = (z, z.clone())
+        mask = (1 - initials).unsqueeze(-1)
+        hx, cx = self.last_state
+        self.last_state = (hx * mask, cx * mask)
+        assert self.last_state[0].shape[0] == n
+        return {"hx": self.last_state[0], "cx": self.last_state[1], "initials": initials}
+
+
+def get_types():
+    return {"cnn": CNN, "fc": FC, "lstm": LSTM}

@@ -1,0 +1,60 @@
+"""DQNPolicy with dueling support (reference rltime/policies/torch/dqn.py:9-148)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .torch_policy import TorchPolicy
+from rltime_amd.models.torch.utils import linear
+
+
+class DQNPolicy(TorchPolicy):
+    def __init__(self, action_space, dueling=False, dueling_value_layer_hidden_size=None, **kwargs):
+        super().__init__(**kwargs)
+        self.num_actions = action_space.n
+        self.out_layer = linear(self.model.out_size, action_space.n * self._outputs_per_action())
+        if dueling:
+            # dqn.py:50-66: value branch in parallel to the LAST model layer
+            inner = int(np.prod(self.model.get_layer_in_shape(-1)))
+            hidden = dueling_value_layer_hidden_size or int(np.prod(self.model.get_layer_out_shape(-1)))
+            self.value_hidden_layer = linear(inner, hidden)
+            self.value_layer = linear(hidden, self._outputs_per_action())
+        else:
+            self.value_layer = None
+
+    def _outputs_per_action(self):
+        return 1
+
+    def _shape_action_outputs(self, output):
+        return output, 1
+
+    def _process_dueling(self, action_outputs, state_layer):
+        """dqn.py:74-87: V + A - mean_a A."""
+        state_layer = state_layer.reshape(state_layer.shape[0], -1)
+        v = self.value_layer(F.relu(self.value_hidden_layer(state_layer)))
+        v, action_dim = self._shape_action_outputs(v)
+        return v + action_outputs - action_outputs.mean(action_dim, keepdim=True)
+
+    def _predict_postprocess(self, output, model_output):
+        if self.value_layer is not None:
+            output = self._process_dueling(output, model_output["layer_inputs"][-1])
+        return output
+
+    def predict(self, x, timesteps):
+        """dqn.py:101-112."""
+        res = self.model(x, timesteps)
+        output, _ = self._shape_action_outputs(self.out_layer(res["output"]))
+        return self._predict_postprocess(output, res)
+
+    def _actor_predict_postprocess(self, pred):
+        return pred
+
+    def actor_predict(self, inp, timesteps, for_eval=False, as_numpy=True):
+        """dqn.py:132-148.  as_numpy=False keeps actions / qvalues on the device
+        (no host sync) for the device-resident ingest path."""
+        with torch.no_grad():
+            qvalues = self._actor_predict_postprocess(self.predict(inp, timesteps))
+        assert qvalues.dim() == 2
+        if not as_numpy:
+            return {"actions": qvalues.argmax(dim=1), "qvalues": qvalues}
+        q = qvalues.cpu().numpy()
+        return {"actions": np.argmax(q, axis=1), "qvalues": q}

@@ -1,0 +1,41 @@
+"""IQNPolicy (reference rltime/policies/torch/iqn.py:9-131): cosine quantile
+embedding injected before a model layer, tau ~ U(0,1) drawn per forward with
+torch.rand on the policy device (consumption order is part of the parity
+contract)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .dqn import DQNPolicy
+from rltime_amd.models.torch.utils import linear
+
+
+class IQNPolicy(DQNPolicy):
+    def __init__(self, *args, embedding_dim=64, num_sampling_quantiles=32, injection_layer=-1, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.num_sampling_quantiles = num_sampling_quantiles
+        self.embedding_dim = embedding_dim
+        inner_shape = self.model.set_layer_preprocessor(injection_layer, self._apply_quantile_layer)
+        self.quantile_layer = linear(embedding_dim, int(np.prod(inner_shape)))
+        self.register_buffer("embedding_range", torch.arange(1, embedding_dim + 1, dtype=torch.float32))
+
+    def _apply_quantile_layer(self, x):
+        """iqn.py:67-106."""
+        n = self.num_sampling_quantiles
+        batch = x.shape[0]
+        x = x.reshape(batch, -1)
+        xt = x.repeat_interleave(n, dim=0)                         # (batch*n, state) grouped per item
+        quantiles = torch.rand(batch * n, device=self.embedding_range.device)
+        emb = torch.cos(self.embedding_range * np.pi * quantiles.unsqueeze(1))
+        emb = F.relu(self.quantile_layer(emb))
+        return xt * emb, {"quantiles": quantiles}
+
+    def _shape_action_outputs(self, output):
+        return output.reshape(-1, self.num_sampling_quantiles, output.shape[-1]), 2
+
+    def _predict_postprocess(self, output, model_output):
+        return super()._predict_postprocess(output, model_output), model_output["quantiles"]
+
+    def _actor_predict_postprocess(self, pred):
+        assert pred[0].shape[1] == self.num_sampling_quantiles
+        return pred[0].mean(1)

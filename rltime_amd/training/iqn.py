@@ -1,0 +1,37 @@
+"""IQN trainer (reference rltime/training/torch/iqn.py:8-129)."""
+import torch
+
+from .dqn import DQN
+from . import qops
+from rltime_amd.policies.iqn import IQNPolicy
+
+
+class IQN(DQN):
+    @staticmethod
+    def create_policy(**kwargs):
+        return IQNPolicy.create(**kwargs)
+
+    def calc_target_values(self, returns, target_states, target_masks, nsteps, timesteps):
+        """iqn.py:15-52 + torch_trainer.py:124-147.  Two forwards in the
+        reference's order (target net, then the selection net with independent
+        taus) and one fused kernel for mean-argmax / gather / rescale."""
+        with torch.no_grad():
+            z_t = self.target_policy.predict(target_states, timesteps=timesteps)[0]
+            sel = self.policy if self.double_q else self.target_policy
+            z_s = sel.predict(target_states, timesteps=timesteps)[0]
+            mk = self.policy.make_tensor
+            return qops.q_target_iqn(z_t, z_s, mk(returns), mk(nsteps), mk(target_masks),
+                                     self.gamma, self.vf_scale_epsilon)
+
+    def _compute_grads(self, states, targets, policy_outputs, extra_data, timesteps):
+        """iqn.py:54-129."""
+        assert self.loss_mode == "huber", "IQN supports only huber loss"
+        actions = self.policy.make_tensor(policy_outputs["actions"]).long()
+        z, taus = self.policy.predict(states, timesteps)
+        loss, report = qops.iqn_loss(z, taus, actions, targets, self._weights(extra_data),
+                                     self.huber_kappa, timesteps, self.loss_aggregation,
+                                     self.loss_timestep_aggregation)
+        loss.backward()
+        self._report_losses_if_needed(report, extra_data)
+        self.value_log.log("qloss", loss.detach(), group="train")
+        self.value_log.log("td_mean", report.mean(), group="train")

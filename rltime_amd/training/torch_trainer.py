@@ -1,0 +1,72 @@
+"""TorchTrainer (reference rltime/training/torch/torch_trainer.py:6-199):
+optimizer, gradient-norm clipping, the n-step bootstrap target tail."""
+import torch
+
+from .multi_step_trainer import MultiStepTrainer
+from rltime_amd.models.torch.utils import set_lr
+
+
+class TorchTrainer(MultiStepTrainer):
+    def _train(self, clip_grad=None, clip_grad_dynamic_alpha=None, adam_epsilon=1e-8,
+               vf_scale_epsilon=None, apply_initial_lr=False, **kwargs):
+        """torch_trainer.py:9-44.  apply_initial_lr=False mirrors the reference,
+        whose train_init ignores `lr` (Adam starts at 1e-3, SURVEY A-14)."""
+        self.clip_grad = float(clip_grad) if clip_grad is not None else None
+        self.clip_grad_dynamic_alpha = clip_grad_dynamic_alpha
+        self._grad_norm_moving_average = None
+        self.adam_epsilon = adam_epsilon
+        assert vf_scale_epsilon is None or vf_scale_epsilon > 0
+        assert (not vf_scale_epsilon) or (not self.clip_rewards), \
+            "Value function rescaling only makes sense with clip_rewards=False"
+        self.vf_scale_epsilon = vf_scale_epsilon
+        self._apply_initial_lr = apply_initial_lr
+        super()._train(**kwargs)
+
+    def train_init(self, lr):
+        """torch_trainer.py:80-83."""
+        kw = {"lr": lr} if self._apply_initial_lr else {}
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), eps=self.adam_epsilon, **kw)
+
+    def set_lr(self, lr):
+        set_lr(self.optimizer, lr)
+
+    def _compute_grads(self, states, targets, policy_outputs, extra_data, timesteps):
+        raise NotImplementedError
+
+    def _clip_value(self, norm):
+        """torch_trainer.py:153-175: fixed clip or clip_grad x EMA(norm); the EMA
+        lives on the device."""
+        if not self.clip_grad:
+            return None
+        if self.clip_grad_dynamic_alpha is None:
+            return self.clip_grad
+        a = self.clip_grad_dynamic_alpha
+        self._grad_norm_moving_average = norm.detach().clone() if self._grad_norm_moving_average is None \
+            else self._grad_norm_moving_average * a + norm.detach() * (1 - a)
+        self.value_log.log("grad_norm_ma", self._grad_norm_moving_average, group="train")
+        return self._grad_norm_moving_average * self.clip_grad
+
+    def train_batch(self, *args, **kwargs):
+        """torch_trainer.py:177-199.  The norm is one fused device reduction and
+        the clip a device-side scale: no host synchronisation per step (the
+        reference does ~2 x #parameters `.item()` calls, torch_policy.py:70-78)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        self._compute_grads(*args, **kwargs)
+        self._reduce_gradients()
+        params = [p for p in self.policy.parameters() if p.grad is not None]
+        grads = [p.grad for p in params]
+        norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2)), 2)
+        self.value_log.log("grad_norm", norm, group="train")
+        clip = self._clip_value(norm)
+        if clip is not None:
+            coef = torch.clamp(clip / (norm + 1e-6), max=1.0)     # torch.nn.utils.clip_grad_norm_
+            torch._foreach_mul_(grads, coef)
+            self.value_log.log("grad_norm_clipped", norm * coef, group="train")
+        self.optimizer.step()
+
+    def _reduce_gradients(self):
+        """Data-parallel hook: all-reduce the gradients across ranks (RCCL) when
+        a process group is attached (rltime_amd.parallel); no-op on 1 GPU."""
+        dp = getattr(self, "data_parallel", None)
+        if dp is not None:
+            dp.all_reduce_gradients(self.policy)
