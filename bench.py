@@ -116,6 +116,9 @@ class SyntheticFeeder:
     def get_env_count(self):
         return self.envs
 
+    def update_state(self, progress, policy_state=None):
+        pass
+
     def get_samples(self, min_samples):
         iters = (max(1, min_samples) + self.envs - 1) // self.envs
         out = self.cls(self.example, self.envs, self.env_base)

@@ -565,7 +565,7 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   h->overlapped = (bk.N < bk.L && !cfg->avoid_episode_crossing) ? 1 : 0;
   h->rows = h->overlapped ? bk.L + bk.N : 2 * bk.L;
   const char* nt = getenv("MIRL_GATHER_NT");
-  h->gather_nt = nt ? atoi(nt) : 0;
+  h->gather_nt = nt ? atoi(nt) : 1;   // non-temporal loads/stores: +7 % on the frame gather (profiles/)
   MIRL_HIP(hipDeviceSynchronize());
   *out = h;
   return MIRL_OK;

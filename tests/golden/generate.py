@@ -497,10 +497,85 @@ def run_qmath_cases():
     print("qmath cases: %d arrays" % len(out))
 
 
+# --------------------------------------------------------------------------
+# Network boundary: reference policies (tiny shapes) -> outputs for given weights,
+# inputs and torch seed.  Pins the restated PyTorch models/policies
+# (rltime_amd.models / rltime_amd.policies), including checkpoint compatibility
+# (same parameter names) and the burn-in state substitution.
+# --------------------------------------------------------------------------
+def run_model_cases():
+    import io
+    import gym
+    from rltime.policies.torch.iqn import IQNPolicy
+    from rltime.policies.torch.dqn import DQNPolicy
+    from rltime.training.torch.iqn import IQN as RefIQN
+    out = {}
+    cnn = {"type": "cnn", "args": {"layers": [{"filters": 4, "kernel": 4, "stride": 2},
+                                              {"filters": 6, "kernel": 3, "stride": 1}]}}
+    lstm = {"type": "lstm", "args": {"num_units": 8}}
+    fc = {"type": "fc", "args": {"fc_size": 16}}
+    cases = {
+        "iqn_lstm": (IQNPolicy, [cnn, lstm, fc], dict(dueling=True, embedding_dim=8, num_sampling_quantiles=4), True),
+        "dqn_ff": (DQNPolicy, [cnn, fc], dict(dueling=True), False),
+        "iqn_ff": (IQNPolicy, [cnn, fc], dict(dueling=False, embedding_dim=8, num_sampling_quantiles=4), False),
+    }
+    T, B, A = 5, 3, 4
+    obs_space = gym.spaces.Box(0, 255, (2, 12, 12), dtype=np.uint8)
+    for name, (cls, layers, pargs, recurrent) in cases.items():
+        torch.manual_seed(42)
+        pol = cls.create(model_config={"type": "sequential", "args": {"layer_configs": layers}},
+                         observation_space=obs_space, action_space=gym.spaces.Discrete(A), cuda=False, **pargs)
+        f = io.BytesIO()
+        torch.save(pol.state_dict(), f)
+        out[name + ".state_dict"] = np.frombuffer(f.getvalue(), dtype=np.uint8)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randint(0, 256, (T * B, 2, 12, 12), generator=g, dtype=torch.uint8).numpy()
+        state = {"x": x, "layer0_state": {}, "layer%d_state" % (len(layers) - 1): {}}
+        if recurrent:
+            initials = (torch.rand(T * B, generator=g) < 0.3).float().numpy()
+            state["layer1_state"] = {"hx": torch.randn(T * B, 8, generator=g).numpy(),
+                                     "cx": torch.randn(T * B, 8, generator=g).numpy(),
+                                     "initials": initials}
+            out[name + ".hx"], out[name + ".cx"] = state["layer1_state"]["hx"], state["layer1_state"]["cx"]
+            out[name + ".initials"] = initials
+        else:
+            state["layer1_state"] = {}
+        out[name + ".x"] = x
+        torch.manual_seed(77)
+        pred = pol.predict(state, T if recurrent else 1)
+        if isinstance(pred, tuple):
+            out[name + ".pred"], out[name + ".taus"] = pred[0].detach().numpy(), pred[1].numpy()
+        else:
+            out[name + ".pred"] = pred.detach().numpy()
+        torch.manual_seed(78)
+        act = pol.actor_predict(state, T if recurrent else 1)
+        out[name + ".act_actions"], out[name + ".act_qvalues"] = act["actions"], act["qvalues"]
+        if recurrent:
+            out[name + ".last_hx"] = pol.model.layers[1].last_state[0].numpy()
+            # burn-in substitution (multi_step_trainer.py:90-131) on (T,B) shaped data
+            tr = RefIQN.__new__(RefIQN)
+            tr.policy = tr.target_policy = pol
+            tr.value_log = ValueLog()
+            shaped = {"states": {
+                "x": torch.from_numpy(x).view(T, B, 2, 12, 12),
+                "layer0_state": {}, "layer2_state": {},
+                "layer1_state": {k: torch.from_numpy(v.copy()).view((T, B) + v.shape[1:])
+                                 for k, v in state["layer1_state"].items()}},
+                "returns": torch.arange(T * B, dtype=torch.float32).view(T, B)}
+            torch.manual_seed(79)
+            res = tr._burn_in(shaped, 2, do_target_states=False)
+            out[name + ".burn.hx"] = res["states"]["layer1_state"]["hx"].numpy()
+            out[name + ".burn.cx"] = res["states"]["layer1_state"]["cx"].numpy()
+            out[name + ".burn.returns"] = res["returns"].numpy()
+    np.savez_compressed(os.path.join(HERE, "model_cases.npz"), **out)
+    print("model cases: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_tree_cases()
     for name, cfg in SCENARIOS.items():
         run_replay_scenario(name, cfg)
     run_qmath_cases()
+    run_model_cases()
     print("golden fixtures written to", HERE)

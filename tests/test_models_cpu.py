@@ -1,0 +1,85 @@
+"""CPU: the restated PyTorch models / policies (the callee side of the hot
+path) against outputs of the unmodified reference's policies for the same
+weights, inputs and torch seed (tests/golden/model_cases.npz).  Also proves
+reference checkpoints load (identical parameter names).  Tolerance 1e-5: the
+LSTM hoists the input projection out of the time loop, which re-associates one
+fp32 add per gate."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rltime_amd.policies.dqn import DQNPolicy
+from rltime_amd.policies.iqn import IQNPolicy
+from rltime_amd.spaces import Box, Discrete
+from tests import scenario
+
+CNN = {"type": "cnn", "args": {"layers": [{"filters": 4, "kernel": 4, "stride": 2},
+                                          {"filters": 6, "kernel": 3, "stride": 1}]}}
+LSTM = {"type": "lstm", "args": {"num_units": 8}}
+FC = {"type": "fc", "args": {"fc_size": 16}}
+CASES = {
+    "iqn_lstm": (IQNPolicy, [CNN, LSTM, FC], dict(dueling=True, embedding_dim=8, num_sampling_quantiles=4), True),
+    "dqn_ff": (DQNPolicy, [CNN, FC], dict(dueling=True), False),
+    "iqn_ff": (IQNPolicy, [CNN, FC], dict(dueling=False, embedding_dim=8, num_sampling_quantiles=4), False),
+}
+T, B, A = 5, 3, 4
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _policy(d, name):
+    cls, layers, pargs, rec = CASES[name]
+    pol = cls.create(model_config={"type": "sequential", "args": {"layer_configs": layers}},
+                     observation_space=Box(0, 255, (2, 12, 12), np.uint8), action_space=Discrete(A),
+                     cuda=False, **pargs)
+    sd = torch.load(io.BytesIO(d[name + ".state_dict"].tobytes()))
+    assert set(sd) == set(pol.state_dict()), set(sd) ^ set(pol.state_dict())
+    pol.load_state_dict(sd)
+    state = {"x": d[name + ".x"], "layer0_state": {}, "layer%d_state" % (len(layers) - 1): {}}
+    state["layer1_state"] = {"hx": d[name + ".hx"], "cx": d[name + ".cx"],
+                             "initials": d[name + ".initials"]} if rec else {}
+    return pol, state, rec
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_policy_matches_reference(name):
+    d = np.load(os.path.join(scenario.GOLDEN, "model_cases.npz"))
+    pol, state, rec = _policy(d, name)
+    torch.manual_seed(77)
+    pred = pol.predict(state, T if rec else 1)
+    if isinstance(pred, tuple):
+        assert np.array_equal(pred[1].numpy(), d[name + ".taus"])      # same tau stream
+        pred = pred[0]
+    np.testing.assert_allclose(pred.detach().numpy(), d[name + ".pred"], **TOL)
+    torch.manual_seed(78)
+    act = pol.actor_predict(state, T if rec else 1)
+    np.testing.assert_allclose(act["qvalues"], d[name + ".act_qvalues"], **TOL)
+    assert np.array_equal(act["actions"], d[name + ".act_actions"])
+    if rec:
+        np.testing.assert_allclose(pol.model.layers[1].last_state[0].numpy(), d[name + ".last_hx"], **TOL)
+
+
+def test_burn_in_matches_reference():
+    """multi_step_trainer.py:90-131: row P of the stored recurrent state is
+    replaced by the burned-in state (zeroed where initials[P]), prefix rows are
+    dropped from every leaf."""
+    from rltime_amd.training.iqn import IQN
+    from rltime_amd.general.value_log import ValueLog
+    d = np.load(os.path.join(scenario.GOLDEN, "model_cases.npz"))
+    name = "iqn_lstm"
+    pol, state, _ = _policy(d, name)
+    tr = IQN.__new__(IQN)
+    tr.policy = tr.target_policy = pol
+    tr.value_log = ValueLog()
+    shaped = {"states": {
+        "x": torch.from_numpy(state["x"]).view(T, B, 2, 12, 12), "layer0_state": {}, "layer2_state": {},
+        "layer1_state": {k: torch.from_numpy(np.array(v)).view((T, B) + v.shape[1:])
+                         for k, v in state["layer1_state"].items()}},
+        "returns": torch.arange(T * B, dtype=torch.float32).view(T, B)}
+    torch.manual_seed(79)
+    res = tr._burn_in(shaped, 2, do_target_states=False)
+    np.testing.assert_allclose(res["states"]["layer1_state"]["hx"].numpy(), d[name + ".burn.hx"], **TOL)
+    np.testing.assert_allclose(res["states"]["layer1_state"]["cx"].numpy(), d[name + ".burn.cx"], **TOL)
+    assert np.array_equal(res["returns"].numpy(), d[name + ".burn.returns"])

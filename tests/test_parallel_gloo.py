@@ -1,0 +1,78 @@
+"""CPU, world_size=2 over gloo: the N>1 path of the hot loop — env-sharded
+replay configuration, flat-bucket gradient all-reduce, and the 3-doubles
+exchange that turns shard-local importance weights into the globally
+normalised ones (rltime_amd/parallel.py).  The RCCL path is the same code with
+backend "nccl"."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rltime_amd.parallel import DataParallel
+    dp = DataParallel()
+    # 1. gradient bucket
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(11, 5, generator=g)
+    net(x).pow(2).mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    dp.all_reduce_gradients(net)
+    reduced = [p.grad.clone() for p in net.parameters()]
+    # 2. importance weights: every rank holds a shard of priorities, samples some
+    beta = 0.6
+    rs = np.random.RandomState(7)
+    prios = [np.abs(rs.randn(40)) + 0.05, np.abs(rs.randn(25)) + 0.05]      # shard trees (leaf priorities)
+    picks = [rs.randint(0, 40, 6), rs.randint(0, 25, 6)]
+    p_l, pk = prios[rank], picks[rank]
+    raw_local = (p_l[pk] / p_l.sum() * len(p_l)) ** (-beta)
+    w_local = torch.from_numpy(raw_local / raw_local.max())
+    w = dp.globalize_weights(w_local, torch.tensor(p_l.sum()), len(p_l), torch.tensor(raw_local.max()), beta)
+    # what one tree over the union of the shards gives for the same sampled items
+    P_g, N_g = prios[0].sum() + prios[1].sum(), 65
+    raw_all = np.concatenate([(prios[r][picks[r]] / P_g * N_g) ** (-beta) for r in range(2)])
+    want = (prios[rank][pk] / P_g * N_g) ** (-beta) / raw_all.max()
+    out[rank] = dict(local=local, reduced=reduced, w=w.numpy(), want=want)
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    for a, b, m0, m1 in zip(r0["local"], r1["local"], r0["reduced"], r1["reduced"]):
+        assert torch.allclose(m0, (a + b) / 2, atol=1e-7)
+        assert torch.equal(m0, m1)
+    for r in (r0, r1):
+        np.testing.assert_allclose(r["w"], r["want"], rtol=1e-12)
+    assert max(r0["w"].max(), r1["w"].max()) == 1.0
+
+
+def test_shard_config():
+    from rltime_amd.general.config import load_config
+    from rltime_amd.parallel import shard_config
+    cfg = load_config("synthetic_atari_iqn_lstm.json")
+    shards = [shard_config(cfg, r, 8) for r in range(8)]
+    assert [s["acting"]["actor_envs"] for s in shards] == [32] * 8
+    assert [s["acting"]["env_base"] for s in shards] == [32 * r for r in range(8)]
+    assert shards[3]["training"]["args"]["history_mode"]["args"]["size"] == 125000
+    assert cfg["acting"]["actor_envs"] == 256       # input untouched

@@ -102,5 +102,7 @@ def run(nt, size, E, B, T, P, n, iters):
 
 if __name__ == "__main__":
     size = int(os.environ.get("PROBE_SIZE", 262144))
-    for nt in (0, 1):
-        print(json.dumps(run(nt, size, 256, 512, 80, 40, 2, 10)), flush=True)
+    iters = int(os.environ.get("PROBE_ITERS", 10))
+    nts = [int(os.environ["PROBE_NT"])] if "PROBE_NT" in os.environ else [0, 1]
+    for nt in nts:
+        print(json.dumps(run(nt, size, 256, 512, 80, 40, 2, iters)), flush=True)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output directory into the summary that is
+committed under profiles/: top kernels by total time, and per-launch HBM traffic
+of the frame-gather kernel from the FETCH_SIZE / WRITE_SIZE PMC passes (FETCH_SIZE
+doubled on gfx950 for wide coalesced reads, MI355X_MICROARCH.md section HBM)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(root, pattern):
+    hits = glob.glob(os.path.join(root, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def main(out):
+    stats = find(os.path.join(out, "stats"), "*kernel_stats.csv")
+    print("== kernel stats (rocprofv3 --kernel-trace --stats; bench.py --steps 5 --warmup 2)")
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        import shutil
+        shutil.copy(stats, os.path.join(out, "kernel_stats.csv"))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        print("%-72s %8s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
+        for r in rows[:28]:
+            print("%-72s %8s %12.3f %10.2f %6.2f" % (
+                r["Name"][:72], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+        ours = [r for r in rows if r["Name"].startswith("mirl::") or "mirl" in r["Name"]]
+        print("\n-- librltime_hip kernels")
+        for r in ours:
+            print("%-72s %8s %12.3f %10.2f" % (r["Name"][:72], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                               float(r["AverageNs"]) / 1e3))
+    else:
+        print("no kernel_stats.csv found under", out)
+    trace = find(os.path.join(out, "stats"), "*kernel_trace.csv")
+    if trace:
+        # per-launch durations of our kernels, split by grid size (the frame gather
+        # and the recurrent-state gather are the same kernel with different rows)
+        import collections
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            name = r.get("Kernel_Name", "")
+            if "mirl::" not in name:
+                continue
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            acc[(name.split("(")[0][:48], r.get("Grid_Size", r.get("Grid_Size_X", "?")))].append(dur)
+        print("\n-- librltime_hip kernels by grid size (us per launch)")
+        print("%-50s %12s %7s %10s %10s %10s" % ("kernel", "grid", "calls", "avg", "min", "max"))
+        for (name, grid), v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            print("%-50s %12s %7d %10.2f %10.2f %10.2f" % (name, grid, len(v), sum(v) / len(v), min(v), max(v)))
+    res = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = find(os.path.join(out, "pmc_" + cname), "*counter_collection.csv")
+        if not f:
+            continue
+        vals = []
+        for r in csv.DictReader(open(f)):
+            if "k_gather_rows" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cname:
+                # only the frame launches: 62464 workgroups of 256 (B=512, L+n=122)
+                if int(r.get("Grid_Size", "0")) >= 62464 * 256 and int(r.get("Workgroup_Size", "256")) == 256:
+                    vals.append(float(r["Counter_Value"]))
+        if vals:
+            with open(os.path.join(out, "gather_%s_launches.txt" % cname), "w") as fh:
+                fh.write("\n".join("%.1f" % v for v in vals))
+            res[cname] = sorted(vals)[len(vals) // 2]       # median launch, KiB units
+            print("\n%s: %d frame-gather launches, median %.0f KiB, min %.0f, max %.0f" % (
+                cname, len(vals), res[cname], min(vals), max(vals)))
+    if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+        fetch = res["FETCH_SIZE"] * 1024 * 2        # gfx950: FETCH_SIZE counts 64 B per 128 B request
+        write = res["WRITE_SIZE"] * 1024
+        algo = 2.0 * 122 * 512 * 28224
+        summary = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+                   "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (fetch + write) / algo,
+                   "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE uncorrected; KiB -> bytes"}
+        print("\n== gather traffic", json.dumps(summary))
+        json.dump(summary, open(os.path.join(out, "gather_traffic.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
