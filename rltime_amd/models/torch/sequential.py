@@ -91,8 +91,14 @@ class SequentialModel(nn.Module):
             state["layer%d_state" % i] = layer.get_state(initials)
         return state
 
-    def forward(self, inp, timesteps):
-        """sequential.py:167-210 -> {"output", "layer_inputs", + pre-processor extras}."""
+    def last_recurrent_layer(self):
+        idx = [i for i, layer in enumerate(self.layers) if layer.is_recurrent()]
+        return idx[-1] if idx else None
+
+    def forward(self, inp, timesteps, stop_after=None):
+        """sequential.py:167-210 -> {"output", "layer_inputs", + pre-processor extras}.
+        stop_after=i ends the pass after layer i (used by the burn-in, which only
+        needs the recurrent state and not the head)."""
         inp = make_tensor(inp, self.device())
         x = inp["x"]
         extra = None
@@ -111,5 +117,7 @@ class SequentialModel(nn.Module):
                 result.update(more)
             result["layer_inputs"].append(x)
             x = layer(x, timesteps=timesteps, **inp.get("layer%d_state" % i, {}))
+            if stop_after is not None and i == stop_after:
+                break
         result["output"] = x
         return result

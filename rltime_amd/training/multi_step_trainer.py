@@ -68,7 +68,16 @@ class MultiStepTrainer(PolicyTrainer):
             todo.append((self.target_policy, train_data["target_states"]))
         for policy, states in todo:
             prefix = deep_apply(deep_apply(states, lambda x: x[:P]), _flat)
-            policy.actor_predict(prefix, timesteps=P, as_numpy=False)
+            last_rnn = policy.model.last_recurrent_layer()
+            if getattr(self, "burn_in_full_forward", False) or last_rnn is None:
+                # the reference's exact call (actor_predict: whole head + a tau draw)
+                policy.actor_predict(prefix, timesteps=P, as_numpy=False)
+            else:
+                # only the recurrent state is consumed: stop after the last
+                # recurrent layer (skips the IQN head on P*B rows; changes how many
+                # torch.rand taus are consumed vs the reference)
+                with torch.no_grad():
+                    policy.model(prefix, P, stop_after=last_rnn)
             for i, layer in enumerate(policy.model.layers):
                 key = "layer%d_state" % i
                 if not states[key]:
