@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--replay-size", type=int, default=1000000, help="transitions per GPU")
     ap.add_argument("--acting", action="store_true", help="run the real actor (policy forward) instead of synthetic actor output")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC conv stack (experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "gather_traffic.json"))
@@ -77,6 +78,8 @@ def build_trainer(args, rank, world, device):
             "warmup_steps": 0, "total_steps": 10 ** 12, "log_freq": 10 ** 12,
             "history_mode": {"args": {"size": args.replay_size, "device_rng": True,
                                       "keep_policy_outputs": False}}}}})
+    if args.channels_last:
+        config["model"]["args"]["layer_configs"][0]["args"]["channels_last"] = True
     actors = create_actors(config, device, device_acting=True)
     cls = get_registered_type("trainers", config["training"]["type"])
     trainer = cls(logger=NullLogger(), actors=actors, model_config=config["model"],
@@ -225,14 +228,16 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))      # exercise the RCCL path on 1 GPU (debug)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
     trainer, config = build_trainer(args, rank, world, device)
-    if world > 1:
+    if world > 1 or force_dist:
         from rltime_amd.parallel import DataParallel
         trainer.data_parallel = DataParallel()
         # identical initial weights on every rank
@@ -341,7 +346,7 @@ def main():
         print(json.dumps(out), flush=True)
     trainer.actors = real_actors
     hist.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -227,6 +227,24 @@ int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const float* z,
                   const float* weights, double kappa, double row_scale,
                   float* row_loss, float* dz, float* abs_td, void* stream);
 
+/* ---- recurrent core: fused LSTM-cell pointwise step --------------------------
+ * Replaces the per-step elementwise chain of torch.nn.LSTMCell inside
+ * rltime/models/torch/modules/lstm.py:83-116 (time loop with state reset on
+ * `initials`).  gates [B][4H] (i,f,g,o): pre-activations in, activated gates
+ * out; c_in [B][H] is the (already masked) cell input; h_next/c_next receive
+ * h*keep_next / c*keep_next (keep_next [B] = 1 - initials of step t+1, NULL = 1)
+ * i.e. the masked inputs of the following step.  h_out / c_out may be NULL.     */
+int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, const float* keep_next,
+                       float* h_out, float* c_out, float* h_next, float* c_next, void* stream);
+/* Backward of one step: gates holds the activated gates on entry and
+ * d loss / d pre-activation on exit; d_out [B][H] = grad of this step's output h
+ * (NULL = 0); dh_rec / dc_rec = grads w.r.t. the next step's masked inputs
+ * (ignored when first != 0, i.e. for the last timestep); dc_rec is overwritten
+ * with the grad w.r.t. this step's c_in.                                        */
+int mirl_lstm_cell_bwd(int32_t B, int32_t H, float* gates, const float* c_t, const float* c_in,
+                       const float* d_out, const float* dh_rec, float* dc_rec, const float* keep_next,
+                       int32_t first, void* stream);
+
 /* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
 int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
 

@@ -344,6 +344,66 @@ k_gather_rows(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out
   }
 }
 
+// --- experimental launch shapes for the frame gather (MIRL_GATHER_VARIANT) ---
+// V1: 512 lanes per row, every load of the row issued before the first store.
+__global__ void __launch_bounds__(512)
+k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
+                 const int32_t* __restrict__ env, const int64_t* __restrict__ start,
+                 int B, int overlapped, int32_t row_bytes, int64_t ring_stride, int order) {
+  int64_t rb = blockIdx.x;
+  const int R = gridDim.x / B;
+  int r, b;
+  if (order) { b = (int)(rb / R); r = (int)(rb % R); rb = (int64_t)r * B + b; }   // source-contiguous order
+  else { r = (int)(rb / B); b = (int)(rb % B); }
+  int32_t e = env[b];
+  if (e < 0 || e >= d.E) e = 0;
+  const int64_t src_off = row_src_off(d, overlapped, r, e, start[b]);
+  const u32x4* s4 = (const u32x4*)(ring + ((int64_t)e * d.C + src_off % d.C) * ring_stride);
+  u32x4* t4 = (u32x4*)(out + rb * (int64_t)row_bytes);
+  const int n = row_bytes >> 4;
+  int c = threadIdx.x;
+  for (; c + 1536 < n; c += 2048) {
+    u32x4 v0 = __builtin_nontemporal_load(s4 + c), v1 = __builtin_nontemporal_load(s4 + c + 512);
+    u32x4 v2 = __builtin_nontemporal_load(s4 + c + 1024), v3 = __builtin_nontemporal_load(s4 + c + 1536);
+    __builtin_nontemporal_store(v0, t4 + c); __builtin_nontemporal_store(v1, t4 + c + 512);
+    __builtin_nontemporal_store(v2, t4 + c + 1024); __builtin_nontemporal_store(v3, t4 + c + 1536);
+  }
+  u32x4 w0, w1, w2; bool h0 = c < n, h1 = c + 512 < n, h2 = c + 1024 < n;
+  if (h0) w0 = __builtin_nontemporal_load(s4 + c);
+  if (h1) w1 = __builtin_nontemporal_load(s4 + c + 512);
+  if (h2) w2 = __builtin_nontemporal_load(s4 + c + 1024);
+  if (h0) __builtin_nontemporal_store(w0, t4 + c);
+  if (h1) __builtin_nontemporal_store(w1, t4 + c + 512);
+  if (h2) __builtin_nontemporal_store(w2, t4 + c + 1024);
+}
+
+// V2: persistent grid (a few workgroups per CU), each walks rows; source-contiguous order.
+__global__ void __launch_bounds__(256)
+k_gather_rows_v2(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
+                 const int32_t* __restrict__ env, const int64_t* __restrict__ start,
+                 int B, int R, int overlapped, int32_t row_bytes, int64_t ring_stride, int order) {
+  const int n = row_bytes >> 4;
+  const int64_t total = (int64_t)R * B;
+  for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
+    int r, b;
+    if (order) { b = (int)(it / R); r = (int)(it % R); } else { r = (int)(it / B); b = (int)(it % B); }
+    const int64_t rb = (int64_t)r * B + b;
+    int32_t e = env[b];
+    if (e < 0 || e >= d.E) e = 0;
+    const int64_t src_off = row_src_off(d, overlapped, r, e, start[b]);
+    const u32x4* s4 = (const u32x4*)(ring + ((int64_t)e * d.C + src_off % d.C) * ring_stride);
+    u32x4* t4 = (u32x4*)(out + rb * (int64_t)row_bytes);
+    int c = threadIdx.x;
+    for (; c + 768 < n; c += 1024) {
+      u32x4 v0 = __builtin_nontemporal_load(s4 + c), v1 = __builtin_nontemporal_load(s4 + c + 256);
+      u32x4 v2 = __builtin_nontemporal_load(s4 + c + 512), v3 = __builtin_nontemporal_load(s4 + c + 768);
+      __builtin_nontemporal_store(v0, t4 + c); __builtin_nontemporal_store(v1, t4 + c + 256);
+      __builtin_nontemporal_store(v2, t4 + c + 512); __builtin_nontemporal_store(v3, t4 + c + 768);
+    }
+    for (; c < n; c += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + c), t4 + c);
+  }
+}
+
 // Per-step scalars of the batch.  One lane per (t, b):
 //   _update_nstep (history.py:71-108): forward scan over <= n rewards / dones,
 //   return accumulated in float64 with gamma**k from the host libm (the Python
@@ -469,6 +529,7 @@ struct mirl_replay {
   std::vector<void*> allocs;
   double* gpow_dev = nullptr;
   int gather_nt = 0;
+  int gather_variant = 1, gather_order = 1, gather_blocks = 2048;   // V1/O1: 5.85 TB/s vs 5.31 (profiles/)
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
@@ -565,7 +626,10 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   h->overlapped = (bk.N < bk.L && !cfg->avoid_episode_crossing) ? 1 : 0;
   h->rows = h->overlapped ? bk.L + bk.N : 2 * bk.L;
   const char* nt = getenv("MIRL_GATHER_NT");
-  h->gather_nt = nt ? atoi(nt) : 1;   // non-temporal loads/stores: +7 % on the frame gather (profiles/)
+  h->gather_nt = nt ? atoi(nt) : 1;
+  if (const char* v = getenv("MIRL_GATHER_VARIANT")) h->gather_variant = atoi(v);
+  if (const char* v = getenv("MIRL_GATHER_ORDER")) h->gather_order = atoi(v);
+  if (const char* v = getenv("MIRL_GATHER_BLOCKS")) h->gather_blocks = atoi(v);   // non-temporal loads/stores: +7 % on the frame gather (profiles/)
   MIRL_HIP(hipDeviceSynchronize());
   *out = h;
   return MIRL_OK;
@@ -732,7 +796,13 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = h->prof && ring == (const void*)h->d.frames;
   if (timed) { MIRL_HIP(hipEventCreate(&e0)); MIRL_HIP(hipEventCreate(&e1)); MIRL_HIP(hipEventRecord(e0, st)); }
-  if (h->gather_nt)
+  if (vec && h->gather_variant == 1)
+    hipLaunchKernelGGL(k_gather_rows_v1, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                       env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
+  else if (vec && h->gather_variant == 2)
+    hipLaunchKernelGGL(k_gather_rows_v2, dim3((unsigned)h->gather_blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                       env, start, B, h->rows, h->overlapped, row_bytes, ring_stride, h->gather_order);
+  else if (h->gather_nt)
     hipLaunchKernelGGL(k_gather_rows<1>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);
   else

@@ -1,0 +1,85 @@
+"""Fused LSTM sequence op for the recurrent core (GPU only).
+
+Same recurrence as the reference's LSTMCell time loop with per-step reset
+(rltime/models/torch/modules/lstm.py:83-116):
+
+    h_in = h(t-1) * keep(t) ; c_in = c(t-1) * keep(t) ; keep = 1 - initials
+    gates = W_ih x(t) + b_ih + W_hh h_in + b_hh       (i, f, g, o)
+    c(t) = sig(f) c_in + sig(i) tanh(g) ; h(t) = sig(o) tanh(c(t))
+
+but one step costs one rocBLAS GEMM (h_in @ W_hh^T accumulated onto the
+pre-computed input projection) plus one fused HIP kernel
+(csrc/lstm.hip: mirl_lstm_cell_fwd / _bwd).  The weight gradient of W_hh is ONE
+GEMM over all timesteps after the backward sweep, and the gradient w.r.t. the
+input projection is returned without a copy.
+"""
+import ctypes as C
+
+import torch
+
+from rltime_amd._lib import lib, check
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _LSTMSequence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, w_hh, h0, c0, keep):
+        # gx (T, B, 4H): input projection incl. b_ih + b_hh; keep (T, B)
+        T, B, G = gx.shape
+        H = G // 4
+        gx = gx.float().contiguous()
+        w = w_hh.float().contiguous()
+        keep = keep.float().contiguous()
+        need_grad = gx.requires_grad or w_hh.requires_grad
+        dev = gx.device
+        gates = torch.empty_like(gx)
+        hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)     # masked h inputs; hm[T] = final h
+        cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev) if need_grad else None
+        torch.mul(h0.float(), keep[0].unsqueeze(-1), out=hm[0])
+        torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
+        wt = w.t()
+        st = _stream()
+        for t in range(T):
+            torch.addmm(gx[t], hm[t], wt, out=gates[t])
+            check(lib.mirl_lstm_cell_fwd(
+                B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+                "mirl_lstm_cell_fwd")
+        if need_grad:
+            ctx.save_for_backward(gates, c_all, cm, hm, keep, w)
+        h_last, c_last = hm[T], cm[T]
+        ctx.mark_non_differentiable(h_last, c_last)
+        return out, h_last, c_last
+
+    @staticmethod
+    def backward(ctx, d_out, _dh, _dc):
+        gates, c_all, cm, hm, keep, w = ctx.saved_tensors
+        T, B, G = gates.shape
+        H = G // 4
+        d_out = d_out.float().contiguous()
+        dh_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+        dc_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+        st = _stream()
+        for t in range(T - 1, -1, -1):
+            check(lib.mirl_lstm_cell_bwd(
+                B, H, _p(gates[t]), _p(c_all[t]), _p(cm[t]), _p(d_out[t]), _p(dh_rec), _p(dc_rec),
+                _p(keep[t + 1]) if t + 1 < T else None, 1 if t == T - 1 else 0, st),
+                "mirl_lstm_cell_bwd")
+            if t > 0:
+                torch.mm(gates[t], w, out=dh_rec)
+        d_w = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H))
+        return gates, d_w, None, None, None
+
+
+def lstm_sequence(gx, w_hh, h0, c0, keep):
+    """-> (out (T,B,H), h_T (B,H), c_T (B,H))."""
+    return _LSTMSequence.apply(gx, w_hh, h0, c0, keep)

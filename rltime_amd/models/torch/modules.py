@@ -31,9 +31,10 @@ class CNN(BaseModule):
     """modules/cnn.py:9-53: conv+ReLU stack on channel-first input; uint8 input
     is converted and scaled (1/255) on the device."""
 
-    def __init__(self, inp_shape, layers, scale=1.0 / 255.0):
+    def __init__(self, inp_shape, layers, scale=1.0 / 255.0, channels_last=False):
         super().__init__()
         self.scale = scale
+        self.channels_last = channels_last
         self.layers = nn.ModuleList()
         ch = inp_shape[0]
         h, w = inp_shape[1:]
@@ -43,10 +44,16 @@ class CNN(BaseModule):
             h, w = conv_out_size(h, k, s), conv_out_size(w, k, s)
             ch = f
         self.out_shape = (ch, h, w)
+        if channels_last:
+            self.to(memory_format=torch.channels_last)
 
     def forward(self, x, **kwargs):
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         if self.scale:
-            x = x.float() * self.scale
+            # uint8 * python float promotes to float32 in ONE pass (same values as
+            # x.float() * scale, cnn.py:44-45)
+            x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale
         for layer in self.layers:
             x = F.relu(layer(x))
         return x
@@ -92,6 +99,7 @@ class LSTM(BaseModule):
         self.lstm_cell = nn.LSTMCell(input_size=self.inp_size, hidden_size=num_units)
         self.out_shape = (num_units,)
         self.last_state = None
+        self.fused = True          # use the fused HIP sequence op on the GPU
         init_weight(self.lstm_cell.weight_hh)
         init_weight(self.lstm_cell.weight_ih)
 
@@ -107,8 +115,16 @@ class LSTM(BaseModule):
         assert initials.shape == ((batch * timesteps) // multi,)
         if multi > 1:
             initials = initials.repeat_interleave(multi, dim=0)
-        keep = (1 - initials).reshape(timesteps, batch, 1)
         cell = self.lstm_cell
+        if x.is_cuda and multi == 1 and self.fused:
+            # MI355X path: one GEMM + one fused HIP kernel per step (lstm_seq.py)
+            from .lstm_seq import lstm_sequence
+            gx = F.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh).reshape(timesteps, batch, -1)
+            out, h_last, c_last = lstm_sequence(gx, cell.weight_hh, hx, cx,
+                                                (1 - initials).reshape(timesteps, batch))
+            self.last_state = (h_last.detach(), c_last.detach())
+            return out.reshape(timesteps * batch, self.num_units)
+        keep = (1 - initials).reshape(timesteps, batch, 1)
         # one GEMM for the input projection of every timestep
         gx = F.linear(x, cell.weight_ih, cell.bias_ih).reshape(timesteps, batch, -1)
         out = []

@@ -39,10 +39,12 @@ class DataParallel:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._flat = None
+        import os
+        self.force = bool(os.environ.get("BENCH_FORCE_DIST"))   # run the collectives even at world 1
 
     def all_reduce_gradients(self, module):
         grads = [p.grad for p in module.parameters() if p.grad is not None]
-        if not grads or self.world == 1:
+        if not grads or (self.world == 1 and not self.force):
             return
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
@@ -63,7 +65,7 @@ class DataParallel:
         Returns weights normalised as if all shards were one tree:
             w_global_i = (p_i * N_g / P_g)^-beta / max_j(...)
         using w_local_i * max_raw = (p_i * N_l / P_l)^-beta."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return weights
         mine = torch.stack([p_sum.double().reshape(()),
                             torch.as_tensor(float(n_active), dtype=torch.float64, device=p_sum.device),

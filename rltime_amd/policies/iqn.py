@@ -24,11 +24,14 @@ class IQNPolicy(DQNPolicy):
         n = self.num_sampling_quantiles
         batch = x.shape[0]
         x = x.reshape(batch, -1)
-        xt = x.repeat_interleave(n, dim=0)                         # (batch*n, state) grouped per item
         quantiles = torch.rand(batch * n, device=self.embedding_range.device)
         emb = torch.cos(self.embedding_range * np.pi * quantiles.unsqueeze(1))
         emb = F.relu(self.quantile_layer(emb))
-        return xt * emb, {"quantiles": quantiles}
+        # iqn.py:84,102: interleaved repeat of x times the embedding, grouped
+        # (batch, n).  Broadcasting gives the same values without materialising
+        # the repeated (batch*n, state) copy of x.
+        out = (x.unsqueeze(1) * emb.reshape(batch, n, -1)).reshape(batch * n, -1)
+        return out, {"quantiles": quantiles}
 
     def _shape_action_outputs(self, output):
         return output.reshape(-1, self.num_sampling_quantiles, output.shape[-1]), 2

@@ -1,0 +1,57 @@
+"""GPU: the fused LSTM sequence op (csrc/lstm.hip + lstm_seq.py) against the
+plain torch time loop (the reference's LSTMCell recurrence with resets,
+modules/lstm.py:83-116): outputs, final state and all gradients, fp32 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("T,B,I,H", [(1, 3, 5, 4), (7, 5, 12, 8), (20, 33, 40, 64), (80, 16, 64, 512)])
+def test_fused_lstm_matches_loop(T, B, I, H):
+    from rltime_amd.models.torch.modules import LSTM
+    torch.manual_seed(T * 100 + B)
+    a = LSTM((I,), H).cuda()
+    b = LSTM((I,), H).cuda()
+    b.load_state_dict(a.state_dict())
+    a.fused, b.fused = True, False
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(T * B, I, generator=g).cuda()
+    hx = torch.randn(T * B, H, generator=g).cuda()
+    cx = torch.randn(T * B, H, generator=g).cuda()
+    initials = (torch.rand(T * B, generator=g) < 0.2).float().cuda()
+    up = torch.randn(T * B, H, generator=g).cuda()
+    res = []
+    for m in (a, b):
+        xi = x.clone().requires_grad_(True)
+        out = m(xi, hx=hx, cx=cx, initials=initials, timesteps=T)
+        (out * up).sum().backward()
+        res.append((out.detach(), m.last_state, xi.grad, {k: p.grad for k, p in m.named_parameters()}))
+    tol = dict(rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(res[0][0].cpu(), res[1][0].cpu(), **tol)
+    np.testing.assert_allclose(res[0][1][0].cpu(), res[1][1][0].cpu(), **tol)
+    np.testing.assert_allclose(res[0][1][1].cpu(), res[1][1][1].cpu(), **tol)
+    np.testing.assert_allclose(res[0][2].cpu(), res[1][2].cpu(), **tol)
+    for k in res[0][3]:
+        scale = float(res[1][3][k].abs().max()) + 1e-6
+        np.testing.assert_allclose(res[0][3][k].cpu() / scale, res[1][3][k].cpu() / scale, rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+def test_fused_lstm_no_grad_matches():
+    from rltime_amd.models.torch.modules import LSTM
+    torch.manual_seed(0)
+    a = LSTM((16,), 32).cuda()
+    T, B = 11, 9
+    x = torch.randn(T * B, 16).cuda()
+    hx, cx = torch.randn(T * B, 32).cuda(), torch.randn(T * B, 32).cuda()
+    ini = (torch.rand(T * B) < 0.3).float().cuda()
+    with torch.no_grad():
+        a.fused = True
+        o1 = a(x, hx=hx, cx=cx, initials=ini, timesteps=T)
+        s1 = a.last_state
+        a.fused = False
+        o2 = a(x, hx=hx, cx=cx, initials=ini, timesteps=T)
+        s2 = a.last_state
+    np.testing.assert_allclose(o1.cpu(), o2.cpu(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(s1[1].cpu(), s2[1].cpu(), rtol=1e-4, atol=2e-5)

@@ -209,3 +209,73 @@ def test_no_gpu_fallback_marker():
     import rltime_amd.history.replay_history as m
     src = open(m.__file__).read()
     assert "oracle" not in src
+
+
+def test_full_size_properties_config_d():
+    """BASELINE configs[3] at full size (1M transitions, B=512, T=80, burn-in 40,
+    n=2, 84x84x4): size-independent properties instead of an oracle run —
+      * every gathered frame row carries the identity of (env, start+t-1);
+      * stratified sum-tree indices are non-decreasing, land on active slots
+        and their windows lie inside the live ring;
+      * importance weights are in (0, 1] with max exactly 1;
+      * the root equals the sum of the leaves (1e-9) and update_losses is
+        idempotent (same losses twice -> identical tree)."""
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    E, T, P, n, B, H = 256, 80, 40, 2, 512, 512
+    buf = PrioritizedReplayHistoryBuffer(
+        size=1000000, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
+        alpha=0.9, beta=0.6, gamma=0.997, device_rng=True, keep_policy_outputs=False)
+    ex = {"x": np.zeros((4, 84, 84), np.uint8),
+          "layer1_state": {"hx": np.zeros(H, np.float32), "cx": np.zeros(H, np.float32), "initials": np.float32(0)}}
+    buf.configure(ex, num_envs=E)
+    dev = buf.device
+    steps = 1000000 // E + 300                   # wraps the rings, evicts ~76k transitions
+    env_ids = torch.arange(E, device=dev, dtype=torch.int32)
+    state = torch.zeros(E, 2 * H, device=dev)
+    zeros_f = torch.zeros(E, device=dev)
+    act = torch.zeros(E, dtype=torch.int32, device=dev)
+    done = torch.zeros(E, dtype=torch.uint8, device=dev)
+    frames = torch.zeros((E, 4 * 84 * 84), dtype=torch.uint8, device=dev)
+    for s in range(steps):
+        # identity in the first 8 bytes: env (2 bytes), offset (4 bytes), checksum-ish
+        frames[:, 0] = (env_ids & 0xFF).to(torch.uint8); frames[:, 1] = (env_ids >> 8).to(torch.uint8)
+        for k in range(4):
+            frames[:, 2 + k] = (s >> (8 * k)) & 0xFF
+        buf.update_batch(frames.view(E, 4, 84, 84), act, zeros_f + float(s % 3) - 1.0, done, state=state, initials=zeros_f)
+    st = buf.stats()
+    assert st["total_items"] == 1000000
+    buf.train_quota = 0          # the fill accrued size*train_frequency of quota (replay_history.py:179 guard)
+    batch = buf.get_train_data(B, 0.5)
+    smp = buf.last_sample
+    slot = smp["slot"].cpu().numpy(); env = smp["env"].cpu().numpy(); start = smp["start"].cpu().numpy()
+    assert np.all(np.diff(slot) >= 0)                                   # stratified => sorted
+    se, sb = buf.slot_table()
+    assert np.all(se[slot] == env) and np.all(sb[slot] - P == start)    # active slots, right windows
+    first, count = buf.env_meta()
+    assert np.all(start >= first[env]) and np.all(start + T + P + n - 1 <= count[env])
+    x = batch["states"]["x"]                                            # (L, B, 4, 84, 84)
+    tx = batch["target_states"]["x"]
+    L = T + P
+    assert x.shape == (L, B, 4, 84, 84) and tx.data_ptr() == x.data_ptr() + n * B * 4 * 84 * 84
+    head = torch.cat([x, tx[-n:]])[:, :, 0].reshape(L + n, B, -1)[:, :, :6].cpu().numpy().astype(np.int64)
+    got_env = head[..., 0] + (head[..., 1] << 8)
+    got_off = head[..., 2] + (head[..., 3] << 8) + (head[..., 4] << 16) + (head[..., 5] << 24)
+    want_off = start[None, :] + np.arange(L + n)[:, None] - 1          # state of transition o is next_state of o-1
+    assert np.array_equal(got_env, np.broadcast_to(env[None, :], got_env.shape))
+    assert np.array_equal(got_off, want_off)
+    w = batch["extra_data"]["importance_weights"].cpu().numpy()
+    assert w.max() == 1.0 and w.min() > 0.0 and np.all(w[0] == w[-1])
+    li = batch["extra_data"]["loss_indices"].cpu().numpy()
+    assert np.all(li[:P] == -1) and np.array_equal(li[P:, :, 1], start[None, :] + P + np.arange(T)[:, None])
+    # tree invariants + idempotent update
+    idx = batch["extra_data"]["loss_indices"][P:].reshape(-1, 2)
+    losses = torch.rand(idx.shape[0], device=dev)
+    buf.update_losses(idx, losses)
+    v1, k1, _ = buf.tree_nodes()
+    cap = len(v1) // 2
+    assert abs(v1[1] - v1[cap:].sum()) <= 1e-9 * v1[1]
+    buf.update_losses(idx, losses)
+    v2, k2, _ = buf.tree_nodes()
+    assert np.array_equal(v1, v2) and np.array_equal(k1, k2)
+    assert st["active_sequences"] == np.count_nonzero(v1[cap:])
+    buf.close()

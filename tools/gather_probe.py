@@ -49,11 +49,15 @@ def run(nt, size, E, B, T, P, n, iters):
     for _ in range(3):
         batch = buf.get_train_data(B, 0.5)
     torch.cuda.synchronize()
+    buf.profile(True)
     e0.record()
     for _ in range(iters):
         batch = buf.get_train_data(B, 0.5)
     e1.record()
     torch.cuda.synchronize()
+    kn, kms = buf.profile(False)
+    out["frames_kernel_ms"] = kms / max(kn, 1)
+    out["frames_kernel_GBps"] = 2 * (T + P + n) * B * 4 * 84 * 84 / (kms / max(kn, 1)) / 1e6
     ms = e0.elapsed_time(e1) / iters
     L = T + P
     frame_bytes = 2 * (L + n) * B * 4 * 84 * 84
@@ -100,7 +104,24 @@ def run(nt, size, E, B, T, P, n, iters):
     return out
 
 
+def sweep():
+    size = int(os.environ.get("PROBE_SIZE", 262144))
+    combos = [dict(V=0, O=0), dict(V=1, O=0), dict(V=1, O=1), dict(V=2, O=0, BL=2048), dict(V=2, O=1, BL=2048),
+              dict(V=2, O=1, BL=4096), dict(V=2, O=0, BL=8192), dict(V=2, O=1, BL=1024)]
+    for c in combos:
+        os.environ["MIRL_GATHER_VARIANT"] = str(c["V"])
+        os.environ["MIRL_GATHER_ORDER"] = str(c["O"])
+        os.environ["MIRL_GATHER_BLOCKS"] = str(c.get("BL", 2048))
+        r = run(1, size, 256, 512, 80, 40, 2, 10)
+        print(json.dumps({"combo": c, "get_train_data_ms": r["get_train_data_ms"],
+                          "frames_kernel_ms": r["frames_kernel_ms"],
+                          "frames_kernel_GBps": r["frames_kernel_GBps"]}), flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("PROBE_SWEEP"):
+        sweep()
+        sys.exit(0)
     size = int(os.environ.get("PROBE_SIZE", 262144))
     iters = int(os.environ.get("PROBE_ITERS", 10))
     nts = [int(os.environ["PROBE_NT"])] if "PROBE_NT" in os.environ else [0, 1]
