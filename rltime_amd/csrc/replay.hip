@@ -344,8 +344,12 @@ k_gather_rows(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out
   }
 }
 
-// --- experimental launch shapes for the frame gather (MIRL_GATHER_VARIANT) ---
-// V1: 512 lanes per row, every load of the row issued before the first store.
+// Default launch shape for 16-byte-aligned rows (MIRL_GATHER_VARIANT=1): 512
+// lanes per row and every load of the row issued before its first store.
+// Measured on MI355X at B=512, L+n=122, 1M-transition replay (profiles/):
+// 0.638 ms (5.53 TB/s) vs 0.654 ms for the 256-lane kernel above; a persistent
+// 2048..8192-workgroup variant and a source-contiguous block order were slower
+// (0.66-0.72 ms) at this replay size and were dropped.
 __global__ void __launch_bounds__(512)
 k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
                  const int32_t* __restrict__ env, const int64_t* __restrict__ start,
@@ -375,33 +379,6 @@ k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ 
   if (h0) __builtin_nontemporal_store(w0, t4 + c);
   if (h1) __builtin_nontemporal_store(w1, t4 + c + 512);
   if (h2) __builtin_nontemporal_store(w2, t4 + c + 1024);
-}
-
-// V2: persistent grid (a few workgroups per CU), each walks rows; source-contiguous order.
-__global__ void __launch_bounds__(256)
-k_gather_rows_v2(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
-                 const int32_t* __restrict__ env, const int64_t* __restrict__ start,
-                 int B, int R, int overlapped, int32_t row_bytes, int64_t ring_stride, int order) {
-  const int n = row_bytes >> 4;
-  const int64_t total = (int64_t)R * B;
-  for (int64_t it = blockIdx.x; it < total; it += gridDim.x) {
-    int r, b;
-    if (order) { b = (int)(it / R); r = (int)(it % R); } else { r = (int)(it / B); b = (int)(it % B); }
-    const int64_t rb = (int64_t)r * B + b;
-    int32_t e = env[b];
-    if (e < 0 || e >= d.E) e = 0;
-    const int64_t src_off = row_src_off(d, overlapped, r, e, start[b]);
-    const u32x4* s4 = (const u32x4*)(ring + ((int64_t)e * d.C + src_off % d.C) * ring_stride);
-    u32x4* t4 = (u32x4*)(out + rb * (int64_t)row_bytes);
-    int c = threadIdx.x;
-    for (; c + 768 < n; c += 1024) {
-      u32x4 v0 = __builtin_nontemporal_load(s4 + c), v1 = __builtin_nontemporal_load(s4 + c + 256);
-      u32x4 v2 = __builtin_nontemporal_load(s4 + c + 512), v3 = __builtin_nontemporal_load(s4 + c + 768);
-      __builtin_nontemporal_store(v0, t4 + c); __builtin_nontemporal_store(v1, t4 + c + 256);
-      __builtin_nontemporal_store(v2, t4 + c + 512); __builtin_nontemporal_store(v3, t4 + c + 768);
-    }
-    for (; c < n; c += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + c), t4 + c);
-  }
 }
 
 // Per-step scalars of the batch.  One lane per (t, b):
@@ -529,7 +506,7 @@ struct mirl_replay {
   std::vector<void*> allocs;
   double* gpow_dev = nullptr;
   int gather_nt = 0;
-  int gather_variant = 1, gather_order = 1, gather_blocks = 2048;   // V1/O1: 5.85 TB/s vs 5.31 (profiles/)
+  int gather_variant = 1, gather_order = 0;
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
@@ -799,9 +776,6 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   if (vec && h->gather_variant == 1)
     hipLaunchKernelGGL(k_gather_rows_v1, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
-  else if (vec && h->gather_variant == 2)
-    hipLaunchKernelGGL(k_gather_rows_v2, dim3((unsigned)h->gather_blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
-                       env, start, B, h->rows, h->overlapped, row_bytes, ring_stride, h->gather_order);
   else if (h->gather_nt)
     hipLaunchKernelGGL(k_gather_rows<1>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);

@@ -273,7 +273,7 @@ def test_full_size_properties_config_d():
     buf.update_losses(idx, losses)
     v1, k1, _ = buf.tree_nodes()
     cap = len(v1) // 2
-    assert abs(v1[1] - v1[cap:].sum()) <= 1e-9 * v1[1]
+    assert abs(v1[1] - v1[cap:].sum()) <= 2e-6 * v1[1]   # f32-kind nodes round like np.float32 adds
     buf.update_losses(idx, losses)
     v2, k2, _ = buf.tree_nodes()
     assert np.array_equal(v1, v2) and np.array_equal(k1, k2)

@@ -1,0 +1,103 @@
+"""GPU: THE LOOP end to end through the plugin surface (json-style config ->
+registry -> device actor -> device replay -> trainer -> logger), tiny networks,
+synthetic env.  Checks the wiring the reference exercises with its cartpole
+smoke configs (readme.md:60-63): it runs, trains, syncs the target network,
+logs the reference's interval keys, and priorities/weights stay finite."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CNN = {"type": "cnn", "args": {"layers": [{"filters": 8, "kernel": 4, "stride": 2},
+                                          {"filters": 8, "kernel": 3, "stride": 1}]}}
+BASE = {
+    "acting": {"actor_envs": 8, "exploration": {"type": "epsilon_greedy", "args": {
+        "eps_start": 1.0, "eps_final": 0.05, "exploration_fraction": 0.5}}},
+    "env": "synthetic-atari", "env_args": {"frame_shape": [2, 20, 20], "n_actions": 4, "done_prob": 0.02},
+    "policy_args": {},
+}
+
+
+def _run(config, device_acting=True):
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.train import train
+    logger = NullLogger()
+    trainer = train(copy.deepcopy(config), logger, device_acting=device_acting)
+    assert logger.rows, "no log interval was reached"
+    last = logger.rows[-1][2]
+    assert last["this_interval"]["steps_trained"] > 0
+    assert last["this_interval"]["steps_trained_per_second"] > 0
+    assert math.isfinite(last["train"]["qloss"]) and math.isfinite(last["train"]["grad_norm"])
+    for p in trainer.policy.parameters():
+        assert torch.isfinite(p).all()
+    return trainer, last
+
+
+def test_dqn_uniform_replay_loop():
+    cfg = dict(BASE)
+    cfg["model"] = {"type": "sequential", "args": {"layer_configs": [CNN, {"type": "fc", "args": {"fc_size": 32}}]}}
+    cfg["training"] = {"type": "dqn", "args": {
+        "clip_rewards": True, "gamma": 0.99, "mbatch_size": 32, "nstep_train": 1, "nstep_target": 3,
+        "lr": 1e-3, "lr_anneal": True, "double_q": True, "clip_grad": 10.0, "target_update_freq": 400,
+        "total_steps": 4000, "log_freq": 1000, "warmup_steps": 400,
+        "history_mode": {"type": "replay", "args": {"size": 1000, "train_frequency": 8}}}}
+    trainer, last = _run(cfg)
+    # train_frequency=8: every acted sample is trained ~8 times once warmed up
+    assert 4.0 < last["this_interval"]["train_ratio"] < 12.0
+    # the target network was synced (target_update_freq crossed) and is not the online net
+    assert trainer.target_policy is not trainer.policy
+
+
+def test_recurrent_iqn_prioritized_loop_with_burn_in():
+    cfg = dict(BASE)
+    cfg["model"] = {"type": "sequential", "args": {"layer_configs": [
+        CNN, {"type": "lstm", "args": {"num_units": 16}}, {"type": "fc", "args": {"fc_size": 32}}]}}
+    cfg["policy_args"] = {"dueling": True, "embedding_dim": 8, "num_sampling_quantiles": 4}
+    cfg["training"] = {"type": "iqn", "args": {
+        "clip_rewards": False, "vf_scale_epsilon": 1e-3, "gamma": 0.99, "mbatch_size": 8, "nstep_train": 8,
+        "burn_in_timesteps": 4, "nstep_target": 2, "lr": 1e-3, "double_q": True, "rnn_bootstrap": True,
+        "clip_grad": 10.0, "clip_grad_dynamic_alpha": 0.9, "target_update_freq": 500,
+        "loss_timestep_aggregation": "mean", "loss_aggregation": "sum",
+        "total_steps": 3000, "log_freq": 1000, "warmup_steps": 300,
+        "history_mode": {"type": "prioritized_replay", "args": {
+            "size": 1200, "train_frequency": 4, "alpha": 0.9, "beta": 0.6, "beta_anneal": True,
+            "max_weight_factor": 0.9}}}}
+    trainer, last = _run(cfg)
+    hist = trainer.history_buffer
+    v, k, _ = hist.tree_nodes()
+    cap = len(v) // 2
+    assert np.isfinite(v).all() and v[1] > 0
+    assert abs(v[1] - v[cap:].sum()) <= 2e-6 * v[1]      # f32-kind nodes round like np.float32 adds
+    assert hist.stats()["total_items"] == 1200          # full, evicting
+    assert 0 < last["train"]["importance_weights"] <= 1.0
+
+
+def test_reference_style_host_actor_feeds_the_device_replay():
+    """device=False: the actor emits the reference's per-env sample dicts
+    (acting_interface.py:83-90) and History.update regroups them."""
+    cfg = dict(BASE)
+    cfg["model"] = {"type": "sequential", "args": {"layer_configs": [
+        CNN, {"type": "lstm", "args": {"num_units": 8}}, {"type": "fc", "args": {"fc_size": 16}}]}}
+    cfg["training"] = {"type": "dqn", "args": {
+        "gamma": 0.99, "mbatch_size": 4, "nstep_train": 4, "nstep_target": 2, "lr": 1e-3,
+        "target_update_freq": 200, "total_steps": 800, "log_freq": 400, "warmup_steps": 100,
+        "history_mode": {"type": "prioritized_replay", "args": {"size": 300, "train_frequency": 4}}}}
+    _run(cfg, device_acting=False)
+
+
+def test_unknown_training_argument_raises_typeerror():
+    """The reference consumes training.args through the _train(**kwargs) chain;
+    an unknown key is a TypeError (policy_trainer.py:284-286)."""
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.train import train
+    cfg = dict(BASE)
+    cfg["model"] = {"type": "sequential", "args": {"layer_configs": [CNN, {"type": "fc", "args": {"fc_size": 8}}]}}
+    cfg["training"] = {"type": "dqn", "args": {
+        "gamma": 0.99, "nstep_train": 1, "lr": 1e-3, "total_steps": 100, "no_such_option": 1,
+        "history_mode": {"type": "replay", "args": {"size": 100, "train_frequency": 4}}}}
+    with pytest.raises(TypeError):
+        train(copy.deepcopy(cfg), NullLogger())

@@ -106,12 +106,10 @@ def run(nt, size, E, B, T, P, n, iters):
 
 def sweep():
     size = int(os.environ.get("PROBE_SIZE", 262144))
-    combos = [dict(V=0, O=0), dict(V=1, O=0), dict(V=1, O=1), dict(V=2, O=0, BL=2048), dict(V=2, O=1, BL=2048),
-              dict(V=2, O=1, BL=4096), dict(V=2, O=0, BL=8192), dict(V=2, O=1, BL=1024)]
+    combos = [dict(V=0, O=0), dict(V=1, O=0), dict(V=1, O=1)]
     for c in combos:
         os.environ["MIRL_GATHER_VARIANT"] = str(c["V"])
         os.environ["MIRL_GATHER_ORDER"] = str(c["O"])
-        os.environ["MIRL_GATHER_BLOCKS"] = str(c.get("BL", 2048))
         r = run(1, size, 256, 512, 80, 40, 2, 10)
         print(json.dumps({"combo": c, "get_train_data_ms": r["get_train_data_ms"],
                           "frames_kernel_ms": r["frames_kernel_ms"],
