@@ -606,7 +606,6 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   h->gather_nt = nt ? atoi(nt) : 1;
   if (const char* v = getenv("MIRL_GATHER_VARIANT")) h->gather_variant = atoi(v);
   if (const char* v = getenv("MIRL_GATHER_ORDER")) h->gather_order = atoi(v);
-  if (const char* v = getenv("MIRL_GATHER_BLOCKS")) h->gather_blocks = atoi(v);   // non-temporal loads/stores: +7 % on the frame gather (profiles/)
   MIRL_HIP(hipDeviceSynchronize());
   *out = h;
   return MIRL_OK;
