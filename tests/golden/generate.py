@@ -571,6 +571,136 @@ def run_model_cases():
     print("model cases: %d arrays" % len(out))
 
 
+# --------------------------------------------------------------------------
+# End-to-end pin: the reference's own training loop (DQN + LSTM + prioritized
+# sequence replay + burn-in + double-Q, CPU) on a scripted actor stream ->
+# per-learner-step loss / grad-norm series.  The GPU test replays the same
+# stream through rltime_amd's loop and compares the series.
+# --------------------------------------------------------------------------
+E2E = dict(
+    spec=dict(seed=31, num_envs=8, frame_shape=(2, 12, 12), lstm_units=8, n_actions=4, done_prob=0.08),
+    model={"type": "sequential", "args": {"layer_configs": [
+        {"type": "cnn", "args": {"layers": [{"filters": 4, "kernel": 4, "stride": 2},
+                                            {"filters": 6, "kernel": 3, "stride": 1}]}},
+        {"type": "lstm", "args": {"num_units": 8}},
+        {"type": "fc", "args": {"fc_size": 16}}]}},
+    policy_args={"dueling": True, "cuda": False},
+    train=dict(total_steps=8 * 48, log_freq=10 ** 9, target_update_freq=64, clip_rewards=True,
+               double_q=True, huber_kappa=1.0, clip_grad=10.0, adam_epsilon=1e-5, gamma=0.99,
+               nstep_train=4, burn_in_timesteps=2, nstep_target=2, mbatch_size=4, lr=1e-3,
+               rnn_bootstrap=True, warmup_steps=0,
+               history_mode={"type": "prioritized_replay",
+                             "args": {"size": 240, "train_frequency": 4, "alpha": 0.7, "beta": 0.5}}),
+    seed=5)
+
+
+def run_e2e_case():
+    import gym
+    from rltime.acting.acting_interface import ActingInterface
+    from rltime.training.torch.dqn import DQN as RefDQN
+    spec = StreamSpec(**E2E["spec"])
+
+    class ScriptedActor(ActingInterface):
+        def __init__(self):
+            super().__init__(gym.spaces.Box(0, 255, spec.frame_shape, dtype=np.uint8),
+                             gym.spaces.Discrete(spec.n_actions))
+            self.t = 0
+
+        def get_env_count(self):
+            return spec.num_envs
+
+        def set_actor_policy(self, p):
+            pass
+
+        def update_state(self, progress, policy_state=None):
+            pass
+
+        def close(self):
+            pass
+
+        def get_samples(self, min_samples):
+            iters = (max(1, min_samples) + spec.num_envs - 1) // spec.num_envs
+            out = []
+            for step in vector_steps(spec, iters, start_step=self.t):
+                out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
+            self.t += iters
+            return out
+
+    class Quiet:
+        def log_result(self, *a, **k):
+            pass
+
+        def save_checkpoint(self, *a, **k):
+            pass
+
+    random.seed(E2E["seed"]); np.random.seed(E2E["seed"]); torch.manual_seed(E2E["seed"])
+    tr = RefDQN(logger=Quiet(), actors=ScriptedActor(), model_config=E2E["model"],
+                policy_args=E2E["policy_args"])
+    series = {"qloss": [], "grad_norm": []}
+    orig = tr.value_log.log
+
+    def tap(key, value, *a, **k):
+        if key in series and k.get("group") == "train":
+            series[key].append(float(value))
+        return orig(key, value, *a, **k)
+    tr.value_log.log = tap
+    init = {}
+    real_init = tr.init_policies
+
+    def init_and_snapshot():
+        real_init()
+        import io
+        f = io.BytesIO()
+        torch.save(tr.policy.state_dict(), f)
+        init["online"] = np.frombuffer(f.getvalue(), dtype=np.uint8)
+        f = io.BytesIO()
+        torch.save(tr.target_policy.state_dict(), f)
+        init["target"] = np.frombuffer(f.getvalue(), dtype=np.uint8)
+    tr.init_policies = init_and_snapshot
+    import copy
+    tr.train(**copy.deepcopy(E2E["train"]))
+    out = {"config": np.array(json.dumps(E2E)), "qloss": np.array(series["qloss"]),
+           "grad_norm": np.array(series["grad_norm"]),
+           "init_online": init["online"], "init_target": init["target"]}
+    np.savez_compressed(os.path.join(HERE, "e2e_dqn_lstm_per.npz"), **out)
+    print("e2e case: %d learner steps, qloss[0..3]=%s" % (len(series["qloss"]), series["qloss"][:4]))
+
+
+# --------------------------------------------------------------------------
+# Schedules: epsilon-greedy (exploration/epsilon_greedy.py:64-99) and the linear
+# anneal used for beta / LR (general/utils.py:85-103)
+# --------------------------------------------------------------------------
+EXPLORE_CASES = {
+    "decay": dict(eps_start=1.0, eps_final=0.01, exploration_fraction=0.1),
+    "apex": dict(eps_start=0.4, eps_final=0.01, eps_min=0.01, per_actor_exponent_factor=7,
+                 exploration_fraction=0.5),
+    "a3c": dict(eps_final=[0.1, 0.01, 0.5], eps_prob=[0.4, 0.3, 0.3], exploration_fraction=0.3),
+}
+
+
+def run_schedule_cases():
+    import gym
+    from rltime.exploration.epsilon_greedy import EpsilonGreedyExplorationManager as RefEps
+    from rltime.general.utils import anneal_value
+    out = {"cases": np.array(json.dumps(EXPLORE_CASES))}
+    space = gym.spaces.Discrete(6)
+    E = 16
+    for name, kw in EXPLORE_CASES.items():
+        m = RefEps(**kw, total_actors=E)
+        for pi, progress in enumerate((0.0, 0.03, 0.25, 0.5, 0.9, 1.0)):
+            np.random.seed(100 + pi)
+            acts, info = m.remap_actions(np.arange(E) % 6, list(range(E)), space, progress)
+            out["%s.p%d.actions" % (name, pi)] = np.array(acts)
+            out["%s.p%d.eps" % (name, pi)] = info["eps"]
+    grid = np.array([0.0, 0.1, 0.5, 0.99, 1.0, 1.7])
+    out["anneal.progress"] = grid
+    out["anneal.true"] = np.array([anneal_value(0.4, p, True, 1.0) for p in grid])
+    out["anneal.to"] = np.array([anneal_value(3e-4, p, 1e-5) for p in grid])
+    out["anneal.off"] = np.array([anneal_value(0.6, p, False) for p in grid])
+    np.savez_compressed(os.path.join(HERE, "schedule_cases.npz"), **out)
+    print("schedule cases: %d arrays" % len(out))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_tree_cases()
@@ -578,4 +708,6 @@ if __name__ == "__main__":
         run_replay_scenario(name, cfg)
     run_qmath_cases()
     run_model_cases()
+    run_e2e_case()
+    run_schedule_cases()
     print("golden fixtures written to", HERE)

@@ -58,12 +58,16 @@ def vector_steps(spec, count, start_step=0):
         yield out
 
 
-def as_reference_samples(spec, step):
+def as_reference_samples(spec, step, empty_layers=()):
     """One vector step -> the list of per-env sample dicts the reference actor
-    would emit (acting_interface.py:83-90, actor.py:132-145)."""
+    would emit (acting_interface.py:83-90, actor.py:132-145).  `empty_layers`
+    adds the `layer{i}_state: {}` entries a real model's make_input_state emits
+    for its non-recurrent layers (sequential.py:143-145)."""
     samples = []
     for e in range(spec.num_envs):
         state = {"x": step["frames"][e]}
+        for i in empty_layers:
+            state["layer%d_state" % i] = {}
         if spec.lstm_units:
             state["layer1_state"] = {
                 "hx": step["hx"][e], "cx": step["cx"][e],

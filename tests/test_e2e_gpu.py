@@ -1,0 +1,86 @@
+"""GPU: end-to-end pin of THE LOOP.  The unmodified reference trained
+DQN + LSTM + prioritized sequence replay + burn-in + double-Q on CPU from a
+scripted actor stream (tests/golden/generate.py: run_e2e_case); the same stream,
+seeds and initial weights go through rltime_amd's loop on the GPU (device
+replay, fused target/loss kernels, fused LSTM) and the per-learner-step loss and
+gradient-norm series must follow the reference's.
+
+Tolerance: 2e-3 relative over the first 40 steps — this is a *trajectory* (40
+Adam updates, CPU fp32 vs GPU fp32 kernels), not a single evaluation; single
+evaluations are held to 1e-4 in test_qmath_gpu.py."""
+import copy
+import io
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from tests import scenario
+from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_series_follows_reference():
+    from rltime_amd.acting.acting_interface import ActingInterface
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.spaces import Box, Discrete
+    from rltime_amd.training.dqn import DQN
+    d = np.load(os.path.join(scenario.GOLDEN, "e2e_dqn_lstm_per.npz"))
+    cfg = json.loads(str(d["config"]))
+    spec = StreamSpec(**cfg["spec"])
+
+    class ScriptedActor(ActingInterface):
+        def __init__(self):
+            super().__init__(Box(0, 255, spec.frame_shape, np.uint8), Discrete(spec.n_actions))
+            self.t = 0
+
+        def get_env_count(self):
+            return spec.num_envs
+
+        def set_actor_policy(self, p):
+            pass
+
+        def update_state(self, progress, policy_state=None):
+            pass
+
+        def close(self):
+            pass
+
+        def get_samples(self, min_samples):
+            iters = (max(1, min_samples) + spec.num_envs - 1) // spec.num_envs
+            out = []
+            for step in vector_steps(spec, iters, start_step=self.t):
+                out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
+            self.t += iters
+            return out
+
+    random.seed(cfg["seed"]); np.random.seed(cfg["seed"]); torch.manual_seed(cfg["seed"])
+    pargs = dict(cfg["policy_args"])
+    pargs["cuda"] = True
+    tr = DQN(logger=NullLogger(), actors=ScriptedActor(), model_config=cfg["model"], policy_args=pargs)
+    series = {"qloss": [], "grad_norm": []}
+    orig = tr.value_log.log
+
+    def tap(key, value, *a, **k):
+        if key in series and k.get("group") == "train":
+            series[key].append(float(value.item() if hasattr(value, "item") else value))
+        return orig(key, value, *a, **k)
+    tr.value_log.log = tap
+    real_init = tr.init_policies
+
+    def init_from_reference():
+        real_init()
+        tr.policy.load_state_dict(torch.load(io.BytesIO(d["init_online"].tobytes()), map_location="cuda"))
+        tr.target_policy.load_state_dict(torch.load(io.BytesIO(d["init_target"].tobytes()), map_location="cuda"))
+    tr.init_policies = init_from_reference
+    tr.train(**copy.deepcopy(cfg["train"]))
+    n = 40
+    assert len(series["qloss"]) == len(d["qloss"])          # same number of learner steps
+    np.testing.assert_allclose(series["qloss"][:n], d["qloss"][:n], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
+    print("max rel dev over all %d steps: qloss %.2e" % (
+        len(d["qloss"]), np.max(np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"]))))
