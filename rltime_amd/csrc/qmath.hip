@@ -49,33 +49,36 @@ k_target_dqn(int64_t M, int A, const float* __restrict__ qt, const float* __rest
   out[m] = finish_target(v, returns[m], powf(gamma, nsteps[m]), masks[m], vf_eps);
 }
 
-// One wavefront per transition.  Phase 1: lanes stride over the (Ns x A)
-// selection block, each lane owning a fixed action (lane % A when A divides
-// 64 evenly is not guaranteed, so lanes own element e -> action e % A and the
-// per-action sums are combined through LDS).  Phase 2: first-max argmax.
+// One wavefront per transition, no block-level barrier.
+// Phase 1: the (Ns x A) selection block is read with fully coalesced loads
+// (element e = lane + 64k, all loads issued back to back) into the wave's own
+// LDS strip.  Phase 2: lane a < A sums its action column from LDS in quantile
+// order (deterministic), mean, then a first-maximum argmax over A.
 // Phase 3: lanes < Nt pick the target quantile of that action and finish.
 __global__ void __launch_bounds__(256)
 k_target_iqn(int64_t M, int Nt, int Ns, int A, const float* __restrict__ zt, const float* __restrict__ zs,
              const float* __restrict__ returns, const float* __restrict__ nsteps, const float* __restrict__ masks,
              float gamma, double vf_eps, float* __restrict__ out) {
-  extern __shared__ float lds[];                 // [4 waves][A] action sums
+  extern __shared__ float lds[];                 // [4 waves][Ns*A + A]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t m = (int64_t)blockIdx.x * 4 + wave;
-  float* acc = lds + wave * A;
-  for (int a = lane; a < A; a += 64) acc[a] = 0.f;
-  __syncthreads();
-  if (m < M) {
-    const float* s = zs + m * (int64_t)Ns * A;
-    // lane a (< A) sums its action over the Ns quantiles in order: every load
-    // instruction reads A consecutive floats of one quantile row.
-    for (int a = lane; a < A; a += 64) {
-      float sum = 0.f;
-      for (int n = 0; n < Ns; ++n) sum += s[n * A + a];
-      acc[a] = sum / (float)Ns;
-    }
+  if (m >= M) return;                            // whole wave exits together; no __syncthreads below
+  const int NA = Ns * A;
+  float* strip = lds + wave * (NA + A);
+  float* acc = strip + NA;
+  const float* s = zs + m * (int64_t)NA;
+  for (int e = lane; e < NA; e += 64) strip[e] = s[e];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int a = lane; a < A; a += 64) {
+    float sum = 0.f;
+    for (int n = 0; n < Ns; ++n) sum += strip[n * A + a];
+    acc[a] = sum / (float)Ns;
   }
-  __syncthreads();
-  if (m >= M) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   int best = 0; float bv = acc[0];
   for (int a = 1; a < A; ++a) { float v = acc[a]; if (v > bv) { bv = v; best = a; } }
   const float ret = returns[m], mask = masks[m], disc = powf(gamma, nsteps[m]);
@@ -107,10 +110,66 @@ k_loss_dqn(int64_t M, int A, const float* __restrict__ q, const int64_t* __restr
   for (int k = 0; k < A; ++k) dq[m * A + k] = (k == a) ? g : 0.f;
 }
 
-// One wavefront per transition; lane j owns online quantile j (theta_j, tau_j)
-// and walks the Nt targets, which are broadcast from LDS.  Per pair (i, j):
+// One wavefront per transition, register/shuffle only (no LDS, no barrier) when
+// N and Nt fit one wavefront (the shipped configs: N = Nt = 32); otherwise the
+// generic LDS kernel below.  Lane l owns online quantile j = l % N and walks the
+// targets of part p = l / N (64/N parts split the Nt targets); targets are
+// broadcast with a wave shuffle.  Per pair (i, j):
 //   td = y_i - theta_j ; rho = |tau_j - 1{td<0}| * huber(td) / kappa
 //   row = mean_i sum_j rho ; report = mean_ij |td| ; d row / d theta_j = -(1/Nt) sum_i |..| huber'(td)/kappa
+__global__ void __launch_bounds__(256)
+k_loss_iqn_wave(int64_t M, int N, int Nt, int A, const float* __restrict__ z, const float* __restrict__ taus,
+                const int64_t* __restrict__ actions, const float* __restrict__ targets, const float* __restrict__ weights,
+                float kappa, float row_scale, float* __restrict__ row_loss, float* __restrict__ dz,
+                float* __restrict__ abs_td) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  const int parts = 64 / N;                      // >= 1 because N <= 64
+  const int j = lane % N, part = lane / N;
+  const bool active = part < parts;
+  const int a = (int)actions[m];
+  const float w = weights ? weights[m] : 1.f;
+  const float yv = lane < Nt ? targets[m * Nt + lane] : 0.f;
+  const float theta = z[(m * N + j) * (int64_t)A + a], tau = taus[m * N + j];
+  const int per = (Nt + parts - 1) / parts;
+  const int i0 = part * per, i1 = (i0 + per < Nt) ? i0 + per : Nt;
+  float lj = 0.f, aj = 0.f, gj = 0.f;
+  for (int i = 0; i < per; ++i) {
+    const int ii = i0 + i;                       // uniform trip count keeps the shuffle convergent
+    const float y = __shfl(yv, ii < Nt ? ii : 0);
+    if (active && ii < i1) {
+      float td = y - theta;                      // iqn.py:85-86
+      float val, grad;
+      huber_pair(td, kappa, val, grad);
+      float pen = fabsf(tau - (td < 0.f ? 1.f : 0.f));   // iqn.py:98-99 (indicator detached)
+      lj += pen * val / kappa;                   // iqn.py:100
+      gj -= pen * grad / kappa;                  // d td / d theta = -1
+      aj += fabsf(td);
+    }
+  }
+  // combine the parts of one quantile (lanes j, j+N, j+2N, ...), then all quantiles
+  for (int o = N; o < 64; o <<= 1) gj += __shfl_xor(gj, o);
+  float loss_sum = lj, abs_sum = aj;
+  for (int o = 32; o > 0; o >>= 1) { loss_sum += __shfl_xor(loss_sum, o); abs_sum += __shfl_xor(abs_sum, o); }
+  if (lane == 0) {
+    row_loss[m] = (loss_sum / (float)Nt) * w;    // iqn.py:102-104, then importance weight (:118)
+    abs_td[m] = abs_sum / ((float)Nt * (float)N);  // iqn.py:112
+  }
+  const float gq = gj * (w * row_scale / (float)Nt);
+  // dense gradient row: coalesced (N*A contiguous floats), zero off the acted action
+  float* g = dz + m * (int64_t)N * A;
+  const int NA = N * A;
+  for (int e0 = 0; e0 < NA; e0 += 64) {
+    const int e = e0 + lane;
+    const int jj = (e < NA ? e : 0) / A;
+    const float gv = __shfl(gq, jj);             // lane jj (part 0) holds quantile jj's gradient
+    if (e < NA) g[e] = (e - jj * A == a) ? gv : 0.f;
+  }
+}
+
+// Generic shapes (N or Nt > 64): lane j strides over quantiles, targets and the
+// per-quantile gradients go through the wave's LDS strip.
 __global__ void __launch_bounds__(256)
 k_loss_iqn(int64_t M, int N, int Nt, int A, const float* __restrict__ z, const float* __restrict__ taus,
            const int64_t* __restrict__ actions, const float* __restrict__ targets, const float* __restrict__ weights,
@@ -133,12 +192,12 @@ k_loss_iqn(int64_t M, int N, int Nt, int A, const float* __restrict__ z, const f
       const float theta = zr[j * A + a], tau = taus[m * N + j];
       float lj = 0.f, aj = 0.f, gj = 0.f;
       for (int i = 0; i < Nt; ++i) {
-        float td = y[i] - theta;                     // iqn.py:85-86
+        float td = y[i] - theta;
         float val, grad;
         huber_pair(td, kappa, val, grad);
-        float pen = fabsf(tau - (td < 0.f ? 1.f : 0.f));   // iqn.py:98-99 (indicator detached)
-        lj += pen * val / kappa;                     // iqn.py:100
-        gj -= pen * grad / kappa;                    // d td / d theta = -1
+        float pen = fabsf(tau - (td < 0.f ? 1.f : 0.f));
+        lj += pen * val / kappa;
+        gj -= pen * grad / kappa;
         aj += fabsf(td);
       }
       loss_sum += lj; abs_sum += aj;
@@ -149,10 +208,9 @@ k_loss_iqn(int64_t M, int N, int Nt, int A, const float* __restrict__ z, const f
   __syncthreads();                                   // gsh[] written by lane j, read by every lane below
   if (!live) return;
   if (lane == 0) {
-    row_loss[m] = (loss_sum / (float)Nt) * w;      // iqn.py:102-104, then importance weight (:118)
-    abs_td[m] = abs_sum / ((float)Nt * (float)N);  // iqn.py:112
+    row_loss[m] = (loss_sum / (float)Nt) * w;
+    abs_td[m] = abs_sum / ((float)Nt * (float)N);
   }
-  // dense gradient row: coalesced (N*A contiguous floats), zero off the acted action
   float* g = dz + m * (int64_t)N * A;
   for (int e = lane; e < N * A; e += 64) { int j = e / A, k = e - j * A; g[e] = (k == a) ? gsh[j] : 0.f; }
 }
@@ -174,7 +232,8 @@ extern "C" int mirl_q_target_iqn(int64_t M, int32_t Nt, int32_t Ns, int32_t A, c
                                  const float* returns, const float* nsteps, const float* masks, double gamma, double vf_eps,
                                  float* targets, void* stream) {
   if (M <= 0 || A <= 0 || Nt <= 0 || Ns <= 0 || !z_target || !z_select || !returns || !nsteps || !masks || !targets) return fail(MIRL_ERR_ARG, "bad q_target_iqn arguments");
-  size_t lds = sizeof(float) * 4 * (size_t)A;
+  size_t lds = sizeof(float) * 4 * ((size_t)Ns * A + A);
+  if (lds > 64 * 1024) return fail(MIRL_ERR_ARG, "q_target_iqn: Ns*A too large for the LDS strip");
   hipLaunchKernelGGL(k_target_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)Nt, (int)Ns, (int)A,
                      z_target, z_select, returns, nsteps, masks, (float)gamma, vf_eps, targets);
   MIRL_LAUNCH_CHECK();
@@ -194,9 +253,14 @@ extern "C" int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const 
                              const float* targets, const float* weights, double kappa, double row_scale, float* row_loss, float* dz,
                              float* abs_td, void* stream) {
   if (M <= 0 || A <= 0 || N <= 0 || Nt <= 0 || !z || !taus || !actions || !targets || !row_loss || !dz || !abs_td) return fail(MIRL_ERR_ARG, "bad loss_iqn arguments");
-  size_t lds = sizeof(float) * 4 * (size_t)(Nt + N);
-  hipLaunchKernelGGL(k_loss_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)N, (int)Nt, (int)A, z, taus,
-                     actions, targets, weights, (float)kappa, (float)row_scale, row_loss, dz, abs_td);
+  if (N <= 64 && Nt <= 64 && (64 % N) == 0) {
+    hipLaunchKernelGGL(k_loss_iqn_wave, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M, (int)N, (int)Nt, (int)A, z, taus,
+                       actions, targets, weights, (float)kappa, (float)row_scale, row_loss, dz, abs_td);
+  } else {
+    size_t lds = sizeof(float) * 4 * (size_t)(Nt + N);
+    hipLaunchKernelGGL(k_loss_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)N, (int)Nt, (int)A, z, taus,
+                       actions, targets, weights, (float)kappa, (float)row_scale, row_loss, dz, abs_td);
+  }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
