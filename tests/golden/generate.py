@@ -62,6 +62,9 @@ def flatten(prefix, tree, out):
     if isinstance(tree, dict):
         for k, v in tree.items():
             flatten(prefix + "." + k if prefix else k, v, out)
+    elif isinstance(tree, (tuple, list)):
+        for i, v in enumerate(tree):
+            flatten("%s.%d" % (prefix, i), v, out)
     else:
         out[prefix] = tree.numpy() if isinstance(tree, torch.Tensor) \
             else np.asarray(tree)
@@ -131,6 +134,16 @@ SCENARIOS = {
                 ("draw", 5, 603, 0.3), ("losses", 703), ("feed", 9),
                 ("draw", 5, 604, 0.6), ("losses", 704), ("feed", 5),
                 ("losses", 705), ("draw", 5, 605, 0.95)]),
+    "per_seq_tuple_obs": dict(
+        mode="per",
+        spec=dict(seed=17, num_envs=3, frame_shape=(1, 4, 4), lstm_units=4,
+                  n_actions=4, done_prob=0.1, extra_features=6),
+        hist=dict(size=45, train_frequency=4, nstep_target=2, nstep_train=4,
+                  prefix_steps=1, alpha=0.8, beta=0.5),
+        gamma=0.99,
+        script=[("feed", 11), ("draw", 4, 900, 0.1), ("losses", 901),
+                ("feed", 9), ("draw", 4, 902, 0.5), ("losses", 903),
+                ("draw", 4, 904, 0.7)]),
     "per_seq_global": dict(
         mode="per",
         spec=dict(seed=16, num_envs=3, frame_shape=(1, 2, 2), lstm_units=2,

@@ -13,7 +13,7 @@ import numpy as np
 class StreamSpec:
     def __init__(self, seed, num_envs, frame_shape=(2, 3, 3), lstm_units=0,
                  n_actions=4, done_prob=0.1, fractional_rewards=True,
-                 env_base=0):
+                 env_base=0, extra_features=0):
         self.seed = seed
         self.num_envs = num_envs
         self.frame_shape = tuple(frame_shape)
@@ -22,6 +22,9 @@ class StreamSpec:
         self.done_prob = done_prob
         self.fractional_rewards = fractional_rewards
         self.env_base = env_base
+        # >0: tuple observation (frame, extra f32 vector), as the reference's
+        # ExtraFeaturesEnvWrapper produces (env_wrappers/common.py)
+        self.extra_features = extra_features
 
 
 def frame_for(env, offset, shape):
@@ -49,6 +52,8 @@ def vector_steps(spec, count, start_step=0):
             "actions": rng.randint(0, spec.n_actions, size=E),
             "qvalues": rng.randn(E, spec.n_actions).astype(np.float32),
         }
+        if spec.extra_features:
+            out["extra"] = rng.randn(E, spec.extra_features).astype(np.float32)
         if spec.lstm_units:
             out["hx"] = rng.randn(E, spec.lstm_units).astype(np.float32)
             out["cx"] = rng.randn(E, spec.lstm_units).astype(np.float32)
@@ -66,6 +71,8 @@ def as_reference_samples(spec, step, empty_layers=()):
     samples = []
     for e in range(spec.num_envs):
         state = {"x": step["frames"][e]}
+        if spec.extra_features:
+            state["x"] = (step["frames"][e], step["extra"][e])
         for i in empty_layers:
             state["layer%d_state" % i] = {}
         if spec.lstm_units:

@@ -10,7 +10,7 @@ from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SCENARIOS = ["uniform_t1", "uniform_seq", "uniform_seq_noxing", "per_t1",
-             "per_seq", "per_seq_global"]
+             "per_seq", "per_seq_global", "per_seq_tuple_obs"]
 
 # importance weights are floating point: the reference evaluates them in f32 or
 # f64 depending on scalar kinds, the device in f64 -> f32.
@@ -26,6 +26,9 @@ def flatten(prefix, tree, out):
     if isinstance(tree, dict):
         for k, v in tree.items():
             flatten(prefix + "." + k if prefix else k, v, out)
+    elif isinstance(tree, (tuple, list)):
+        for i, v in enumerate(tree):
+            flatten("%s.%d" % (prefix, i), v, out)
     else:
         out[prefix] = tree
     return out

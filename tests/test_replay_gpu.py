@@ -279,3 +279,119 @@ def test_full_size_properties_config_d():
     assert np.array_equal(v1, v2) and np.array_equal(k1, k2)
     assert st["active_sequences"] == np.count_nonzero(v1[cap:])
     buf.close()
+
+
+def test_ragged_vector_steps_vs_oracle():
+    """Calls that carry only a subset of the envs, in shuffled env order (each env
+    at most once per call): per-env rings advance unevenly, the global FIFO
+    eviction and the PER activation order must still follow the reference."""
+    from oracle import replay as orc
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    spec = StreamSpec(seed=51, num_envs=5, frame_shape=(2, 5, 7), lstm_units=4, n_actions=3, done_prob=0.1)
+    hist = dict(size=120, train_frequency=4, nstep_target=2, nstep_train=4, prefix_steps=2, alpha=0.7, beta=0.4)
+    ora = orc.OraclePrioritizedReplay(**hist, discount_function=orc.make_discount(0.95))
+    dev = PrioritizedReplayHistoryBuffer(**hist, gamma=0.95, num_envs=5, env_base=0, env_ring_slack=80)
+    rng = np.random.RandomState(9)
+    per_env_step = [0] * 5
+    for call in range(140):
+        envs = [e for e in rng.permutation(5) if rng.rand() < 0.7] or [int(rng.randint(5))]
+        chunk = []
+        for e in envs:
+            st = next(vector_steps(spec, 1, start_step=per_env_step[e]))
+            chunk.append(as_reference_samples(spec, st)[e])
+            per_env_step[e] += 1
+        ora.update([dict(s) for s in chunk])
+        dev.update([dict(s) for s in chunk])
+        if call % 20 == 19:
+            random.seed(call)
+            a = ora.get_train_data(4, 0.3)
+            random.seed(call)
+            b = dev.get_train_data(4, 0.3)
+            assert (a is None) == (b is None)
+            if a is not None:
+                fb = {k: scenario.to_numpy(v) for k, v in scenario.flatten("", b, {}).items()}
+                for k, w in scenario.flatten("", a, {}).items():
+                    if k.endswith("importance_weights"):
+                        np.testing.assert_allclose(fb[k], w.astype(np.float32), rtol=scenario.WEIGHT_RTOL)
+                    else:
+                        assert np.array_equal(fb[k], scenario.make_tensor_dtype(w) if not k.endswith(("actions", "loss_indices")) else w), k
+            assert np.array_equal(dev.free_slots(), np.array(list(ora.free_slots)))
+    dev.close()
+
+
+def test_large_batch_strata_on_device():
+    """B = 3000 > the 1024 lanes of the sampling workgroup: every stratum still
+    gets its own query (lanes loop), indices stay sorted, weights max is 1."""
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    buf = PrioritizedReplayHistoryBuffer(size=40000, train_frequency=0, nstep_target=1, nstep_train=1,
+                                         gamma=0.99, device_rng=True, keep_policy_outputs=False)
+    E = 50
+    buf.configure({"x": np.zeros((32,), np.uint8)}, num_envs=E)
+    dev = buf.device
+    fr = torch.zeros((E, 32), dtype=torch.uint8, device=dev)
+    z = torch.zeros(E, device=dev)
+    for _ in range(900):
+        buf.update_batch(fr, z.int(), z, z.to(torch.uint8))
+    B = 3000
+    batch = buf.get_train_data(B, 0.5)
+    idx = batch["extra_data"]["loss_indices"].reshape(-1, 2)
+    buf.update_losses(idx, torch.rand(B, device=dev) * 3)
+    batch = buf.get_train_data(B, 0.5)
+    slot = buf.last_sample["slot"].cpu().numpy()
+    assert np.all(np.diff(slot) >= 0) and len(np.unique(slot)) > B // 2
+    w = batch["extra_data"]["importance_weights"].cpu().numpy()
+    assert w.max() == 1.0 and w.min() > 0
+    buf.close()
+
+
+@pytest.mark.parametrize("mode", ["dqn_uniform_config_b", "rainbow_per_config_c"])
+def test_full_size_properties_t1_configs(mode):
+    """BASELINE configs[1] (DQN, uniform, B=256) and configs[2] (Rainbow-style,
+    PER with a 2^20-leaf tree, n=3, B=512) at the full 1M-transition size."""
+    from rltime_amd.history import ReplayHistoryBuffer, PrioritizedReplayHistoryBuffer
+    E = 32
+    per = mode.startswith("rainbow")
+    n = 3 if per else 1
+    B = 512 if per else 256
+    kw = dict(size=1000000, train_frequency=8, nstep_target=n, nstep_train=1, gamma=0.99,
+              device_rng=True, keep_policy_outputs=False)
+    buf = PrioritizedReplayHistoryBuffer(alpha=0.6, beta=0.4, beta_anneal=True, **kw) if per \
+        else ReplayHistoryBuffer(**kw)
+    buf.configure({"x": np.zeros((4, 84, 84), np.uint8)}, num_envs=E)
+    dev = buf.device
+    env_ids = torch.arange(E, device=dev, dtype=torch.int32)
+    frames = torch.zeros((E, 4 * 84 * 84), dtype=torch.uint8, device=dev)
+    act = torch.zeros(E, dtype=torch.int32, device=dev)
+    done = torch.zeros(E, dtype=torch.uint8, device=dev)
+    rew = torch.ones(E, device=dev)
+    steps = 1000000 // E + 50
+    for s in range(steps):
+        frames[:, 0] = env_ids.to(torch.uint8)
+        for k in range(4):
+            frames[:, 1 + k] = (s >> (8 * k)) & 0xFF
+        buf.update_batch(frames.view(E, 4, 84, 84), act, rew, done)
+    assert buf.stats()["total_items"] == 1000000
+    buf.train_quota = 0
+    if per:
+        assert buf.stats()["tree_capacity"] == 1 << 20
+    batch = buf.get_train_data(B, 0.25)
+    env = buf.last_sample["env"].cpu().numpy(); start = buf.last_sample["start"].cpu().numpy()
+    x = batch["states"]["x"].reshape(1, B, -1)[0, :, :5].cpu().numpy().astype(np.int64)
+    tx = batch["target_states"]["x"].reshape(1, B, -1)[0, :, :5].cpu().numpy().astype(np.int64)
+    off = lambda h: h[:, 1] + (h[:, 2] << 8) + (h[:, 3] << 16) + (h[:, 4] << 24)   # noqa: E731
+    assert np.array_equal(x[:, 0], env) and np.array_equal(off(x), start - 1)           # state = next_state of o-1
+    assert np.array_equal(tx[:, 0], env) and np.array_equal(off(tx), start + n - 1)     # n-step target state
+    ret = batch["returns"].cpu().numpy()[0]
+    want = sum(0.99 ** k for k in range(n))
+    np.testing.assert_allclose(ret, np.float32(want), rtol=1e-7)
+    assert np.all(batch["nsteps"].cpu().numpy() == n) and np.all(batch["target_masks"].cpu().numpy() == 1)
+    if per:
+        slot = buf.last_sample["slot"].cpu().numpy()
+        assert np.all(np.diff(slot) >= 0)
+        idx = batch["extra_data"]["loss_indices"].reshape(-1, 2)
+        buf.update_losses(idx, torch.randn(B, device=dev))
+        v, k, _ = buf.tree_nodes()
+        cap = len(v) // 2
+        assert abs(v[1] - v[cap:].sum()) <= 2e-6 * v[1]
+        assert np.all(k[cap:][np.unique(slot)] == 1)          # updated leaves are np.float32-kind
+    buf.close()
