@@ -772,7 +772,7 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = h->prof && ring == (const void*)h->d.frames;
   if (timed) { MIRL_HIP(hipEventCreate(&e0)); MIRL_HIP(hipEventCreate(&e1)); MIRL_HIP(hipEventRecord(e0, st)); }
-  if (vec && h->gather_variant == 1)
+  if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16)      // small rows (recurrent state) keep the 256-lane shape
     hipLaunchKernelGGL(k_gather_rows_v1, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
   else if (h->gather_nt)

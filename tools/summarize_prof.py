@@ -59,10 +59,15 @@ def main(out):
         vals = []
         for r in csv.DictReader(open(f)):
             if "k_gather_rows" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cname:
-                # only the frame launches: 62464 workgroups of 256 (B=512, L+n=122)
-                if int(r.get("Grid_Size", "0")) >= 62464 * 256 and int(r.get("Workgroup_Size", "256")) == 256:
+                # only the frame launches: 62464 workgroups (B=512, L+n=122) of 512 lanes
+                # (256 lanes for the older launch shape); the recurrent-state gather of
+                # the same kernel family has 256-lane workgroups and far fewer bytes
+                wg = int(r.get("Workgroup_Size", "256"))
+                grid = int(r.get("Grid_Size", "0"))
+                if grid == 62464 * wg and (wg == 512 or "v1" not in r.get("Kernel_Name", "")):
                     vals.append(float(r["Counter_Value"]))
         if vals:
+            vals = [v for v in vals if v > 0.5 * max(vals)]     # drop the (much smaller) recurrent-state launches
             with open(os.path.join(out, "gather_%s_launches.txt" % cname), "w") as fh:
                 fh.write("\n".join("%.1f" % v for v in vals))
             res[cname] = sorted(vals)[len(vals) // 2]       # median launch, KiB units
