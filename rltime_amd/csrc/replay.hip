@@ -26,7 +26,6 @@
 #include "book.hpp"
 #include "np_emul.h"
 
-#include <mutex>
 #include <cstring>
 #include <cmath>
 #include <cstdlib>
@@ -96,12 +95,12 @@ k_ingest_scalars(Dev d, int K, const int32_t* __restrict__ s_env, const int64_t*
 }
 
 struct LossGet {
-  const float* loss; int64_t base_slot; int64_t C; int64_t ring0; int64_t off;
+  const float* loss; int64_t C; int64_t ring0; int64_t off;
   __device__ float operator()(int t) const { return loss[ring0 + (off + t) % C]; }
 };
 
 __device__ __forceinline__ TV priority_of(const Dev& d, int32_t e, int64_t base) {
-  LossGet g{d.loss, 0, d.C, (int64_t)e * d.C, base};
+  LossGet g{d.loss, d.C, (int64_t)e * d.C, base};
   PrioParams p{d.T, d.alpha, d.mwf};
   return seq_priority(g, p);
 }

@@ -288,7 +288,7 @@ def test_ragged_vector_steps_vs_oracle():
     from oracle import replay as orc
     from rltime_amd.history import PrioritizedReplayHistoryBuffer
     spec = StreamSpec(seed=51, num_envs=5, frame_shape=(2, 5, 7), lstm_units=4, n_actions=3, done_prob=0.1)
-    hist = dict(size=120, train_frequency=4, nstep_target=2, nstep_train=4, prefix_steps=2, alpha=0.7, beta=0.4)
+    hist = dict(size=120, train_frequency=0, nstep_target=2, nstep_train=4, prefix_steps=2, alpha=0.7, beta=0.4)
     ora = orc.OraclePrioritizedReplay(**hist, discount_function=orc.make_discount(0.95))
     dev = PrioritizedReplayHistoryBuffer(**hist, gamma=0.95, num_envs=5, env_base=0, env_ring_slack=80)
     rng = np.random.RandomState(9)
@@ -395,3 +395,45 @@ def test_full_size_properties_t1_configs(mode):
         assert abs(v[1] - v[cap:].sum()) <= 2e-6 * v[1]
         assert np.all(k[cap:][np.unique(slot)] == 1)          # updated leaves are np.float32-kind
     buf.close()
+
+
+def test_error_behaviour_mirrors_reference_asserts():
+    """The reference aborts with asserts; the C-ABI returns an error code and a
+    message (never aborts), surfaced as MirlError by the mirror."""
+    from rltime_amd._lib import MirlError
+    from rltime_amd.history import ReplayHistoryBuffer, PrioritizedReplayHistoryBuffer
+    # prioritized_replay_history.py:102  "Overlap must be < nstep_train"
+    with pytest.raises(AssertionError):
+        PrioritizedReplayHistoryBuffer(size=64, train_frequency=4, nstep_target=1, nstep_train=4, overlap=4, gamma=0.9)
+    # history.py:43-44: n-step > 1 needs a discount
+    with pytest.raises((AssertionError, ValueError)):
+        ReplayHistoryBuffer(size=64, train_frequency=4, nstep_target=3, nstep_train=1)
+    # replay_history.py:113: buffer full but no batch can ever be formed
+    spec = StreamSpec(seed=1, num_envs=4, frame_shape=(1, 4, 4), done_prob=0.0)
+    buf = ReplayHistoryBuffer(size=16, train_frequency=0, nstep_target=2, nstep_train=4, gamma=0.9)
+    for st in vector_steps(spec, 6):
+        buf.update(as_reference_samples(spec, st))
+    np.random.seed(0)
+    with pytest.raises(MirlError, match="replay_history.py:113"):
+        buf.get_train_data(2)
+    buf.close()
+    # replay_history.py:179-181: train/act ratio drift
+    buf = ReplayHistoryBuffer(size=64, train_frequency=4, nstep_target=1, nstep_train=1, gamma=0.9)
+    for st in vector_steps(spec, 8):
+        buf.update(as_reference_samples(spec, st))
+    np.random.seed(0)
+    with pytest.raises(MirlError, match="179-181"):
+        for _ in range(200):
+            buf.get_train_data(4)
+    buf.close()
+    # an env id outside the shard
+    buf = ReplayHistoryBuffer(size=64, train_frequency=0, nstep_target=1, nstep_train=1, gamma=0.9, num_envs=4, env_base=0)
+    bad = as_reference_samples(spec, next(vector_steps(spec, 1)))
+    bad[2]["env_id"] = 9
+    with pytest.raises(MirlError, match="outside this shard"):
+        buf.update(bad)
+    buf.close()
+    # get_train_data before anything was fed -> None (feed more)
+    buf = PrioritizedReplayHistoryBuffer(size=64, train_frequency=4, nstep_target=1, nstep_train=1, gamma=0.9)
+    assert buf.get_train_data(4, 0.0) is None
+    assert buf.needed_feed_count(4, 8) == 8
