@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .fused import linear_relu
 from .utils import conv2d, conv_out_size, init_weight, linear
 
 
@@ -75,10 +76,14 @@ class FC(BaseModule):
             self.layers.append(block)
         self.out_shape = (sz,)
         self.activation = getattr(F, activation)
+        self.fuse_relu = activation == "relu"
 
     def forward(self, x, **kwargs):
         x = x.reshape(-1, self.flat_size)
         for block in self.layers:
+            if self.fuse_relu and len(block) == 1:
+                x = linear_relu(x, block[0].weight, block[0].bias)   # ReLU in the GEMM epilogue on the GPU
+                continue
             for sub in block:
                 x = sub(x)
             x = self.activation(x)

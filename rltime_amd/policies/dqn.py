@@ -4,6 +4,7 @@ import torch
 import torch.nn.functional as F
 
 from .torch_policy import TorchPolicy
+from rltime_amd.models.torch.fused import linear_relu
 from rltime_amd.models.torch.utils import linear
 
 
@@ -30,7 +31,8 @@ class DQNPolicy(TorchPolicy):
     def _process_dueling(self, action_outputs, state_layer):
         """dqn.py:74-87: V + A - mean_a A."""
         state_layer = state_layer.reshape(state_layer.shape[0], -1)
-        v = self.value_layer(F.relu(self.value_hidden_layer(state_layer)))
+        v = self.value_layer(linear_relu(state_layer, self.value_hidden_layer.weight,
+                                         self.value_hidden_layer.bias))
         v, action_dim = self._shape_action_outputs(v)
         return v + action_outputs - action_outputs.mean(action_dim, keepdim=True)
 

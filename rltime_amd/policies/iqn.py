@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .dqn import DQNPolicy
+from rltime_amd.models.torch.fused import linear_relu
 from rltime_amd.models.torch.utils import linear
 
 
@@ -26,7 +27,7 @@ class IQNPolicy(DQNPolicy):
         x = x.reshape(batch, -1)
         quantiles = torch.rand(batch * n, device=self.embedding_range.device)
         emb = torch.cos(self.embedding_range * np.pi * quantiles.unsqueeze(1))
-        emb = F.relu(self.quantile_layer(emb))
+        emb = linear_relu(emb, self.quantile_layer.weight, self.quantile_layer.bias)
         # iqn.py:84,102: interleaved repeat of x times the embedding, grouped
         # (batch, n).  Broadcasting gives the same values without materialising
         # the repeated (batch*n, state) copy of x.

@@ -55,3 +55,24 @@ def test_fused_lstm_no_grad_matches():
         s2 = a.last_state
     np.testing.assert_allclose(o1.cpu(), o2.cpu(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(s1[1].cpu(), s2[1].cpu(), rtol=1e-4, atol=2e-5)
+
+
+def test_linear_relu_epilogue_matches_autograd():
+    """fused.linear_relu (hipBLASLt ReLU epilogue + explicit backward) == relu(linear)."""
+    import torch.nn.functional as F
+    from rltime_amd.models.torch.fused import linear_relu
+    g = torch.Generator().manual_seed(0)
+    for rows, fin, fout in [(7, 5, 3), (4096, 64, 512), (20000, 512, 512)]:
+        x = torch.randn(rows, fin, generator=g).cuda()
+        w = (torch.randn(fout, fin, generator=g) * 0.1).cuda()
+        b = torch.randn(fout, generator=g).cuda()
+        up = torch.randn(rows, fout, generator=g).cuda()
+        outs = []
+        for fn in (linear_relu, lambda a, ww, bb: F.relu(F.linear(a, ww, bb))):
+            xi, wi, bi = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = fn(xi, wi, bi)
+            (y * up).sum().backward()
+            outs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+        for a, c in zip(outs[0], outs[1]):
+            scale = float(c.abs().max()) + 1e-6
+            np.testing.assert_allclose(a.cpu() / scale, c.cpu() / scale, rtol=1e-4, atol=1e-5)
