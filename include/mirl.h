@@ -245,6 +245,12 @@ int mirl_lstm_cell_bwd(int32_t B, int32_t H, float* gates, const float* c_t, con
                        const float* d_out, const float* dh_rec, float* dc_rec, const float* keep_next,
                        int32_t first, void* stream);
 
+/* The CNN's input conversion (rltime/models/torch/modules/cnn.py:44-45,
+ * `x.float() * scale`) fused with the NCHW -> NHWC layout change: src uint8
+ * [N][C][HW] -> dst float32 [N][HW][C] = src * scale, one pass.                  */
+int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale,
+                            float* dst, void* stream);
+
 /* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
 int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
 

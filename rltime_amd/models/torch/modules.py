@@ -17,6 +17,17 @@ from .fused import linear_relu
 from .utils import conv2d, conv_out_size, init_weight, linear
 
 
+def _frames_to_f32_nhwc(x, scale):
+    import ctypes as C
+    from rltime_amd._lib import lib, check
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    check(lib.mirl_frames_to_f32_nhwc(
+        n, c, h * w, C.c_void_p(x.data_ptr()), float(scale), C.c_void_p(out.data_ptr()),
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_frames_to_f32_nhwc")
+    return out
+
+
 class BaseModule(nn.Module):
     """modules/base.py:4-13."""
 
@@ -49,9 +60,14 @@ class CNN(BaseModule):
             self.to(memory_format=torch.channels_last)
 
     def forward(self, x, **kwargs):
-        if self.channels_last:
+        if self.channels_last and self.scale and x.is_cuda and x.dtype == torch.uint8 \
+                and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled():
+            x = _frames_to_f32_nhwc(x, self.scale)       # one fused HIP pass (csrc/lstm.hip)
+        elif self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        if self.scale:
+            if self.scale:
+                x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale
+        elif self.scale:
             # uint8 * python float promotes to float32 in ONE pass (same values as
             # x.float() * scale, cnn.py:44-45)
             x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale

@@ -76,3 +76,15 @@ def test_linear_relu_epilogue_matches_autograd():
         for a, c in zip(outs[0], outs[1]):
             scale = float(c.abs().max()) + 1e-6
             np.testing.assert_allclose(a.cpu() / scale, c.cpu() / scale, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(3, 4, 84, 84), (5, 4, 7, 9), (2, 1, 20, 20), (7, 3, 6, 6), (1000, 4, 84, 84)])
+def test_fused_frame_conversion_is_exact(shape):
+    """u8 NCHW -> f32 NHWC * (1/255) in one pass == x.float() * scale (cnn.py:44-45), bit for bit."""
+    from rltime_amd.models.torch.modules import _frames_to_f32_nhwc
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).cuda()
+    got = _frames_to_f32_nhwc(x, 1.0 / 255.0)
+    want = x.float() * (1.0 / 255.0)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
