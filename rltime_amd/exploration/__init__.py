@@ -1,6 +1,10 @@
-"""Exploration plugins (reference rltime/exploration/__init__.py)."""
+"""Exploration plugins (registry group "exploration")."""
+from rltime_amd.general.lazy_types import LazyTypes
+
+_TABLE = LazyTypes({
+    "epsilon_greedy": "rltime_amd.exploration.epsilon_greedy:EpsilonGreedyExplorationManager",
+})
 
 
 def get_types():
-    from .epsilon_greedy import EpsilonGreedyExplorationManager
-    return {"epsilon_greedy": EpsilonGreedyExplorationManager}
+    return _TABLE

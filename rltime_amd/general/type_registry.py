@@ -1,31 +1,32 @@
-"""String -> class registry with the reference's groups and keys
-(rltime/general/type_registry.py:6-39)."""
+"""Plugin registry: (group, name) -> class.  Groups and names are the ones the
+reference's json configs use (trainers, models, modules, history, exploration);
+anything that is not a string is returned unchanged, so configs may also carry
+classes directly."""
+import importlib
 
-_registry = None
+_GROUP_MODULES = {
+    "trainers": "rltime_amd.training",
+    "models": "rltime_amd.models",
+    "modules": "rltime_amd.models.torch.modules",
+    "history": "rltime_amd.history",
+    "exploration": "rltime_amd.exploration",
+}
+_cache = {}
 
 
-def _build():
-    from rltime_amd import training, models, history, exploration
-    from rltime_amd.models.torch import modules
-    return {
-        "trainers": training.get_types(),
-        "models": models.get_types(),
-        "modules": modules.get_types(),
-        "history": history.get_types(),
-        "exploration": exploration.get_types(),
-    }
+def _group(group):
+    if group not in _GROUP_MODULES:
+        raise TypeError("No types registered for group '%s'" % group)
+    if group not in _cache:
+        _cache[group] = importlib.import_module(_GROUP_MODULES[group]).get_types()
+    return _cache[group]
 
 
 def get_registered_type(group, ref):
-    global _registry
     if not isinstance(ref, str):
-        return ref                      # a python class passes straight through
-    if _registry is None:
-        _registry = _build()
-    if group not in _registry:
-        raise TypeError("No types registered for group '%s'" % group)
-    if ref not in _registry[group]:
-        raise TypeError(
-            "No type '%s' registered in group '%s', available types in this "
-            "group are: %s" % (ref, group, list(_registry[group].keys())))
-    return _registry[group][ref]
+        return ref
+    table = _group(group)
+    if ref not in table:
+        raise TypeError("No type '%s' registered in group '%s', available types in this group are: %s"
+                        % (ref, group, list(table.keys())))
+    return table[ref]

@@ -1,6 +1,8 @@
-"""Model plugins, registry keys as in the reference (rltime/models/__init__.py)."""
+"""Model plugins (registry group "models")."""
+from rltime_amd.general.lazy_types import LazyTypes
+
+_TABLE = LazyTypes({"sequential": "rltime_amd.models.torch.sequential:SequentialModel"})
 
 
 def get_types():
-    from .torch.sequential import SequentialModel
-    return {"sequential": SequentialModel}
+    return _TABLE

@@ -1,9 +1,12 @@
-"""Trainer plugins, registry keys as in the reference
-(rltime/training/torch/__init__.py:8-15).  Only the Q-learning trainers are on
-the MI355X hot path; a2c / ppo / dist_dqn are out of scope."""
+"""Trainer plugins (registry group "trainers").  Only the Q-learning trainers
+are on the MI355X hot path; a2c / ppo / dist_dqn are out of scope."""
+from rltime_amd.general.lazy_types import LazyTypes
+
+_TABLE = LazyTypes({
+    "dqn": "rltime_amd.training.dqn:DQN",
+    "iqn": "rltime_amd.training.iqn:IQN",
+})
 
 
 def get_types():
-    from .dqn import DQN
-    from .iqn import IQN
-    return {"dqn": DQN, "iqn": IQN}
+    return _TABLE
