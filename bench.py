@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--envs", type=int, default=256, help="envs per GPU")
     ap.add_argument("--replay-size", type=int, default=1000000, help="transitions per GPU")
     ap.add_argument("--acting", action="store_true", help="run the real actor (policy forward) instead of synthetic actor output")
+    ap.add_argument("--acting-graph", action="store_true", help="with --acting: replay the acting forward from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--channels-last", action="store_true", help="NHWC conv stack (experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,7 +81,7 @@ def build_trainer(args, rank, world, device):
                                       "keep_policy_outputs": False}}}}})
     if args.channels_last:
         config["model"]["args"]["layer_configs"][0]["args"]["channels_last"] = True
-    actors = create_actors(config, device, device_acting=True)
+    actors = create_actors(config, device, device_acting=True, use_graph=args.acting_graph)
     cls = get_registered_type("trainers", config["training"]["type"])
     trainer = cls(logger=NullLogger(), actors=actors, model_config=config["model"],
                   policy_args=config.get("policy_args", {}))

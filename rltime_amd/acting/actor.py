@@ -13,8 +13,40 @@ from rltime_amd.general.type_registry import get_registered_type
 from rltime_amd.general.utils import deep_apply
 
 
+class GraphedPredict:
+    """The acting forward (policy.actor_predict on the E-env batch) captured once
+    in a HIP graph and replayed per vector step: at E=256 the eager forward is
+    ~30 launch-bound kernels; the replay is one graph launch.  Inputs are copied
+    into static buffers; the recurrent layers' `last_state` tensors are part of
+    the captured outputs, so `make_input_state` keeps working unchanged."""
+
+    def __init__(self, policy, example_state):
+        self.policy = policy
+        self.static_in = deep_apply(example_state, lambda t: t.clone())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):          # warm-up outside capture (MIOpen find, hipBLASLt workspaces)
+            for _ in range(3):
+                policy.actor_predict(self.static_in, timesteps=1, as_numpy=False)
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = policy.actor_predict(self.static_in, timesteps=1, as_numpy=False)
+        self._src, self._dst = [], []
+
+    def __call__(self, state):
+        src, dst = [], []
+        deep_apply(state, lambda t: src.append(t))
+        deep_apply(self.static_in, lambda t: dst.append(t))
+        torch._foreach_copy_(dst, src)
+        self.graph.replay()
+        return {k: v.clone() for k, v in self.static_out.items()}
+
+
 class Actor(ActingInterface):
-    def __init__(self, vec_env, exploration_config=None, base_env_id=0, total_env_ids=None, device=False):
+    def __init__(self, vec_env, exploration_config=None, base_env_id=0, total_env_ids=None, device=False,
+                 use_graph=False):
         self._vec_env = vec_env
         self._num_envs = vec_env.num_envs
         self._base_env_id = base_env_id
@@ -28,6 +60,8 @@ class Actor(ActingInterface):
         self._policy = None
         self._progress = 0
         self._device_mode = device
+        self._use_graph = use_graph and device
+        self._graphed = None
         super().__init__(vec_env.observation_space, vec_env.action_space)
 
     def get_env_count(self):
@@ -73,10 +107,23 @@ class Actor(ActingInterface):
             self.last_state = states
         return samples
 
+    def _predict_device(self, state):
+        if not self._use_graph:
+            return self._policy.actor_predict(state, timesteps=1, as_numpy=False)
+        if self._graphed is None:
+            try:
+                self._graphed = GraphedPredict(self._policy, _to_device_tree(state, self._policy.device()))
+            except Exception as e:                       # capture unsupported for this model: stay eager
+                import logging
+                logging.getLogger().warning("acting graph capture failed (%s); running eagerly", e)
+                self._use_graph = False
+                return self._policy.actor_predict(state, timesteps=1, as_numpy=False)
+        return self._graphed(_to_device_tree(state, self._policy.device()))
+
     def _device_steps(self, iters):
         out = None
         for _ in range(iters):
-            pred = self._policy.actor_predict(self.last_state, timesteps=1, as_numpy=False)
+            pred = self._predict_device(self.last_state)
             actions = pred["actions"]
             if self._exploration is not None:
                 actions, _ = self._exploration.remap_actions_device(
@@ -93,6 +140,11 @@ class Actor(ActingInterface):
             out.append(**fields)
             self.last_state = states
         return out
+
+
+def _to_device_tree(state, device):
+    return deep_apply(state, lambda x: x if isinstance(x, torch.Tensor)
+                      else torch.as_tensor(x, device=device))
 
 
 def _pack_state(states):

@@ -24,13 +24,13 @@ def make_vec_env(env, env_args, num_envs, device, seed=0):
     return SyntheticAtariVecEnv(num_envs, device=device, seed=seed, **args)
 
 
-def create_actors(config, device="cuda", device_acting=True):
+def create_actors(config, device="cuda", device_acting=True, use_graph=False):
     """acting/create.py:4-27 for the local synchronous actor."""
     from rltime_amd.acting.actor import Actor
     acting = config.get("acting", {})
     n = acting.get("actor_envs", 1)
     env = make_vec_env(config.get("env"), config.get("env_args"), n, device)
-    return Actor(env, exploration_config=acting.get("exploration"), device=device_acting,
+    return Actor(env, exploration_config=acting.get("exploration"), device=device_acting, use_graph=use_graph,
                  base_env_id=acting.get("env_base", 0), total_env_ids=acting.get("total_envs"))
 
 

@@ -101,3 +101,30 @@ def test_unknown_training_argument_raises_typeerror():
         "history_mode": {"type": "replay", "args": {"size": 100, "train_frequency": 4}}}}
     with pytest.raises(TypeError):
         train(copy.deepcopy(cfg), NullLogger())
+
+
+def test_graph_captured_acting_matches_eager():
+    """Actor(use_graph=True): the acting forward replayed from a HIP graph gives
+    the same actions / q-values / recurrent state as the eager forward (DQN+LSTM:
+    no RNG inside the forward)."""
+    from rltime_amd.acting.actor import Actor
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    from rltime_amd.policies.dqn import DQNPolicy
+    model = {"type": "sequential", "args": {"layer_configs": [
+        dict(CNN, args=dict(CNN["args"], channels_last=True)),
+        {"type": "lstm", "args": {"num_units": 16}}, {"type": "fc", "args": {"fc_size": 32}}]}}
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        env = SyntheticAtariVecEnv(8, frame_shape=(2, 20, 20), n_actions=4, seed=3)
+        pol = DQNPolicy.create(model_config=model, observation_space=env.observation_space,
+                               action_space=env.action_space, dueling=True)
+        actor = Actor(env, device=True, use_graph=use_graph)
+        actor.set_actor_policy(pol)
+        batch = actor.get_samples(8 * 6)
+        assert actor._use_graph == use_graph          # capture must not have fallen back
+        outs.append([(s["actions"].cpu(), s["policy"].cpu(), s["state"].cpu()) for s in batch.vector_steps])
+    for a, b in zip(*outs):
+        assert torch.equal(a[0], b[0])
+        assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-6)
