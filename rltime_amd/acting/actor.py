@@ -33,7 +33,11 @@ class GraphedPredict:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = policy.actor_predict(self.static_in, timesteps=1, as_numpy=False)
-        self._src, self._dst = [], []
+        # recurrent layers publish their running state through `last_state`; the
+        # captured tensors are refreshed by every replay, but the attribute is
+        # re-bound by get_state() and by the learner's own forwards -> re-attach
+        self.static_last = [(layer, layer.last_state) for layer in policy.model.layers
+                            if getattr(layer, "last_state", None) is not None]
 
     def __call__(self, state):
         src, dst = [], []
@@ -41,6 +45,8 @@ class GraphedPredict:
         deep_apply(self.static_in, lambda t: dst.append(t))
         torch._foreach_copy_(dst, src)
         self.graph.replay()
+        for layer, state in self.static_last:
+            layer.last_state = state
         return {k: v.clone() for k, v in self.static_out.items()}
 
 
