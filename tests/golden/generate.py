@@ -714,6 +714,29 @@ def run_schedule_cases():
     print("schedule cases: %d arrays" % len(out))
 
 
+# --------------------------------------------------------------------------
+# Config loader semantics (general/config.py:32-117): '@json', '@python', '_'
+# comment keys, '**' shallow merge, '***' deep merge, nested key paths.
+# --------------------------------------------------------------------------
+def run_config_cases():
+    from rltime.general.config import load_config
+    cfg_dir = os.path.join(HERE, "configs")
+    out = {}
+    for name in sorted(os.listdir(cfg_dir)):
+        if not name.endswith(".json"):
+            continue
+        loaded = load_config(os.path.join(cfg_dir, name))
+
+        def enc(o):
+            if callable(o):
+                return "<python:%s.%s>" % (o.__module__.split(".", 1)[-1], o.__name__)
+            raise TypeError(o)
+        out[name] = json.loads(json.dumps(loaded, default=enc))
+    with open(os.path.join(HERE, "config_cases.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("config cases: %s" % ", ".join(out))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_tree_cases()
@@ -723,4 +746,5 @@ if __name__ == "__main__":
     run_model_cases()
     run_e2e_case()
     run_schedule_cases()
+    run_config_cases()
     print("golden fixtures written to", HERE)
