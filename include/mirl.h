@@ -175,6 +175,15 @@ int mirl_replay_gather(mirl_replay* h, int32_t mbatch, const int32_t* env,
 int mirl_replay_update_losses(mirl_replay* h, int64_t count, const int64_t* indices,
                               const float* losses, void* stream);
 
+/* Snapshot / resume of a whole shard (the reference
+ * checkpoints weights only, policy_trainer.py:170-185): host bookkeeping (ring
+ * heads, global FIFO, free list, quota), every device array and the priority
+ * trees, streamed to / from `path` through a pinned staging buffer.  Restoring
+ * needs a handle created with the same mirl_replay_config; afterwards sampling,
+ * gathering and priority updates continue bit-identically.  Both synchronise.   */
+int mirl_replay_save(mirl_replay* h, const char* path_host);
+int mirl_replay_load(mirl_replay* h, const char* path_host);
+
 /* Per-kernel timing of the dominant kernel (the frame gather) with HIP events
  * on the launch stream: enable, run, then read {launches, total ms}.  Reading
  * synchronises the device.                                                    */

@@ -58,6 +58,9 @@ class FifoRing {     // fixed-capacity FIFO with index access
   bool push(T v) { if (len_ == cap_) return false; buf_[(size_t)((head_ + len_) % cap_)] = v; ++len_; return true; }
   T pop() { T v = buf_[(size_t)head_]; head_ = (head_ + 1) % cap_; --len_; return v; }
   T at(int64_t i) const { return buf_[(size_t)((head_ + i) % cap_)]; }
+  // flat (FIFO-order) export / import for snapshots
+  void dump(std::vector<T>& out) const { out.resize((size_t)len_); for (int64_t i = 0; i < len_; ++i) out[(size_t)i] = at(i); }
+  bool restore(const std::vector<T>& in) { if ((int64_t)in.size() > cap_) return false; head_ = 0; len_ = 0; for (T v : in) push(v); return true; }
  private:
   std::vector<T> buf_;
   int64_t cap_ = 1, head_ = 0, len_ = 0;

@@ -801,6 +801,133 @@ extern "C" int mirl_replay_profile(mirl_replay* h, int32_t enable, int64_t* laun
   return MIRL_OK;
 }
 
+// ---- snapshot / resume ------------------------------------------------------------
+namespace {
+const uint64_t kSnapMagic = 0x4D49524C534E4150ull;   // "MIRLSNAP"
+const uint32_t kSnapVersion = 1;
+
+struct SnapIO {
+  FILE* f = nullptr; char* pin = nullptr; size_t pin_bytes = 64u << 20; bool ok = true;
+  bool open(const char* path, const char* mode) {
+    f = fopen(path, mode);
+    if (!f) return false;
+    if (hipHostMalloc((void**)&pin, pin_bytes, hipHostMallocDefault) != hipSuccess) { fclose(f); f = nullptr; return false; }
+    return true;
+  }
+  void close() { if (f) fclose(f); if (pin) (void)hipHostFree(pin); f = nullptr; pin = nullptr; }
+  void put(const void* p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+  void get(void* p, size_t n) { if (ok && n && fread(p, 1, n, f) != n) ok = false; }
+  template <class T> void put_vec(const std::vector<T>& v) { uint64_t n = v.size(); put(&n, 8); put(v.data(), n * sizeof(T)); }
+  template <class T> void get_vec(std::vector<T>& v) { uint64_t n = 0; get(&n, 8); if (!ok || n > (1ull << 40)) { ok = false; return; } v.resize((size_t)n); get(v.data(), n * sizeof(T)); }
+  void put_dev(const void* d, size_t n) {          // device -> file, section prefixed by its size
+    uint64_t sz = d ? n : 0; put(&sz, 8);
+    for (size_t at = 0; ok && at < sz; at += pin_bytes) {
+      size_t c = sz - at < pin_bytes ? sz - at : pin_bytes;
+      if (hipMemcpy(pin, (const char*)d + at, c, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+      put(pin, c);
+    }
+  }
+  void get_dev(void* d, size_t n) {                // file -> device; sizes must agree
+    uint64_t sz = 0; get(&sz, 8);
+    if (!ok || sz != (d ? n : 0)) { ok = false; return; }
+    for (size_t at = 0; ok && at < sz; at += pin_bytes) {
+      size_t c = sz - at < pin_bytes ? sz - at : pin_bytes;
+      get(pin, c);
+      if (ok && hipMemcpy((char*)d + at, pin, c, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    }
+  }
+};
+
+bool same_config(const mirl_replay_config& a, const mirl_replay_config& b) {
+  return a.size == b.size && a.num_envs == b.num_envs && a.env_base == b.env_base && a.frame_bytes == b.frame_bytes &&
+         a.extra_f32 == b.extra_f32 && a.state_f32 == b.state_f32 && a.has_initials == b.has_initials &&
+         a.policy_f32 == b.policy_f32 && a.nstep_train == b.nstep_train && a.prefix_steps == b.prefix_steps &&
+         a.nstep_target == b.nstep_target && a.gamma == b.gamma && a.mode == b.mode &&
+         a.train_frequency == b.train_frequency && a.avoid_episode_crossing == b.avoid_episode_crossing &&
+         a.overlap == b.overlap && a.alpha == b.alpha && a.beta == b.beta && a.eps == b.eps &&
+         a.max_weight_factor == b.max_weight_factor && a.beta_anneal_mode == b.beta_anneal_mode &&
+         a.beta_anneal_to == b.beta_anneal_to && a.global_importance_scaling == b.global_importance_scaling &&
+         a.env_ring_slack == b.env_ring_slack;
+}
+
+template <class F>
+void snap_device_arrays(mirl_replay* h, F&& io) {
+  Dev& d = h->d;
+  const size_t slots = (size_t)d.E * (size_t)d.C;
+  io(d.frames, slots * (size_t)d.Fp);
+  io(d.extra, slots * (size_t)d.X * 4);
+  io(d.state, slots * (size_t)d.S * 4);
+  io(d.initials, d.has_init ? slots * 4 : 0);
+  io(d.actions, slots * 4);
+  io(d.policy, slots * (size_t)d.A * 4);
+  io(d.rewards, slots * 4);
+  io(d.dones, slots);
+  io(d.first, (size_t)d.E * 8);
+  io(d.count, (size_t)d.E * 8);
+  if (d.per) {
+    io(d.loss, slots * 4);
+    io(d.prio_index, slots * 4);
+    io(d.stamp, slots * 8);
+    io(d.tv, (size_t)(2 * d.cap) * 8);
+    io(d.tk, (size_t)(2 * d.cap));
+    io(d.tmin, d.tmin ? (size_t)(2 * d.cap) * 8 : 0);
+    io(d.slot_env, (size_t)d.n_slots * 4);
+    io(d.slot_base, (size_t)d.n_slots * 8);
+  }
+}
+}  // namespace
+
+extern "C" int mirl_replay_save(mirl_replay* h, const char* path) {
+  if (!h || !path) return fail(MIRL_ERR_ARG, "null argument");
+  MIRL_HIP(hipDeviceSynchronize());
+  SnapIO io;
+  if (!io.open(path, "wb")) return fail(MIRL_ERR_ARG, std::string("cannot open snapshot for writing: ") + path);
+  Book& b = h->book;
+  io.put(&kSnapMagic, 8); io.put(&kSnapVersion, 4);
+  io.put(&b.cfg, sizeof(b.cfg));
+  int64_t scal[4] = {b.quota, b.active, (int64_t)h->epoch, (int64_t)h->sample_calls};
+  io.put(scal, sizeof(scal));
+  io.put_vec(b.first); io.put_vec(b.count); io.put_vec(b.env_order); io.put_vec(b.env_seen);
+  std::vector<int32_t> tmp;
+  b.fifo.dump(tmp); io.put_vec(tmp);
+  b.free_slots.dump(tmp); io.put_vec(tmp);
+  io.put_vec(b.slot_env); io.put_vec(b.slot_base); io.put_vec(b.prio_index);
+  snap_device_arrays(h, [&](const void* p, size_t n) { io.put_dev(p, n); });
+  bool ok = io.ok;
+  io.close();
+  return ok ? MIRL_OK : fail(MIRL_ERR_HIP, "snapshot write failed");
+}
+
+extern "C" int mirl_replay_load(mirl_replay* h, const char* path) {
+  if (!h || !path) return fail(MIRL_ERR_ARG, "null argument");
+  MIRL_HIP(hipDeviceSynchronize());
+  SnapIO io;
+  if (!io.open(path, "rb")) return fail(MIRL_ERR_ARG, std::string("cannot open snapshot: ") + path);
+  Book& b = h->book;
+  uint64_t magic = 0; uint32_t ver = 0; mirl_replay_config cfg;
+  io.get(&magic, 8); io.get(&ver, 4); io.get(&cfg, sizeof(cfg));
+  if (!io.ok || magic != kSnapMagic || ver != kSnapVersion || !same_config(cfg, b.cfg)) {   // device ordinal may differ
+    io.close();
+    return fail(MIRL_ERR_ARG, "snapshot does not match this handle's configuration (or is not a snapshot)");
+  }
+  int64_t scal[4];
+  io.get(scal, sizeof(scal));
+  io.get_vec(b.first); io.get_vec(b.count); io.get_vec(b.env_order); io.get_vec(b.env_seen);
+  std::vector<int32_t> tmp;
+  io.get_vec(tmp); bool r1 = b.fifo.restore(tmp);
+  io.get_vec(tmp); bool r2 = b.free_slots.restore(tmp);
+  io.get_vec(b.slot_env); io.get_vec(b.slot_base); io.get_vec(b.prio_index);
+  if (io.ok && r1 && r2) {
+    b.quota = scal[0]; b.active = scal[1]; h->epoch = (uint64_t)scal[2]; h->sample_calls = (uint64_t)scal[3];
+    snap_device_arrays(h, [&](void* p, size_t n) { io.get_dev(p, n); });
+    if (h->d.per) (void)hipMemset(h->d.flag, 0, (size_t)h->d.n_slots), (void)hipMemset(h->d.dirty_count, 0, 4);
+  }
+  bool ok = io.ok && r1 && r2;
+  io.close();
+  MIRL_HIP(hipDeviceSynchronize());
+  return ok ? MIRL_OK : fail(MIRL_ERR_STATE, "snapshot is truncated or inconsistent; the handle must be recreated");
+}
+
 extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env, const int64_t* start, const float* weight,
                                   const mirl_batch* out, void* stream) {
   if (!h || B <= 0 || !env || !start || !out) return fail(MIRL_ERR_ARG, "bad gather arguments");

@@ -413,6 +413,20 @@ class ReplayHistoryBuffer(History):
                 "tree_capacity", "n_slots")
         return dict(zip(keys, (x.value for x in v)))
 
+    def save(self, path):
+        """Snapshot the whole shard (bookkeeping + device arrays + trees) to `path`."""
+        check(lib.mirl_replay_save(self._h, str(path).encode()), "mirl_replay_save")
+
+    def load(self, path, example_state=None, num_envs=None, env_base=0, policy_f32=0):
+        """Restore a snapshot written by an identically configured buffer.  A
+        buffer that has not seen data yet needs the transition layout
+        (`example_state`, `num_envs`) to create its shard first."""
+        if self._h is None:
+            if example_state is None or num_envs is None:
+                raise _lib.MirlError("load() on an empty buffer needs example_state and num_envs")
+            self.configure(example_state, num_envs, env_base, policy_f32)
+        check(lib.mirl_replay_load(self._h, str(path).encode()), "mirl_replay_load")
+
     def profile(self, enable):
         """Frame-gather kernel timing (HIP events on the launch stream):
         returns (launches, total_ms) accumulated since the last call."""
