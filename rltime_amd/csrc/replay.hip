@@ -482,6 +482,21 @@ k_recalc_flagged(Dev d) {
 __global__ void k_copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// same copy with non-temporal access, one 16 B element per lane and a full-size
+// grid: the device-copy ceiling the gather is compared against
+__global__ void __launch_bounds__(512) k_copy16_nt(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 2048 + threadIdx.x;
+  u32x4 v0, v1, v2, v3;
+  bool h0 = i < n, h1 = i + 512 < n, h2 = i + 1024 < n, h3 = i + 1536 < n;
+  if (h0) v0 = __builtin_nontemporal_load(src + i);
+  if (h1) v1 = __builtin_nontemporal_load(src + i + 512);
+  if (h2) v2 = __builtin_nontemporal_load(src + i + 1024);
+  if (h3) v3 = __builtin_nontemporal_load(src + i + 1536);
+  if (h0) __builtin_nontemporal_store(v0, dst + i);
+  if (h1) __builtin_nontemporal_store(v1, dst + i + 512);
+  if (h2) __builtin_nontemporal_store(v2, dst + i + 1024);
+  if (h3) __builtin_nontemporal_store(v3, dst + i + 1536);
+}
 
 }  // namespace mirl
 
@@ -1053,7 +1068,10 @@ extern "C" int mirl_replay_losses_peek(mirl_replay* h, int32_t env_local, int64_
 
 extern "C" int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
   if (!dst || !src || bytes <= 0 || (bytes % 16) || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return fail(MIRL_ERR_ARG, "copy needs 16-byte aligned pointers and size");
-  hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, bytes / 16);
+  static int nt = getenv("MIRL_COPY_NT") ? atoi(getenv("MIRL_COPY_NT")) : 0;
+  const int64_t n = bytes / 16;
+  if (nt) hipLaunchKernelGGL(k_copy16_nt, dim3((unsigned)((n + 2047) / 2048)), dim3(512), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
+  else hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
