@@ -8,5 +8,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 "$HIPCC" $FLAGS -c "$HERE/replay.hip" -o "$HERE/replay.o"
 "$HIPCC" $FLAGS -c "$HERE/qmath.hip" -o "$HERE/qmath.o"
 "$HIPCC" $FLAGS -c "$HERE/lstm.hip" -o "$HERE/lstm.o"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" "$HERE/lstm.o" -o "$OUT"
+"$HIPCC" $FLAGS -c "$HERE/convert.hip" -o "$HERE/convert.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" "$HERE/lstm.o" "$HERE/convert.o" -o "$OUT"
 echo "built $OUT"

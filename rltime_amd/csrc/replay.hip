@@ -643,6 +643,7 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   Dev& d = h->d;
   const int K = in->count;
   if (!in->frames || !in->actions || !in->rewards || !in->dones) return fail(MIRL_ERR_ARG, "frames/actions/rewards/dones are required");
+  if (K > 65535) return fail(MIRL_ERR_ARG, "at most 65535 transitions per ingest call (split the vector step)");
   if ((d.X && !in->extra) || (d.S && !in->state) || (d.has_init && !in->initials) || (d.A && !in->policy))
     return fail(MIRL_ERR_ARG, "a configured payload array is NULL");
   int rc = h->book.ingest(K, in->env_ids_host, h->plan);

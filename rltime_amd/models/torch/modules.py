@@ -62,7 +62,7 @@ class CNN(BaseModule):
     def forward(self, x, **kwargs):
         if self.channels_last and self.scale and x.is_cuda and x.dtype == torch.uint8 \
                 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled():
-            x = _frames_to_f32_nhwc(x, self.scale)       # one fused HIP pass (csrc/lstm.hip)
+            x = _frames_to_f32_nhwc(x, self.scale)       # one fused HIP pass (csrc/convert.hip)
         elif self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
             if self.scale:
