@@ -36,7 +36,7 @@ k_frames_to_f32_nhwc(int64_t N, int C, int HW, const uint8_t* __restrict__ src, 
 }  // namespace mirl
 
 extern "C" int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale, float* dst, void* stream) {
-  if (N <= 0 || C <= 0 || HW <= 0 || !src || !dst) return fail(MIRL_ERR_ARG, "bad frames_to_f32_nhwc arguments");
+  if (N <= 0 || C <= 0 || HW <= 0 || !src || !dst) return mirl::fail(MIRL_ERR_ARG, "bad frames_to_f32_nhwc arguments");
   int64_t n = N * ((HW + 3) / 4);
   hipLaunchKernelGGL(mirl::k_frames_to_f32_nhwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, (int)C, (int)HW, src, scale, dst);
   MIRL_LAUNCH_CHECK();
