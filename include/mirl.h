@@ -148,8 +148,14 @@ int mirl_replay_set_train_quota(mirl_replay* h, int64_t quota);
  * Returns MIRL_NEED_MORE for the reference's `None`.                          */
 int mirl_replay_sample(mirl_replay* h, int32_t mbatch, double train_progress,
                        const void* rng_host, uint64_t seed,
-                       int32_t* slot, int32_t* env, int64_t* start, float* weight,
-                       double* stats, void* stream);
+                       int32_t* slot, int32_t* env, int64_t* start, int64_t* loss_start,
+                       float* weight, double* stats, void* stream);
+/* `loss_start` (device, mbatch int64, may be NULL): per-env offset of the first
+ * TRAINED transition whose loss the sequence's priority tracks.  It equals
+ * start + prefix_steps except when avoid_episode_crossing shifted the window:
+ * the reference keeps reporting losses against the unshifted sequence
+ * (prioritized_replay_history.py:335-338 uses base_offset, :320 shifts only the
+ * sampled range).  Pass it on to mirl_replay_gather.                           */
 /* `stats` (device, 2 doubles, may be NULL; PER only): [0] = sum of priorities of
  * this shard's tree, [1] = the un-normalised batch-max weight that `weight` was
  * divided by.  With the active-sequence count (mirl_replay_stats) this is what
@@ -166,7 +172,7 @@ int mirl_replay_state_rows(mirl_replay* h, int32_t* rows, int32_t* overlapped);
  * (history.py:71-108,178-201), _make_train_batch + StateStore.stack
  * (history.py:203-286, general/backend.py:112-153).                           */
 int mirl_replay_gather(mirl_replay* h, int32_t mbatch, const int32_t* env,
-                       const int64_t* start, const float* weight,
+                       const int64_t* start, const int64_t* loss_start, const float* weight,
                        const mirl_batch* out, void* stream);
 
 /* update_losses (prioritized_replay_history.py:243-279) + _recalc_weighted_priority

@@ -108,14 +108,14 @@ _SIGNATURES = {
     "mirl_replay_destroy": [_vp],
     "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
-    "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_replay_profile": [_vp, _i32, _P(_i64), _P(_f64)],
     "mirl_replay_save": [_vp, C.c_char_p],
     "mirl_replay_load": [_vp, C.c_char_p],
     "mirl_replay_uniform_total": [_vp, _P(_i64)],
     "mirl_replay_set_train_quota": [_vp, _i64],
     "mirl_replay_state_rows": [_vp, _P(_i32), _P(_i32)],
-    "mirl_replay_gather": [_vp, _i32, _vp, _vp, _vp, _P(Batch), _vp],
+    "mirl_replay_gather": [_vp, _i32, _vp, _vp, _vp, _vp, _P(Batch), _vp],
     "mirl_replay_update_losses": [_vp, _i64, _vp, _vp, _vp],
     "mirl_replay_stats": [_vp, _P(_i64), _P(_i64), _P(_i64), _P(_i64), _P(_i64)],
     "mirl_replay_env_meta": [_vp, _vp, _vp],

@@ -215,7 +215,8 @@ __global__ void __launch_bounds__(1024)
 k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, uint64_t call,
              double active, double beta, int global_scale,
              int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out, int64_t* __restrict__ start_out,
-             float* __restrict__ w_out, double* __restrict__ w_tmp, double* __restrict__ stats) {
+             int64_t* __restrict__ base_out, float* __restrict__ w_out, double* __restrict__ w_tmp,
+             double* __restrict__ stats) {
   __shared__ double s_tv[MIRL_LDS_NODES];
   __shared__ uint8_t s_tk[MIRL_LDS_NODES];
   __shared__ double s_red[16];
@@ -237,9 +238,11 @@ k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, u
     int32_t idx = (int32_t)(pos - d.cap);
     slot_out[i] = idx;
     int32_t e = d.slot_env[idx];
-    int64_t start = d.slot_base[idx] - d.P;
+    const int64_t base = d.slot_base[idx];
+    int64_t start = base - d.P;
     if (e >= 0) start = refine_start(d, e, start);
     env_out[i] = e; start_out[i] = start;
+    if (base_out) base_out[i] = base;                  // losses stay attached to the unshifted sequence
     // weight = ((leaf / p_sum) * total_items) ** (-beta)
     double w = pow((d.tv[pos] / total.v) * active, -beta);
     w_tmp[i] = w;
@@ -270,7 +273,7 @@ __global__ void __launch_bounds__(256)
 k_uniform_sample(Dev d, int B, const int64_t* __restrict__ picks, uint64_t seed, uint64_t call,
                  int n_cum, const int64_t* __restrict__ cum, const int32_t* __restrict__ cum_env,
                  int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out,
-                 int64_t* __restrict__ start_out, float* __restrict__ w_out) {
+                 int64_t* __restrict__ start_out, int64_t* __restrict__ base_out, float* __restrict__ w_out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   const int64_t total = cum[n_cum - 1];
@@ -283,6 +286,7 @@ k_uniform_sample(Dev d, int B, const int64_t* __restrict__ picks, uint64_t seed,
   int64_t before = lo ? cum[lo - 1] : 0;
   int64_t start = refine_start(d, e, d.first[e] + (p - before));
   slot_out[i] = (int32_t)p; env_out[i] = e; start_out[i] = start; w_out[i] = 1.0f;
+  if (base_out) base_out[i] = start + d.P;
 }
 
 // ---------------------------------------------------------------------------
@@ -388,7 +392,8 @@ k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ 
 //   (prioritized_replay_history.py:329-338) and the `initials` rows.
 __global__ void __launch_bounds__(256)
 k_gather_scalars(Dev d, int B, int R, int overlapped, const int32_t* __restrict__ env,
-                 const int64_t* __restrict__ start, const float* __restrict__ weight, mirl_batch o) {
+                 const int64_t* __restrict__ start, const int64_t* __restrict__ loss_start,
+                 const float* __restrict__ weight, mirl_batch o) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int rows = R > d.L ? R : d.L;
   if (i >= (int64_t)rows * B) return;
@@ -424,7 +429,10 @@ k_gather_scalars(Dev d, int B, int R, int overlapped, const int32_t* __restrict_
   if (o.weights) o.weights[i] = weight[b];
   if (o.loss_indices) {
     if (r < d.P) { o.loss_indices[2 * i] = -1; o.loss_indices[2 * i + 1] = -1; }
-    else { o.loss_indices[2 * i] = (int64_t)(e + d.env_base); o.loss_indices[2 * i + 1] = off; }
+    else {
+      o.loss_indices[2 * i] = (int64_t)(e + d.env_base);
+      o.loss_indices[2 * i + 1] = loss_start ? loss_start[b] + (r - d.P) : off;
+    }
   }
 }
 
@@ -717,7 +725,8 @@ static double anneal_beta(const mirl_replay_config& c, double progress) {
 }
 
 extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progress, const void* rng_host, uint64_t seed,
-                                  int32_t* slot, int32_t* env, int64_t* start, float* weight, double* stats, void* stream) {
+                                  int32_t* slot, int32_t* env, int64_t* start, int64_t* loss_start, float* weight,
+                                  double* stats, void* stream) {
   if (!h || B <= 0 || !slot || !env || !start || !weight) return fail(MIRL_ERR_ARG, "bad sample arguments");
   hipStream_t st = (hipStream_t)stream;
   Book& bk = h->book;
@@ -746,7 +755,7 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
     }
     double beta = anneal_beta(bk.cfg, train_progress);
     hipLaunchKernelGGL(k_per_sample, dim3(1), dim3(1024), 0, st, d, (int)B, u_dev, seed, h->sample_calls,
-                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, weight, h->w_tmp, stats);
+                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, loss_start, weight, h->w_tmp, stats);
     MIRL_LAUNCH_CHECK();
     if (rng_host) return h->staging.mark(st);
     return MIRL_OK;
@@ -774,7 +783,7 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
   rc = h->staging.upload(total, st); if (rc) return rc;
   hipLaunchKernelGGL(k_uniform_sample, dim3((B + 255) / 256), dim3(256), 0, st, d, (int)B,
                      rng_host ? (const int64_t*)(db + o_pick) : (const int64_t*)nullptr, seed, h->sample_calls,
-                     (int)nc, (const int64_t*)(db + o_cum), (const int32_t*)(db + o_env), slot, env, start, weight);
+                     (int)nc, (const int64_t*)(db + o_cum), (const int32_t*)(db + o_env), slot, env, start, loss_start, weight);
   MIRL_LAUNCH_CHECK();
   return h->staging.mark(st);
 }
@@ -944,8 +953,8 @@ extern "C" int mirl_replay_load(mirl_replay* h, const char* path) {
   return ok ? MIRL_OK : fail(MIRL_ERR_STATE, "snapshot is truncated or inconsistent; the handle must be recreated");
 }
 
-extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env, const int64_t* start, const float* weight,
-                                  const mirl_batch* out, void* stream) {
+extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env, const int64_t* start, const int64_t* loss_start,
+                                  const float* weight, const mirl_batch* out, void* stream) {
   if (!h || B <= 0 || !env || !start || !out) return fail(MIRL_ERR_ARG, "bad gather arguments");
   if (!out->frames || !out->returns || !out->nsteps || !out->masks || !out->actions) return fail(MIRL_ERR_ARG, "frames/returns/nsteps/masks/actions outputs are required");
   if (out->weights && !weight) return fail(MIRL_ERR_ARG, "weights output requested without a weight input");
@@ -961,7 +970,7 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
   int rows = h->rows > d.L ? h->rows : d.L;
   int64_t n = (int64_t)rows * B;
   hipLaunchKernelGGL(k_gather_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, (int)B, h->rows, h->overlapped,
-                     env, start, weight, o);
+                     env, start, loss_start, weight, o);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

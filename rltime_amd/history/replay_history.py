@@ -313,22 +313,23 @@ class ReplayHistoryBuffer(History):
         slot = torch.empty(B, dtype=torch.int32, device=dev)
         env = torch.empty(B, dtype=torch.int32, device=dev)
         start = torch.empty(B, dtype=torch.int64, device=dev)
+        loss_start = torch.empty(B, dtype=torch.int64, device=dev)
         weight = torch.empty(B, dtype=torch.float32, device=dev)
         stats = torch.zeros(2, dtype=torch.float64, device=dev)
         self._seed += 1
         rc = check(lib.mirl_replay_sample(
             self._h, B, -1.0 if train_progress is None else float(train_progress),
             _lib.np_ptr(rng) if rng is not None else None, self._seed,
-            _ptr(slot), _ptr(env), _ptr(start), _ptr(weight), _ptr(stats), _stream()),
+            _ptr(slot), _ptr(env), _ptr(start), _ptr(loss_start), _ptr(weight), _ptr(stats), _stream()),
             "mirl_replay_sample")
         if rc == _lib.MIRL_NEED_MORE:
             return None
         self.last_beta = self._current_beta(train_progress)
         self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight,
-                            "stats": stats}
-        return self._gather(B, env, start, weight)
+                            "stats": stats, "loss_start": loss_start}
+        return self._gather(B, env, start, weight, loss_start)
 
-    def _gather(self, B, env, start, weight):
+    def _gather(self, B, env, start, weight, loss_start=None):
         lay, dev = self._layout, self.device
         L = self.nstep_train + self.prefix_steps
         R = self._rows
@@ -354,7 +355,7 @@ class ReplayHistoryBuffer(History):
             masks=_ptr(masks), actions=_ptr(actions), policy=_ptr(policy),
             weights=_ptr(weights), loss_indices=_ptr(loss_idx))
         check(lib.mirl_replay_gather(
-            self._h, B, _ptr(env), _ptr(start), _ptr(weight), C.byref(out), _stream()),
+            self._h, B, _ptr(env), _ptr(start), _ptr(loss_start), _ptr(weight), C.byref(out), _stream()),
             "mirl_replay_gather")
 
         if self._overlapped:

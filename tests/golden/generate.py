@@ -144,6 +144,17 @@ SCENARIOS = {
         script=[("feed", 11), ("draw", 4, 900, 0.1), ("losses", 901),
                 ("feed", 9), ("draw", 4, 902, 0.5), ("losses", 903),
                 ("draw", 4, 904, 0.7)]),
+    "per_seq_noxing": dict(
+        mode="per",
+        spec=dict(seed=18, num_envs=3, frame_shape=(1, 4, 4), lstm_units=0,
+                  n_actions=3, done_prob=0.18, extra_features=8),
+        hist=dict(size=90, train_frequency=4, nstep_target=2, nstep_train=6,
+                  prefix_steps=0, alpha=0.6, beta=0.4, overlap=3,
+                  avoid_episode_crossing=True),
+        gamma=0.9,
+        script=[("feed", 20), ("draw", 6, 950, 0.2), ("losses", 951),
+                ("feed", 15), ("draw", 6, 952, 0.6), ("losses", 953),
+                ("feed", 4), ("draw", 6, 954, 0.9)]),
     "per_seq_global": dict(
         mode="per",
         spec=dict(seed=16, num_envs=3, frame_shape=(1, 2, 2), lstm_units=2,

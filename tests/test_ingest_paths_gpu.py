@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_dict_and_batched_ingest_are_identical():
     from rltime_amd.history import PrioritizedReplayHistoryBuffer
     spec = StreamSpec(seed=41, num_envs=6, frame_shape=(4, 21, 21), lstm_units=16, n_actions=5, done_prob=0.05,
-                      fractional_rewards=False)
+                      fractional_rewards=False, extra_features=8)     # 32 B extra rows: the 16 B/lane path
     hist = dict(size=300, train_frequency=4, nstep_target=2, nstep_train=6, prefix_steps=3, alpha=0.8, beta=0.5)
     a = PrioritizedReplayHistoryBuffer(**hist, gamma=0.99)
     b = PrioritizedReplayHistoryBuffer(**hist, gamma=0.99)
@@ -32,6 +32,7 @@ def test_dict_and_batched_ingest_are_identical():
             torch.from_numpy(st["frames"]).to(dev), torch.from_numpy(st["actions"].astype(np.int32)).to(dev),
             torch.from_numpy(st["rewards"].astype(np.float32)).to(dev),
             torch.from_numpy(st["dones"].astype(np.uint8)).to(dev),
+            extra=torch.from_numpy(st["extra"]).to(dev),
             state=torch.from_numpy(np.concatenate([st["hx"], st["cx"]], axis=1)).to(dev),
             initials=torch.from_numpy(st["initials"]).to(dev),
             policy=torch.from_numpy(st["qvalues"]).to(dev))
