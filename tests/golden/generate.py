@@ -155,6 +155,17 @@ SCENARIOS = {
         script=[("feed", 20), ("draw", 6, 950, 0.2), ("losses", 951),
                 ("feed", 15), ("draw", 6, 952, 0.6), ("losses", 953),
                 ("feed", 4), ("draw", 6, 954, 0.9)]),
+    "per_seq_full_overlap": dict(
+        mode="per",
+        spec=dict(seed=19, num_envs=2, frame_shape=(1, 3, 3), lstm_units=2,
+                  n_actions=3, done_prob=0.1, env_base=32),
+        hist=dict(size=40, train_frequency=4, nstep_target=1, nstep_train=3,
+                  prefix_steps=1, alpha=0.5, beta=0.7, overlap=-1,
+                  max_weight_factor=0.5),
+        gamma=0.9,
+        script=[("feed", 9), ("draw", 5, 970, 0.2), ("losses", 971),
+                ("feed", 14), ("draw", 5, 972, 0.6), ("losses", 973),
+                ("draw", 5, 974, 0.9)]),
     "per_seq_global": dict(
         mode="per",
         spec=dict(seed=16, num_envs=3, frame_shape=(1, 2, 2), lstm_units=2,

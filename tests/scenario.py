@@ -10,7 +10,8 @@ from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SCENARIOS = ["uniform_t1", "uniform_seq", "uniform_seq_noxing", "per_t1",
-             "per_seq", "per_seq_global", "per_seq_tuple_obs", "per_seq_noxing"]
+             "per_seq", "per_seq_global", "per_seq_tuple_obs", "per_seq_noxing",
+             "per_seq_full_overlap"]
 
 # importance weights are floating point: the reference evaluates them in f32 or
 # f64 depending on scalar kinds, the device in f64 -> f32.

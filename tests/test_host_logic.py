@@ -20,7 +20,7 @@ def make_cfg(cfg):
     per = cfg["mode"] == "per"
     ba = h.get("beta_anneal", False)
     return _lib.ReplayConfig(
-        size=h["size"], num_envs=cfg["spec"]["num_envs"], env_base=0, frame_bytes=16,
+        size=h["size"], num_envs=cfg["spec"]["num_envs"], env_base=cfg["spec"].get("env_base", 0), frame_bytes=16,
         nstep_train=h["nstep_train"], prefix_steps=h["prefix_steps"],
         nstep_target=h["nstep_target"], gamma=cfg["gamma"],
         mode=_lib.MODE_PER if per else _lib.MODE_UNIFORM,
@@ -81,7 +81,7 @@ def test_bookkeeping_follows_reference(name):
                 first = np.zeros(E, dtype=np.int64)
                 check(lib.mirl_book_env_meta(b.h, np_ptr(first), None))
                 win = gold[tag + ".windows"]          # (env, ring position)
-                assert np.array_equal(env, win[:, 0]), tag
+                assert np.array_equal(env + cfg["spec"].get("env_base", 0), win[:, 0]), tag
                 assert np.array_equal(start - first[env], win[:, 1]), tag
         if per:
             total, active, quota, cap, n_slots = b.stats()
@@ -92,6 +92,8 @@ def test_bookkeeping_follows_reference(name):
             se = np.zeros(n_slots, dtype=np.int32)
             sb = np.zeros(n_slots, dtype=np.int64)
             check(lib.mirl_book_slot_table(b.h, np_ptr(se), np_ptr(sb)))
+            se = se.astype(np.int64)
+            se[se >= 0] += cfg["spec"].get("env_base", 0)          # the book keeps local env indices
             assert np.array_equal(se, gold[tag + ".slot_env"]), tag
             assert np.array_equal(sb, gold[tag + ".slot_base"]), tag
             first = np.zeros(E, dtype=np.int64)

@@ -486,3 +486,42 @@ def test_snapshot_resume_round_trip(tmp_path):
     with pytest.raises(MirlError, match="does not match"):
         c.load(path, example_state=example, num_envs=5, policy_f32=spec.n_actions)
     a.close(); b.close(); c.close()
+
+
+def test_two_recurrent_layers_vs_oracle():
+    """Input-state pytrees with two recurrent layers of different widths (e.g. a
+    CNN -> LSTM -> FC -> LSTM model): each layer's hx/cx/initials come back in
+    their own sub-dict, bit-exact."""
+    from oracle import replay as orc
+    from rltime_amd.history import ReplayHistoryBuffer
+    E, T, P, n = 3, 5, 2, 2
+    hist = dict(size=150, train_frequency=0, nstep_target=n, nstep_train=T, prefix_steps=P)
+    ora = orc.OracleReplay(**hist, discount_function=orc.make_discount(0.97))
+    dev = ReplayHistoryBuffer(**hist, gamma=0.97)
+    rng = np.random.RandomState(4)
+    for s in range(70):
+        dones = rng.rand(E) < 0.1
+        samples = []
+        for e in range(E):
+            ini = np.float32(dones[e])
+            samples.append({
+                "policy_output": {"actions": int(rng.randint(3)), "qvalues": rng.randn(3).astype(np.float32)},
+                "next_state": {"x": rng.randint(0, 256, (2, 6, 6)).astype(np.uint8), "layer0_state": {},
+                               "layer1_state": {"hx": rng.randn(4).astype(np.float32), "cx": rng.randn(4).astype(np.float32), "initials": ini},
+                               "layer2_state": {},
+                               "layer3_state": {"hx": rng.randn(7).astype(np.float32), "cx": rng.randn(7).astype(np.float32), "initials": ini}},
+                "reward": float(rng.randint(-1, 2)), "done": bool(dones[e]), "info": {}, "env_id": e})
+        ora.update([dict(x) for x in samples])
+        dev.update([dict(x) for x in samples])
+    np.random.seed(8)
+    a = ora.get_train_data(6)
+    np.random.seed(8)
+    b = dev.get_train_data(6)
+    fb = {k: scenario.to_numpy(v) for k, v in scenario.flatten("", b, {}).items()}
+    fa = scenario.flatten("", a, {})
+    assert set(fa) == set(fb)
+    for k, w in fa.items():
+        want = w if k.endswith("actions") else scenario.make_tensor_dtype(w)
+        assert np.array_equal(fb[k], want), k
+    assert fb["states.layer3_state.hx"].shape == (T + P, 6, 7)
+    dev.close()
