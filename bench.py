@@ -12,11 +12,12 @@ replay of 1M transitions per GPU pre-filled before timing.
 
 One *step* = one pass of THE LOOP body of the reference
 (rltime/training/multi_step_trainer.py:245-375) over one batch:
-  ingest of the transitions the train quota asks for (train_frequency=4 ->
-  10 240 per step, as 40 vector steps of 256 envs, device-resident synthetic
-  actor output) -> stratified sum-tree sampling -> sequence gather -> burn-in
-  -> IQN double-Q targets -> forward/backward -> grad all-reduce (N>1) -> clip
-  + Adam -> update_losses.
+  acting for the transitions the train quota asks for (train_frequency=4 ->
+  10 240 per step = 40 vector steps of 256 envs: policy forward replayed from a
+  HIP graph, epsilon-greedy, synthetic env step, device-resident ingest)
+  -> stratified sum-tree sampling -> sequence gather -> burn-in -> IQN
+  double-Q targets -> forward/backward -> grad all-reduce (N>1) -> clip + Adam
+  -> update_losses.  (--no-acting feeds pre-generated actor output instead.)
 Nothing is skipped inside the timed region.  Weak scaling: every rank owns a
 replay shard (its envs) and trains B=512 local sequences; gradients are
 all-reduced, importance weights globalised (rltime_amd/parallel.py).
@@ -54,8 +55,8 @@ def parse():
     ap.add_argument("--nstep-target", type=int, default=2)
     ap.add_argument("--envs", type=int, default=256, help="envs per GPU")
     ap.add_argument("--replay-size", type=int, default=1000000, help="transitions per GPU")
-    ap.add_argument("--acting", action="store_true", help="run the real actor (policy forward) instead of synthetic actor output")
-    ap.add_argument("--acting-graph", action="store_true", help="with --acting: replay the acting forward from a HIP graph")
+    ap.add_argument("--no-acting", action="store_true", help="feed pre-generated actor output instead of running the device actor's policy forward inside the step")
+    ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--channels-last", action="store_true", help="NHWC conv stack (experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +82,7 @@ def build_trainer(args, rank, world, device):
                                       "keep_policy_outputs": False}}}}})
     if args.channels_last:
         config["model"]["args"]["layer_configs"][0]["args"]["channels_last"] = True
-    actors = create_actors(config, device, device_acting=True, use_graph=args.acting_graph)
+    actors = create_actors(config, device, device_acting=True, use_graph=not args.no_acting_graph)
     cls = get_registered_type("trainers", config["training"]["type"])
     trainer = cls(logger=NullLogger(), actors=actors, model_config=config["model"],
                   policy_args=config.get("policy_args", {}))
@@ -210,14 +211,26 @@ def cpu_baseline(args, seconds):
         buf.update_losses(data["extra_data"]["loss_indices"], rep.numpy())
         t_steps += time.time() - t1
         steps += 1
+    # acting share (actor.py:108-147): policy forward on a 32-env vector step, 1 thread
+    EA = 32
+    act_state = {"x": rng.randint(0, 256, (EA, 4, 84, 84)).astype(np.uint8), "layer0_state": {},
+                 "layer1_state": {"hx": np.zeros((EA, H), np.float32), "cx": np.zeros((EA, H), np.float32),
+                                  "initials": np.zeros(EA, np.float32)}, "layer2_state": {}}
+    policy.actor_predict(act_state, 1)
+    t2 = time.time()
+    for _ in range(5):
+        policy.actor_predict(act_state, 1)
+    act_rate = 5 * EA / (time.time() - t2)
+    acted_per_step = args.mbatch * T / 4                        # train_frequency=4
     per_step_full = (t_steps / steps) * (args.mbatch / Bs)
-    per_step_full += (args.mbatch * T / 4) / ingest_rate       # train_frequency=4 ingest share
+    per_step_full += acted_per_step / ingest_rate + acted_per_step / act_rate
     return {
         "value": args.mbatch * T / per_step_full, "unit": "transitions/s", "cores": 1, "kind": "port",
         "learner_steps_per_sec": 1.0 / per_step_full,
         "sample": "oracle (reference algorithm restated): %d learner steps at B=%d (x%d to B=%d), T=%d, burn-in %d, "
-                  "n=%d, torch-CPU fp32 1 thread; ingest %.0f transitions/s; scaled linearly in B"
-                  % (steps, Bs, args.mbatch // Bs, args.mbatch, T, P, n, ingest_rate)}
+                  "n=%d, torch-CPU fp32 1 thread; + acting %.0f and ingest %.0f transitions/s for the step's %d acted "
+                  "transitions; scaled linearly in B" % (steps, Bs, args.mbatch // Bs, args.mbatch, T, P, n, act_rate,
+                                                         ingest_rate, acted_per_step)}
 
 
 def main():
@@ -248,8 +261,7 @@ def main():
     hist = trainer.history_buffer
     feeder = SyntheticFeeder(trainer, args.envs, rank * args.envs, device, seed=99 + rank)
     real_actors = trainer.actors
-    if not args.acting:
-        trainer.actors = feeder
+    trainer.actors = feeder            # pre-fill with pre-generated actor output (no policy forward)
 
     # ---- pre-fill the replay shard (untimed) ---------------------------------
     t0 = time.time()
@@ -264,6 +276,9 @@ def main():
     # the quota accrued during the fill is not training debt of the timed region:
     # start from the steady-state balance so every step feeds exactly its share
     hist.train_quota = 0
+    if not args.no_acting:
+        trainer.actors = real_actors    # timed steps run the real device actor: policy forward (HIP-graph
+        #                                 replay), epsilon-greedy, synthetic env step, DeviceSamples ingest
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if args.amp == "bf16" else None
 
     def one_step():
@@ -328,7 +343,8 @@ def main():
                 "replay_transitions_per_gpu": hist_stats["total_items"],
                 "active_sequences_per_gpu": hist_stats["active_sequences"],
                 "envs_per_gpu": args.envs, "acted_transitions_per_step_per_gpu": acted / args.steps,
-                "acting_policy_forward_in_step": bool(args.acting),
+                "acting_policy_forward_in_step": not args.no_acting,
+                "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world,
                 "replay_fill_seconds": round(fill_s, 2)},
             "roofline": {
