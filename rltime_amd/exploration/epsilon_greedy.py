@@ -50,9 +50,21 @@ class EpsilonGreedyExplorationManager:
         return actions, {"eps": np.array(used)}
 
     def remap_actions_device(self, actions, actor_indices, action_space, progress, generator=None):
+        """Batched device form of remap_actions: per-actor epsilons from one
+        tensor pow (exponents cached on the device), one rand / randint pair."""
         eps = self._get_eps(progress)
-        per = torch.tensor([self._actor_eps(eps, int(a)) for a in actor_indices],
-                           dtype=torch.float32, device=actions.device)
+        key = (actions.device, len(actor_indices))
+        cache = getattr(self, "_dev_cache", None)
+        if cache is None or cache[0] != key:
+            idx = torch.as_tensor([float(a) for a in actor_indices], dtype=torch.float64, device=actions.device)
+            if self.per_actor_exponent_factor:
+                assert int(idx.max().item()) < self.total_actors
+                expo = 1 + (idx / (self.total_actors - 1)) * self.per_actor_exponent_factor
+            else:
+                expo = torch.ones_like(idx)
+            cache = self._dev_cache = (key, expo)
+        per = torch.clamp(torch.pow(torch.as_tensor(eps, dtype=torch.float64, device=actions.device), cache[1]),
+                          min=self.eps_min).float()
         explore = torch.rand(actions.shape[0], device=actions.device, generator=generator) < per
         rnd = torch.randint(0, action_space.n, actions.shape, device=actions.device, generator=generator)
         return torch.where(explore, rnd.to(actions.dtype), actions), {"eps": per}
