@@ -24,6 +24,7 @@ class PolicyTrainer:
         self.model_config, self.policy_args = model_config, policy_args
         self.target_update_freq = 0
         self.value_log = ValueLog()
+        self._gpu_spans = []
 
     # -- hooks for subclasses ------------------------------------------------
     @staticmethod
@@ -76,16 +77,46 @@ class PolicyTrainer:
         self.clock.learner_steps = v
 
     # -- timers (same keys as the reference's timings_* groups) -------------------
+    # The reference times phases with a wall clock only (policy_trainer.py:230-246),
+    # which mis-attributes asynchronous GPU work to whichever phase synchronises
+    # first.  Besides the same wall-clock groups, every phase is bracketed by HIP
+    # events on the current stream; they are resolved (no sync in the hot loop) when
+    # the interval is logged, into the groups timings_gpu_mean_ms / _total_ms.
     def _start_timer(self, name):
         import time
-        self._timer = (name, time.time())
+        ev = None
+        if self._gpu_timing():
+            import torch
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        self._timer = (name, time.time(), ev)
 
     def _end_timer(self):
         import time
-        name, t0 = self._timer
+        name, t0, ev0 = self._timer
         ms = (time.time() - t0) * 1e3
         for agg, group in (("mean", "timings_mean_ms"), ("sum", "timings_total_ms")):
             self.value_log.log(name, ms, agg=agg, group=group, precision=2)
+        if ev0 is not None:
+            import torch
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self._gpu_spans.append((name, ev0, ev1))
+            if len(self._gpu_spans) > 4096:          # long intervals: resolve the oldest (already complete)
+                self._resolve_gpu_spans(2048)
+
+    def _gpu_timing(self):
+        pol = getattr(self, "policy", None)
+        return pol is not None and hasattr(pol, "is_cuda") and pol.is_cuda()
+
+    def _resolve_gpu_spans(self, count=None):
+        spans = self._gpu_spans if count is None else self._gpu_spans[:count]
+        for name, e0, e1 in spans:
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            for agg, group in (("mean", "timings_gpu_mean_ms"), ("sum", "timings_gpu_total_ms")):
+                self.value_log.log(name, ms, agg=agg, group=group, precision=3)
+        del self._gpu_spans[:len(spans)]
 
     # -- acting ----------------------------------------------------------------
     def _log_episode(self, reward, length):
@@ -120,6 +151,7 @@ class PolicyTrainer:
 
     # -- logging / checkpoint ------------------------------------------------------
     def _log_checkpoint(self):
+        self._resolve_gpu_spans()
         rates, total_seconds = self.clock.rates()
         for key, val in rates.items():
             self.value_log.log(key, val, group="this_interval")

@@ -32,6 +32,10 @@ def _run(config, device_acting=True):
     assert last["this_interval"]["steps_trained"] > 0
     assert last["this_interval"]["steps_trained_per_second"] > 0
     assert math.isfinite(last["train"]["qloss"]) and math.isfinite(last["train"]["grad_norm"])
+    # phase timings: the reference's wall-clock keys plus HIP-event GPU time per phase
+    for phase in ("sample_actors", "history_update", "get_train_data", "calc_target_values", "train"):
+        assert phase in last["timings_mean_ms"], phase
+        assert last["timings_gpu_mean_ms"][phase] >= 0.0
     for p in trainer.policy.parameters():
         assert torch.isfinite(p).all()
     return trainer, last
