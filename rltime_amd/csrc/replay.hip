@@ -18,10 +18,11 @@
 //   k_tree_fix        re-sum ancestors of dirty leaves, level by level (a3)
 //   k_per_sample      LDS-staged stratified descent + IS weights      (a3, a4, a8)
 //   k_uniform_sample  flat choice -> (env, start) (+ episode refine)  (a5)
-//   k_gather_rows     time-major state-block gather, 16 B/lane        (a7)
+//   k_gather_rows(_v1) time-major state-block gather, 16 B/lane non-temporal (a7)
 //   k_gather_scalars  n-step scan + per-step scalars                  (a6, a7)
 //   k_loss_stamp / k_loss_write / k_recalc_flagged                    (a9)
-// Row labels are SURVEY.md section 8(a).
+// Row labels are SURVEY.md section 8(a).  Also here: mirl_replay_save / _load
+// (snapshot) and the host-only test hooks (mirl_book_*, mirl_emul_*).
 #include "common.hpp"
 #include "book.hpp"
 #include "np_emul.h"
