@@ -101,6 +101,11 @@ class SequentialModel(nn.Module):
         needs the recurrent state and not the head)."""
         inp = make_tensor(inp, self.device())
         x = inp["x"]
+        # optional: output of layer 0 computed earlier for exactly these rows by
+        # THIS model (trainer-level sharing of the conv stack between the training
+        # pass and the double-Q selection pass, multi_step_trainer.py)
+        shared = inp.get("x_features")
+        first_out = shared.get(id(self)) if isinstance(shared, dict) else None
         extra = None
         if isinstance(x, (tuple, list)):
             x, extra = x[0], torch.cat([v.reshape(v.shape[0], -1) for v in x[1:]], dim=-1)
@@ -116,7 +121,10 @@ class SequentialModel(nn.Module):
                 x, more = self.layer_pre_processors[i](x)
                 result.update(more)
             result["layer_inputs"].append(x)
-            x = layer(x, timesteps=timesteps, **inp.get("layer%d_state" % i, {}))
+            if i == 0 and first_out is not None:
+                x = first_out
+            else:
+                x = layer(x, timesteps=timesteps, **inp.get("layer%d_state" % i, {}))
             if stop_after is not None and i == stop_after:
                 break
         result["output"] = x

@@ -172,6 +172,35 @@ class MultiStepTrainer(PolicyTrainer):
         self._end_timer()
         return True
 
+    def _share_online_features(self, train_data, nstep_target):
+        """The online network sees almost the same frames twice per learner step:
+        `states` in the training pass and `target_states` (the same block shifted
+        by n rows, history.py:245-265) in the double-Q selection pass.  When the two
+        are views of one gathered block, run the online model's first (stateless,
+        conv) layer ONCE over the union of rows, with grad, and hand both passes
+        their slice; the values are those of the separate passes."""
+        if not getattr(self, "double_q", False) or not getattr(self, "share_online_cnn", True):
+            return
+        model = self.policy.model
+        if len(model.layers) < 2 or model.layers[0].is_recurrent() or 0 in model.layer_pre_processors \
+                or model.extra_input_layer == 0:
+            return
+        sx, tx = train_data["states"]["x"], train_data["target_states"]["x"]
+        if isinstance(sx, (tuple, list)):
+            sx, tx = sx[0], tx[0]
+        if not (isinstance(sx, torch.Tensor) and sx.is_cuda and sx.is_contiguous() and tx.is_contiguous()
+                and sx.shape == tx.shape and sx.dtype == tx.dtype):
+            return
+        T, B = sx.shape[0], sx.shape[1]
+        row = sx[0].numel() * sx.element_size()
+        if tx.data_ptr() - sx.data_ptr() != nstep_target * row or nstep_target >= T:
+            return                                     # not the overlapped layout
+        union = torch.as_strided(sx, (T + nstep_target, B) + tuple(sx.shape[2:]), sx.stride())
+        feats = model.layers[0](union.reshape(((T + nstep_target) * B,) + tuple(sx.shape[2:])), timesteps=1)
+        train_data["states"]["x_features"] = {id(model): feats[:T * B].reshape((T, B) + tuple(feats.shape[1:]))}
+        train_data["target_states"]["x_features"] = {
+            id(model): feats[nstep_target * B:].detach().reshape((T, B) + tuple(feats.shape[1:]))}
+
     def learner_step(self, train_data, nstep_train, nstep_target, burn_in_timesteps=0,
                      rnn_steps_train=None, rnn_bootstrap=False, epochs=1, minibatches=1):
         """One pass of multi_step_trainer.py:278-353 over one batch: burn-in,
@@ -180,6 +209,8 @@ class MultiStepTrainer(PolicyTrainer):
         rnn_steps_train = rnn_steps_train or nstep_train
         if burn_in_timesteps:
             train_data = self._burn_in(train_data, burn_in_timesteps, do_target_states=rnn_bootstrap)
+        if epochs * minibatches == 1:        # the shared features' graph is consumed by one backward
+            self._share_online_features(train_data, nstep_target)
         self._start_timer("calc_target_values")
         train_data = deep_apply(train_data, _flat)
         train_data["targets"] = self.calc_target_values(

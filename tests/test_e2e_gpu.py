@@ -84,3 +84,60 @@ def test_training_series_follows_reference():
     np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
     print("max rel dev over all %d steps: qloss %.2e" % (
         len(d["qloss"]), np.max(np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"]))))
+
+
+def test_shared_online_cnn_gives_the_same_trajectory():
+    """share_online_cnn (one conv pass over the union of states / target_states
+    rows for the online net) vs two separate passes: same loss / grad-norm series."""
+    from rltime_amd.acting.acting_interface import ActingInterface
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.spaces import Box, Discrete
+    from rltime_amd.training.iqn import IQN
+    d = np.load(os.path.join(scenario.GOLDEN, "e2e_dqn_lstm_per.npz"))
+    cfg = json.loads(str(d["config"]))
+    spec = StreamSpec(**cfg["spec"])
+
+    class Scripted(ActingInterface):
+        def __init__(self):
+            super().__init__(Box(0, 255, spec.frame_shape, np.uint8), Discrete(spec.n_actions))
+            self.t = 0
+
+        def get_env_count(self):
+            return spec.num_envs
+
+        def set_actor_policy(self, p):
+            pass
+
+        def update_state(self, progress, policy_state=None):
+            pass
+
+        def close(self):
+            pass
+
+        def get_samples(self, min_samples):
+            iters = (max(1, min_samples) + spec.num_envs - 1) // spec.num_envs
+            out = []
+            for step in vector_steps(spec, iters, start_step=self.t):
+                out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
+            self.t += iters
+            return out
+
+    runs = []
+    for share in (True, False):
+        random.seed(3); np.random.seed(3); torch.manual_seed(3)
+        tr = IQN(logger=NullLogger(), actors=Scripted(), model_config=cfg["model"],
+                 policy_args={"dueling": True, "cuda": True, "embedding_dim": 8, "num_sampling_quantiles": 4})
+        series = []
+        orig = tr.value_log.log
+
+        def tap(key, value, *a, _s=series, _o=orig, **k):
+            if key in ("qloss", "grad_norm") and k.get("group") == "train":
+                _s.append(float(value.item() if hasattr(value, "item") else value))
+            return _o(key, value, *a, **k)
+        tr.value_log.log = tap
+        args = copy.deepcopy(cfg["train"])
+        args["share_online_cnn"] = share
+        tr.train(**args)
+        runs.append(series)
+    assert len(runs[0]) == len(runs[1]) > 40
+    np.testing.assert_allclose(runs[0][:60], runs[1][:60], rtol=2e-4, atol=1e-6)
