@@ -47,8 +47,6 @@ class CNN(BaseModule):
         super().__init__()
         self.scale = scale
         self.channels_last = channels_last
-        import os
-        self.fuse_conv_relu = bool(int(os.environ.get("RLTIME_AMD_FUSE_CONV_RELU", "0")))
         self.layers = nn.ModuleList()
         ch = inp_shape[0]
         h, w = inp_shape[1:]
@@ -73,15 +71,8 @@ class CNN(BaseModule):
             # uint8 * python float promotes to float32 in ONE pass (same values as
             # x.float() * scale, cnn.py:44-45)
             x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale
-        fused = self.fuse_conv_relu and x.is_cuda and not torch.is_grad_enabled() \
-            and x.dtype == torch.float32 and not torch.is_autocast_enabled()
         for layer in self.layers:
-            if fused:
-                # no-grad passes (burn-in, target network): MIOpen's fused conv + bias + ReLU
-                x = torch.miopen_convolution_relu(x, layer.weight, layer.bias, layer.stride, layer.padding,
-                                                  layer.dilation, layer.groups)
-            else:
-                x = F.relu(layer(x))
+            x = F.relu(layer(x))
         return x
 
 

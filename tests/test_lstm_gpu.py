@@ -89,19 +89,3 @@ def test_fused_frame_conversion_is_exact(shape):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
 
-
-def test_fused_conv_relu_matches_plain():
-    """no-grad CNN passes through torch.miopen_convolution_relu == relu(conv + bias)."""
-    from rltime_amd.models.torch.modules import CNN
-    torch.manual_seed(0)
-    layers = [{"filters": 32, "kernel": 8, "stride": 4}, {"filters": 64, "kernel": 4, "stride": 2},
-              {"filters": 64, "kernel": 3, "stride": 1}]
-    for cl in (True, False):
-        m = CNN((4, 84, 84), layers, channels_last=cl).cuda()
-        x = torch.randint(0, 256, (64, 4, 84, 84), dtype=torch.uint8).cuda()
-        with torch.no_grad():
-            m.fuse_conv_relu = False
-            a = m(x)
-            m.fuse_conv_relu = True
-            b = m(x)
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
