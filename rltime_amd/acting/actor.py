@@ -13,41 +13,83 @@ from rltime_amd.general.type_registry import get_registered_type
 from rltime_amd.general.utils import deep_apply
 
 
-class GraphedPredict:
-    """The acting forward (policy.actor_predict on the E-env batch) captured once
-    in a HIP graph and replayed per vector step: at E=256 the eager forward is
-    ~30 launch-bound kernels; the replay is one graph launch.  Inputs are copied
-    into static buffers; the recurrent layers' `last_state` tensors are part of
-    the captured outputs, so `make_input_state` keeps working unchanged."""
+class GraphedStep:
+    """One acting vector step minus the environment, as two HIP graphs that share
+    static buffers (reference order of operations, actor.py:108-128):
 
-    def __init__(self, policy, example_state):
-        self.policy = policy
-        self.static_in = deep_apply(example_state, lambda t: t.clone())
+      graph A  (after env.step):  make_input_state (recurrent-state reset on
+               `dones`) -> pack the stored next_state -> policy forward ->
+               epsilon-greedy -> actions for the next env step
+      graph B  (first step of a get_samples call): only the forward +
+               epsilon-greedy on graph A's state, so that the first action after a
+               learner update is chosen with the CURRENT weights like the
+               reference's loop does.
+
+    At E=256 the eager version is ~60 launch-bound kernels and ~0.5 ms of host
+    work per step; a replay is two small input copies and one graph launch.  The
+    recurrent carry lives in static buffers the captured kernels read and write,
+    so it survives the learner's forwards re-binding `layer.last_state`."""
+
+    def __init__(self, actor, obs, dones):
+        pol, self.actor = actor._policy, actor
+        dev = pol.device()
+        self.obs, self.dones = obs.clone(), dones.clone()
+        self.eps = torch.zeros((), dtype=torch.float64, device=dev)
+        self.rec = [layer for layer in pol.model.layers if layer.is_recurrent()]
+        self.carry = [tuple(t.clone() for t in layer.last_state) for layer in self.rec]
+        saved = [tuple(t.clone() for t in pair) for pair in self.carry]
+
+        def head():
+            for layer, pair in zip(self.rec, self.carry):
+                layer.last_state = pair
+            states = pol.make_input_state(self.obs, self.dones)
+            return states, _pack_state(states)
+
+        def tail(states):
+            pred = pol.actor_predict(states, timesteps=1, as_numpy=False)
+            actions = pred["actions"]
+            if actor._exploration is not None:
+                actions, _ = actor._exploration.remap_with_eps_tensor(
+                    actions, self.eps, actor._env_ids, actor._action_space)
+            for layer, (h, c) in zip(self.rec, self.carry):
+                h.copy_(layer.last_state[0])
+                c.copy_(layer.last_state[1])
+            return actions.to(torch.int32), pred["qvalues"].contiguous()
+
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):          # warm-up outside capture (MIOpen find, hipBLASLt workspaces)
             for _ in range(3):
-                policy.actor_predict(self.static_in, timesteps=1, as_numpy=False)
+                states, _ = head()
+                tail(states)
         cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = policy.actor_predict(self.static_in, timesteps=1, as_numpy=False)
-        # recurrent layers publish their running state through `last_state`; the
-        # captured tensors are refreshed by every replay, but the attribute is
-        # re-bound by get_state() and by the learner's own forwards -> re-attach
-        self.static_last = [(layer, layer.last_state) for layer in policy.model.layers
-                            if getattr(layer, "last_state", None) is not None]
+        self.example = deep_apply(states, lambda x: x[0].cpu().numpy())
+        for pair, keep in zip(self.carry, saved):            # the warm-ups advanced the carry
+            pair[0].copy_(keep[0])
+            pair[1].copy_(keep[1])
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.states, self.fields = head()
+            self.next_actions, self.next_q = tail(self.states)
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self.b_actions, self.b_q = tail(self.states)
 
-    def __call__(self, state):
-        src, dst = [], []
-        deep_apply(state, lambda t: src.append(t))
-        deep_apply(self.static_in, lambda t: dst.append(t))
-        torch._foreach_copy_(dst, src)
-        self.graph.replay()
-        for layer, state in self.static_last:
-            layer.last_state = state
-        return {k: v.clone() for k, v in self.static_out.items()}
+    def after_env_step(self, obs, dones, eps):
+        self.obs.copy_(obs)
+        self.dones.copy_(dones)
+        self.eps.fill_(eps)
+        self.graph_a.replay()
+        fields = {k: v.clone() for k, v in self.fields.items() if k != "frames"}
+        fields["frames"] = obs                    # the env's own tensor; the static copy is overwritten next step
+        return fields, self.next_actions.clone(), self.next_q.clone()
+
+    def reselect(self, eps):
+        """Re-run forward + exploration on the current state with the current weights."""
+        self.eps.fill_(eps)
+        self.graph_b.replay()
+        return self.b_actions.clone(), self.b_q.clone()
 
 
 class Actor(ActingInterface):
@@ -113,39 +155,53 @@ class Actor(ActingInterface):
             self.last_state = states
         return samples
 
-    def _predict_device(self, state):
-        if not self._use_graph:
-            return self._policy.actor_predict(state, timesteps=1, as_numpy=False)
-        if self._graphed is None:
-            try:
-                self._graphed = GraphedPredict(self._policy, _to_device_tree(state, self._policy.device()))
-            except Exception as e:                       # capture unsupported for this model: stay eager
-                import logging
-                logging.getLogger().warning("acting graph capture failed (%s); running eagerly", e)
-                self._use_graph = False
-                return self._policy.actor_predict(state, timesteps=1, as_numpy=False)
-        return self._graphed(_to_device_tree(state, self._policy.device()))
+    def _act_eager(self, state):
+        pred = self._policy.actor_predict(state, timesteps=1, as_numpy=False)
+        actions = pred["actions"]
+        if self._exploration is not None:
+            actions, _ = self._exploration.remap_actions_device(
+                actions, self._env_ids, self._action_space, self._progress)
+        return actions.to(torch.int32), pred["qvalues"].contiguous()
 
     def _device_steps(self, iters):
-        out = None
-        for _ in range(iters):
-            pred = self._predict_device(self.last_state)
-            actions = pred["actions"]
-            if self._exploration is not None:
-                actions, _ = self._exploration.remap_actions_device(
-                    actions, self._env_ids, self._action_space, self._progress)
+        out, pending = None, None
+        for it in range(iters):
+            # (1)+(2) actor.py:108-122: action selection with the current weights
+            if pending is not None:
+                actions, qvalues = pending
+            elif self._graphed is not None:
+                actions, qvalues = self._graphed.reselect(self._eps())
+            else:
+                actions, qvalues = self._act_eager(self.last_state)
+            # (3) actor.py:124: the environments
             obs, rewards, dones, stats = self._vec_env.step_device(actions)
-            states = self._policy.make_input_state(obs, dones)
+            rewards, dones8 = rewards.to(torch.float32), dones.to(torch.uint8)
+            # (4) actor.py:128: next input state (+ the next action when replayed from the graph)
+            fields, pending = None, None
+            if self._use_graph:
+                try:
+                    if self._graphed is None:
+                        self._graphed = GraphedStep(self, obs, dones)
+                    fields, next_actions, next_q = self._graphed.after_env_step(obs, dones, self._eps())
+                    pending = (next_actions, next_q)
+                    example = self._graphed.example
+                except Exception as e:                     # capture unsupported for this model: stay eager
+                    import logging
+                    logging.getLogger().warning("acting graph capture failed (%s); running eagerly", e)
+                    self._use_graph, self._graphed = False, None
+            if fields is None:
+                states = self._policy.make_input_state(obs, dones)
+                fields = _pack_state(states)
+                example = deep_apply(states, lambda x: x[0].cpu().numpy()) if out is None else None
+                self.last_state = states
             if out is None:
-                example = deep_apply(states, lambda x: x[0].cpu().numpy())
                 out = DeviceSamples(example, self._num_envs, self._base_env_id)
-            fields = _pack_state(states)
-            fields.update(actions=actions.to(torch.int32), policy=pred["qvalues"].contiguous(),
-                          rewards=rewards.to(torch.float32), dones=dones.to(torch.uint8),
-                          episode_stats=stats)
+            fields.update(actions=actions, policy=qvalues, rewards=rewards, dones=dones8, episode_stats=stats)
             out.append(**fields)
-            self.last_state = states
         return out
+
+    def _eps(self):
+        return self._exploration._get_eps(self._progress) if self._exploration is not None else 0.0
 
 
 def _to_device_tree(state, device):

@@ -49,22 +49,31 @@ class EpsilonGreedyExplorationManager:
             used.append(e)
         return actions, {"eps": np.array(used)}
 
-    def remap_actions_device(self, actions, actor_indices, action_space, progress, generator=None):
-        """Batched device form of remap_actions: per-actor epsilons from one
-        tensor pow (exponents cached on the device), one rand / randint pair."""
-        eps = self._get_eps(progress)
-        key = (actions.device, len(actor_indices))
+    def _device_exponents(self, actor_indices, device):
+        key = (device, len(actor_indices))
         cache = getattr(self, "_dev_cache", None)
         if cache is None or cache[0] != key:
-            idx = torch.as_tensor([float(a) for a in actor_indices], dtype=torch.float64, device=actions.device)
+            idx = torch.as_tensor([float(a) for a in actor_indices], dtype=torch.float64, device=device)
             if self.per_actor_exponent_factor:
                 assert int(idx.max().item()) < self.total_actors
                 expo = 1 + (idx / (self.total_actors - 1)) * self.per_actor_exponent_factor
             else:
                 expo = torch.ones_like(idx)
             cache = self._dev_cache = (key, expo)
-        per = torch.clamp(torch.pow(torch.as_tensor(eps, dtype=torch.float64, device=actions.device), cache[1]),
+        return cache[1]
+
+    def remap_with_eps_tensor(self, actions, eps, actor_indices, action_space, generator=None):
+        """Device half of the remapping for a base epsilon held in a 0-dim float64
+        tensor (so the whole thing can live inside a captured HIP graph): per-actor
+        epsilons from one tensor pow, one rand / randint pair."""
+        per = torch.clamp(torch.pow(eps, self._device_exponents(actor_indices, actions.device)),
                           min=self.eps_min).float()
         explore = torch.rand(actions.shape[0], device=actions.device, generator=generator) < per
         rnd = torch.randint(0, action_space.n, actions.shape, device=actions.device, generator=generator)
         return torch.where(explore, rnd.to(actions.dtype), actions), {"eps": per}
+
+    def remap_actions_device(self, actions, actor_indices, action_space, progress, generator=None):
+        """Batched device form of remap_actions (same epsilon schedule, one
+        np.random draw for the final-epsilon pick like the reference)."""
+        eps = torch.as_tensor(self._get_eps(progress), dtype=torch.float64, device=actions.device)
+        return self.remap_with_eps_tensor(actions, eps, actor_indices, action_space, generator)
