@@ -69,11 +69,13 @@ class GraphedStep:
             pair[0].copy_(keep[0])
             pair[1].copy_(keep[1])
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        # thread_local: RCCL's watchdog thread polls events concurrently in multi-GPU
+        # runs; it must not invalidate this thread's capture
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             self.states, self.fields = head()
             self.next_actions, self.next_q = tail(self.states)
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
             self.b_actions, self.b_q = tail(self.states)
 
     def after_env_step(self, obs, dones, eps):
