@@ -3,31 +3,42 @@
 
     python bench.py --gpus N --steps K --warmup W          # N=1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config {iqn_lstm,rainbow_iqn,dqn_uniform} [--scaling {weak,strong}]
 
-Workload (BASELINE.json configs[3], the configuration the metric is quoted on):
-recurrent IQN (conv -> LSTM512 -> FC512, dueling, 32 quantiles, double-Q,
-rnn_bootstrap) with prioritized sequence replay, B=512 sequences x T=80 train
-steps + 40 burn-in steps, n=2, observations (4,84,84) uint8, synthetic data,
-replay of 1M transitions per GPU pre-filled before timing.
+Workloads (`--config`, default = the one BASELINE.json's
+metric is quoted on):
+  iqn_lstm     BASELINE configs[3]: recurrent IQN (conv -> LSTM512 -> FC512, dueling,
+               32 quantiles, double-Q, rnn_bootstrap), prioritized sequence replay,
+               B=512 sequences x T=80 train steps + 40 burn-in steps, n=2, 256 envs
+  rainbow_iqn  BASELINE configs[2]: IQN (dueling, 3-step), prioritized replay with
+               the 2^20-leaf sum tree, B=512, T=1, 32 envs
+  dqn_uniform  BASELINE configs[1]: DQN + uniform replay, B=256, T=1, n=1, 32 envs
+all on (4,84,84) uint8 synthetic frames with a replay of 1M transitions per GPU
+pre-filled before timing, fp32 (the reference's precision).
 
 One *step* = one pass of THE LOOP body of the reference
 (rltime/training/multi_step_trainer.py:245-375) over one batch:
-  acting for the transitions the train quota asks for (train_frequency=4 ->
-  10 240 per step = 40 vector steps of 256 envs: policy forward replayed from a
-  HIP graph, epsilon-greedy, synthetic env step, device-resident ingest)
-  -> stratified sum-tree sampling -> sequence gather -> burn-in -> IQN
-  double-Q targets -> forward/backward -> grad all-reduce (N>1) -> clip + Adam
-  -> update_losses.  (--no-acting feeds pre-generated actor output instead.)
-Nothing is skipped inside the timed region.  Weak scaling: every rank owns a
-replay shard (its envs) and trains B=512 local sequences; gradients are
-all-reduced, importance weights globalised (rltime_amd/parallel.py).
+  acting for the transitions the train quota asks for (policy forward replayed from
+  a HIP graph, epsilon-greedy, synthetic env step, device-resident ingest)
+  -> sampling (stratified sum-tree / uniform) -> gather -> burn-in -> targets
+  -> forward/backward -> grad all-reduce (N>1) -> clip + Adam -> update_losses.
+Nothing is skipped inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant HIP kernel of the
-path, the frame gather: algorithmic bytes = 2*(L+n)*B*F per launch (read once,
-write once) over the mean launch duration measured with
-HIP events on the launch stream inside the timed region.  `cpu_baseline` is the
-oracle (the reference's algorithm class restated, oracle/) timed on this box's
-host cores on a bounded sample and scaled linearly (stated in `sample`).
+Multi-GPU (`--scaling`): every rank owns a replay shard (its envs).  weak (default,
+what `scaling` reports): each rank trains the configured batch on its own full-size
+shard; strong: the configured batch / envs / replay size are
+whole-job values split over the ranks.  Gradients are all-reduced, importance
+weights globalised (rltime_amd/parallel.py).
+
+Prints ONE JSON line (rank 0).  `value` comes from the wall time of exactly K steps
+between barriers (max over ranks); `step_ms` holds median / p10 / p90 of the K
+per-step device times (HIP events).  `roofline` is the dominant HIP kernel of the
+path, the frame gather: algorithmic bytes per launch over the mean launch duration
+measured with HIP events on the launch stream inside the timed region.
+`roofline_all` lists every librltime_hip kernel (events around every launch, in a
+separate short pass after the timed region so that ~1500 event records per step do
+not perturb `value`).  `cpu_baseline` is the oracle (the reference's algorithm class
+restated, oracle/) timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -43,80 +54,107 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+CONFIGS = {
+    "iqn_lstm": dict(
+        file="synthetic_atari_iqn_lstm.json", envs=256,
+        workload="BASELINE configs[3] atari_iqn_lstm: recurrent IQN, prioritized sequence replay",
+        metric="sampled transitions/sec (= learner steps/sec x B x T), IQN-LSTM B=512 T=80 84x84x4"),
+    "rainbow_iqn": dict(
+        file="synthetic_atari_rainbow_iqn.json", envs=32,
+        workload="BASELINE configs[2] Rainbow-style IQN: dueling, 3-step, prioritized replay (2^20-leaf sum tree)",
+        metric="sampled transitions/sec (= learner steps/sec x B), Rainbow-IQN B=512 T=1 84x84x4"),
+    "dqn_uniform": dict(
+        file="synthetic_atari_dqn.json", envs=32,
+        workload="BASELINE configs[1] DQN + uniform replay, 1M buffer",
+        metric="sampled transitions/sec (= learner steps/sec x B), DQN uniform replay B=256 T=1 84x84x4"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mbatch", type=int, default=512)
-    ap.add_argument("--nstep-train", type=int, default=80)
-    ap.add_argument("--burn-in", type=int, default=40)
-    ap.add_argument("--nstep-target", type=int, default=2)
-    ap.add_argument("--envs", type=int, default=256, help="envs per GPU")
-    ap.add_argument("--replay-size", type=int, default=1000000, help="transitions per GPU")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="iqn_lstm", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--mbatch", type=int, default=None, help="override mbatch_size (whole job under --scaling strong)")
+    ap.add_argument("--nstep-train", type=int, default=None)
+    ap.add_argument("--burn-in", type=int, default=None)
+    ap.add_argument("--nstep-target", type=int, default=None)
+    ap.add_argument("--envs", type=int, default=None, help="envs (per GPU when weak, whole job when strong)")
+    ap.add_argument("--replay-size", type=int, default=1000000, help="transitions (per GPU when weak, whole job when strong)")
     ap.add_argument("--no-acting", action="store_true", help="feed pre-generated actor output instead of running the device actor's policy forward inside the step")
     ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
-    ap.add_argument("--channels-last", action="store_true", help="NHWC conv stack (experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
+    ap.add_argument("--train-arg", action="append", default=[], help="KEY=JSON extra training.args override (experiments)")
     ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "gather_traffic.json"))
     return ap.parse_args()
 
 
-def build_trainer(args, rank, world, device):
+def build_config(args, rank, world):
     from rltime_amd.general.config import load_config
+    from rltime_amd.general.utils import deep_dictionary_update
+    from rltime_amd.parallel import shard_config
+    spec = CONFIGS[args.config]
+    config = load_config(spec["file"])
+    targs = {"warmup_steps": 0, "total_steps": 10 ** 12, "log_freq": 10 ** 12,
+             "history_mode": {"args": {"size": args.replay_size, "device_rng": True, "keep_policy_outputs": False}}}
+    for key, val in (("mbatch_size", args.mbatch), ("nstep_train", args.nstep_train),
+                     ("burn_in_timesteps", args.burn_in), ("nstep_target", args.nstep_target)):
+        if val is not None:
+            targs[key] = val
+    for kv in args.train_arg:
+        k, v = kv.split("=", 1)
+        targs[k] = json.loads(v)
+    deep_dictionary_update(config, {"acting": {"actor_envs": args.envs or spec["envs"]}, "training": {"args": targs}})
+    return shard_config(config, rank, world, args.scaling)
+
+
+def build_trainer(config, device, use_graph, data_parallel):
     from rltime_amd.general.loggers import NullLogger
     from rltime_amd.general.type_registry import get_registered_type
-    from rltime_amd.general.utils import deep_dictionary_update
     from rltime_amd.train import create_actors
-    config = load_config("synthetic_atari_iqn_lstm.json")
-    deep_dictionary_update(config, {
-        "acting": {"actor_envs": args.envs, "env_base": rank * args.envs, "total_envs": world * args.envs},
-        "training": {"args": {
-            "mbatch_size": args.mbatch, "nstep_train": args.nstep_train,
-            "burn_in_timesteps": args.burn_in, "nstep_target": args.nstep_target,
-            "warmup_steps": 0, "total_steps": 10 ** 12, "log_freq": 10 ** 12,
-            "history_mode": {"args": {"size": args.replay_size, "device_rng": True,
-                                      "keep_policy_outputs": False}}}}})
-    if args.channels_last:
-        config["model"]["args"]["layer_configs"][0]["args"]["channels_last"] = True
-    actors = create_actors(config, device, device_acting=True, use_graph=not args.no_acting_graph)
+    actors = create_actors(config, device, device_acting=True, use_graph=use_graph)
     cls = get_registered_type("trainers", config["training"]["type"])
     trainer = cls(logger=NullLogger(), actors=actors, model_config=config["model"],
                   policy_args=config.get("policy_args", {}))
+    trainer.data_parallel = data_parallel
     trainer.setup(**config["training"]["args"])
-    return trainer, config
+    return trainer
 
 
 class SyntheticFeeder:
-    """Stands in for Actor.get_samples during the bench: the same DeviceSamples a
-    device-resident actor emits (frames, LSTM state, actions, rewards, dones),
-    pre-generated in HBM, without the policy forward."""
+    """Stands in for Actor.get_samples during the replay pre-fill (and for the
+    --no-acting variant): the same DeviceSamples a device-resident actor emits,
+    pre-generated in HBM with the layout of one real acting step, without the
+    policy forward."""
 
-    def __init__(self, trainer, envs, env_base, device, seed):
+    def __init__(self, probe, device, seed):
         from rltime_amd.acting.acting_interface import DeviceSamples
         self.cls = DeviceSamples
-        self.envs, self.env_base = envs, env_base
+        self.envs, self.env_base, self.example = probe.num_envs, probe.env_base, probe.example_state
+        step = probe.vector_steps[0]
         g = torch.Generator(device=device).manual_seed(seed)
-        H = 512
+        E = self.envs
         self.pool = []
         for _ in range(8):
-            u = torch.rand(2, envs, device=device, generator=g)
-            self.pool.append(dict(
-                frames=torch.randint(0, 256, (envs, 4, 84, 84), dtype=torch.uint8, device=device, generator=g),
-                state=torch.randn(envs, 2 * H, device=device, generator=g) * 0.3,
-                initials=(u[1] < 0.002).float(),
-                actions=torch.randint(0, 6, (envs,), dtype=torch.int32, device=device, generator=g),
+            u = torch.rand(2, E, device=device, generator=g)
+            fields = dict(
+                frames=torch.randint(0, 256, tuple(step["frames"].shape), dtype=torch.uint8, device=device, generator=g),
+                actions=torch.randint(0, 6, (E,), dtype=torch.int32, device=device, generator=g),
                 rewards=torch.bucketize(u[0], torch.tensor([0.1, 0.9, 1.0], device=device)).clamp(max=2).float() - 1.0,
-                dones=(u[1] < 0.002).to(torch.uint8)))
-        self.example = {"x": np.zeros((4, 84, 84), np.uint8), "layer0_state": {},
-                        "layer1_state": {"hx": np.zeros(H, np.float32), "cx": np.zeros(H, np.float32),
-                                         "initials": np.float32(0)},
-                        "layer2_state": {}}
+                dones=(u[1] < 0.002).to(torch.uint8))
+            if step.get("state") is not None:
+                fields["state"] = torch.randn(tuple(step["state"].shape), device=device, generator=g) * 0.3
+            if step.get("initials") is not None:
+                fields["initials"] = (u[1] < 0.002).float()
+            if step.get("extra") is not None:
+                fields["extra"] = torch.randn(tuple(step["extra"].shape), device=device, generator=g)
+            self.pool.append(fields)
         self.t = 0
-        self.count = envs
 
     def get_env_count(self):
         return self.envs
@@ -133,31 +171,50 @@ class SyntheticFeeder:
         return out
 
 
+def seed_priorities(hist, device, chunk=1 << 18):
+    """after the fill, priorities = |N(0,1)| + 1e-6 written
+    through update_losses for every live transition (T = 1: one leaf each)."""
+    first, count = hist.env_meta()
+    g = torch.Generator(device=device).manual_seed(5)
+    for e in range(len(first)):
+        offs = torch.arange(int(first[e]), int(count[e]), device=device, dtype=torch.int64)
+        for at in range(0, offs.numel(), chunk):
+            o = offs[at:at + chunk]
+            idx = torch.stack([torch.full_like(o, e + hist._env_base), o], dim=1).contiguous()
+            hist.update_losses(idx, torch.randn(o.numel(), device=device, generator=g).abs() + 1e-6)
+
+
 def cpu_baseline(args, seconds):
     """The oracle — the reference's algorithm class (per-transition records,
-    np.stack batch assembly, torch-CPU fwd/bwd with the reference's 1 thread) —
-    on a bounded sample of the same workload, scaled linearly to B x T."""
+    np.stack batch assembly, torch-CPU fwd/bwd) — on bounded samples of the
+    config-D workload, scaled linearly in B to B=512.  Headline leg: 1 torch
+    thread, what the reference runs with (models/torch/torch_model.py:25 calls
+    torch.set_num_threads(1)); second leg: all host cores."""
     from oracle import replay as orc
     from oracle import qmath
+    from oracle.replay import tree_map
     from rltime_amd.general.config import load_config
+    from rltime_amd.models.torch.utils import make_tensor
     from rltime_amd.policies.iqn import IQNPolicy
     from rltime_amd.spaces import Box, Discrete
-    torch.set_num_threads(1)          # reference: models/torch/torch_model.py:25
-    T, P, n = args.nstep_train, args.burn_in, args.nstep_target
-    Bs, E, H, A = 4, 8, 512, 6
+    nproc = os.cpu_count() or 1
+    T, P, n = 80, 40, 2
+    B_full = 512
+    E, H, A = 8, 512, 6
     config = load_config("synthetic_atari_iqn_lstm.json")
+    torch.set_num_threads(1)
     mk = lambda: IQNPolicy.create(model_config=config["model"], observation_space=Box(0, 255, (4, 84, 84), np.uint8),  # noqa: E731
                                   action_space=Discrete(A), cuda=False, **config["policy_args"])
     policy, target = mk(), mk()
     opt = torch.optim.Adam(policy.parameters(), eps=1e-5)
     buf = orc.OraclePrioritizedReplay(
-        size=E * 400, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
+        size=E * 500, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
         alpha=0.9, beta=0.6, max_weight_factor=0.9, discount_function=orc.make_discount(0.99))
     rng = np.random.RandomState(0)
     frame_pool = [rng.randint(0, 256, (4, 84, 84)).astype(np.uint8) for _ in range(64)]
     t0 = time.time()
     fed = 0
-    for s in range(300):
+    for s in range(400):
         samples = []
         for e in range(E):
             samples.append({
@@ -171,22 +228,19 @@ def cpu_baseline(args, seconds):
         buf.update(samples)
         fed += E
     ingest_rate = fed / (time.time() - t0)
-    buf.train_quota = 0
 
     def flat(x):
         return x.reshape((x.shape[0] * x.shape[1],) + x.shape[2:])
 
     def tt(tree):
-        from rltime_amd.models.torch.utils import make_tensor
         return make_tensor(tree, "cpu")
 
-    steps, t_steps = 0, 0.0
-    while t_steps < seconds and steps < 3:
-        t1 = time.time()
+    f32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.float32))  # noqa: E731
+
+    def learner_step(Bs):
+        buf.train_quota = 0
         batch = buf.get_train_data(Bs, 0.5)
-        from oracle.replay import tree_map
-        # burn-in (multi_step_trainer.py:90-131)
-        for pol, key in ((policy, "states"), (target, "target_states")):
+        for pol, key in ((policy, "states"), (target, "target_states")):      # multi_step_trainer.py:90-131
             st = tt(tree_map(batch[key], lambda x: flat(x[:P])))
             with torch.no_grad():
                 pol.predict(st, P)
@@ -195,7 +249,6 @@ def cpu_baseline(args, seconds):
             batch[key]["layer1_state"]["hx"][P] = (hx * keep).numpy()
             batch[key]["layer1_state"]["cx"][P] = (cx * keep).numpy()
         data = tree_map(batch, lambda x: flat(x[P:]))
-        f32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.float32))  # noqa: E731
         with torch.no_grad():
             z_t = target.predict(tt(data["target_states"]), T)[0]
             z_s = policy.predict(tt(data["target_states"]), T)[0]
@@ -209,8 +262,31 @@ def cpu_baseline(args, seconds):
         torch.nn.utils.clip_grad_norm_(policy.parameters(), 40.0)
         opt.step()
         buf.update_losses(data["extra_data"]["loss_indices"], rep.numpy())
-        t_steps += time.time() - t1
-        steps += 1
+
+    def leg(threads, plan, budget):
+        """plan: [(B, max steps)] -> seconds per B=512 learner step from the largest B that ran."""
+        torch.set_num_threads(threads)
+        per_b, spent = {}, 0.0
+        for Bs, reps in plan:
+            times = []
+            for _ in range(reps):
+                if spent > budget and times:
+                    break
+                t1 = time.time()
+                learner_step(Bs)
+                times.append(time.time() - t1)
+                spent += times[-1]
+            if times:
+                per_b[Bs] = (min(times), len(times))
+            if spent > budget:
+                break
+        Bmax = max(per_b)
+        return per_b[Bmax][0] * (B_full / Bmax), per_b, spent
+
+    learner_step(2)                                           # untimed warm-up (allocator, MKL)
+    one_s, one_b, one_spent = leg(1, [(4, 1), (16, 1)], seconds * 0.6)
+    all_s, all_b, all_spent = leg(nproc, [(32, 1)], seconds * 0.4)
+    torch.set_num_threads(1)
     # acting share (actor.py:108-147): policy forward on a 32-env vector step, 1 thread
     EA = 32
     act_state = {"x": rng.randint(0, 256, (EA, 4, 84, 84)).astype(np.uint8), "layer0_state": {},
@@ -221,55 +297,59 @@ def cpu_baseline(args, seconds):
     for _ in range(5):
         policy.actor_predict(act_state, 1)
     act_rate = 5 * EA / (time.time() - t2)
-    acted_per_step = args.mbatch * T / 4                        # train_frequency=4
-    per_step_full = (t_steps / steps) * (args.mbatch / Bs)
-    per_step_full += acted_per_step / ingest_rate + acted_per_step / act_rate
+    acted_per_step = B_full * T / 4                        # train_frequency=4
+    extra = acted_per_step / ingest_rate + acted_per_step / act_rate
+    fmt = lambda d: ", ".join("B=%d: %.2f s/step (%d run%s)" % (b, t, k, "" if k == 1 else "s") for b, (t, k) in sorted(d.items()))  # noqa: E731
     return {
-        "value": args.mbatch * T / per_step_full, "unit": "transitions/s", "cores": 1, "kind": "port",
-        "learner_steps_per_sec": 1.0 / per_step_full,
-        "sample": "oracle (reference algorithm restated): %d learner steps at B=%d (x%d to B=%d), T=%d, burn-in %d, "
-                  "n=%d, torch-CPU fp32 1 thread; + acting %.0f and ingest %.0f transitions/s for the step's %d acted "
-                  "transitions; scaled linearly in B" % (steps, Bs, args.mbatch // Bs, args.mbatch, T, P, n, act_rate,
-                                                         ingest_rate, acted_per_step)}
+        "value": B_full * T / (one_s + extra), "unit": "transitions/s", "cores": 1, "kind": "port",
+        "learner_steps_per_sec": 1.0 / (one_s + extra),
+        "host_nproc": nproc,
+        "all_cores": {"value": B_full * T / (all_s + extra), "unit": "transitions/s", "cores": nproc,
+                      "learner_steps_per_sec": 1.0 / (all_s + extra),
+                      "sample": "same oracle path with torch.set_num_threads(%d): %s, scaled x%d to B=512; acting/ingest shares as in the 1-thread leg"
+                                % (nproc, fmt(all_b), B_full // max(all_b))},
+        "sample": "oracle (reference algorithm restated, config D: T=80, burn-in 40, n=2, torch-CPU fp32, 1 thread like the "
+                  "reference's torch.set_num_threads(1)): %s; the largest B scaled linearly x%d to B=512 (%.1f s of CPU work); "
+                  "+ acting %.0f and ingest %.0f transitions/s for the step's %d acted transitions; host has %d logical cores"
+                  % (fmt(one_b), B_full // max(one_b), one_spent + all_spent, act_rate, ingest_rate, acted_per_step, nproc)}
 
 
 def main():
     args = parse()
+    from rltime_amd import parallel
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))      # exercise the RCCL path on 1 GPU (debug)
-    if world > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+    rank, world, local, dp = parallel.init_from_env(device=device)
 
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
-    trainer, config = build_trainer(args, rank, world, device)
-    if world > 1 or force_dist:
-        from rltime_amd.parallel import DataParallel
-        trainer.data_parallel = DataParallel()
-        # identical initial weights on every rank
-        for p in trainer.policy.parameters():
-            dist.broadcast(p.data, 0)
-        trainer.sync_target()
+    spec = CONFIGS[args.config]
+    config = build_config(args, rank, world)
+    targs = config["training"]["args"]
+    trainer = build_trainer(config, device, use_graph=not args.no_acting_graph, data_parallel=dp)
     hist = trainer.history_buffer
-    feeder = SyntheticFeeder(trainer, args.envs, rank * args.envs, device, seed=99 + rank)
     real_actors = trainer.actors
-    trainer.actors = feeder            # pre-fill with pre-generated actor output (no policy forward)
+    envs = real_actors.get_env_count()
+    size = targs["history_mode"]["args"]["size"]
 
     # ---- pre-fill the replay shard (untimed) ---------------------------------
     t0 = time.time()
-    per_call = 64 * args.envs
-    fed = 0
-    while fed < args.replay_size + args.envs:
+    probe = real_actors.get_samples(envs)                    # one real acting step: learns the transition layout
+    hist.update(probe)
+    feeder = SyntheticFeeder(probe, device, seed=99 + rank)
+    trainer.actors = feeder            # pre-generated actor output (no policy forward) for the fill
+    per_call = 64 * envs
+    fed = envs
+    while fed < size + envs:
         hist.update(feeder.get_samples(per_call))
         fed += per_call
+    per = targs["history_mode"]["type"] == "prioritized_replay"
+    if per and targs["nstep_train"] == 1:
+        seed_priorities(hist, device)
     torch.cuda.synchronize()
     fill_s = time.time() - t0
     hist_stats = hist.stats()
@@ -297,52 +377,90 @@ def main():
         dist.barrier()
     hist.profile(True)
     steps_before = trainer.steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     launches, gather_ms = hist.profile(False)
     acted = trainer.steps - steps_before
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- per-kernel pass (untimed): HIP events around every librltime_hip launch
+    table, prof_step_ms = [], None
+    if args.profile_steps > 0:
+        from rltime_amd import _lib
+        _lib.check(_lib.lib.mirl_profile_reset())
+        _lib.check(_lib.lib.mirl_profile_set(2))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.profile_steps):
+            one_step()
+        torch.cuda.synchronize()
+        prof_step_ms = (time.perf_counter() - t1) / args.profile_steps * 1e3
+        _lib.check(_lib.lib.mirl_profile_set(0))
+        table = _lib.profile_table()
+
     if rank == 0:
-        T, P, n, B = args.nstep_train, args.burn_in, args.nstep_target, args.mbatch
+        T, P, n, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs.get("nstep_target") or targs["nstep_train"], targs["mbatch_size"]
         L = T + P
         F = 4 * 84 * 84
-        rows = L + n if n < L else 2 * L
+        rows = hist._rows
         algo_bytes = 2.0 * rows * B * F
         avg_ms = gather_ms / max(launches, 1)
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
-        traffic = None
-        if os.path.isfile(args.pmc_traffic):
+        traffic, traffic_src = None, None
+        if args.config == "iqn_lstm" and os.path.isfile(args.pmc_traffic):
             try:
                 traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/gather_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) over tools/gather_probe.py " \
+                              "at this B/T/P/n, collected by tools/profile_round.sh — NOT measured in this run"
             except Exception:
                 traffic = None
+        kernels = []
+        for row in sorted(table, key=lambda r: -r["total_ms"]):
+            if not row["calls"]:
+                continue
+            avg_us = row["total_ms"] / row["calls"] * 1e3
+            by = row["algorithmic_bytes"] / row["calls"]
+            gbps = by / (avg_us * 1e-6) / 1e9 if by > 0 else None
+            kernels.append({"kernel": row["name"], "launches_per_step": round(row["calls"] / args.profile_steps, 2),
+                            "avg_us": round(avg_us, 2), "ms_per_step": round(row["total_ms"] / args.profile_steps, 4),
+                            "algorithmic_bytes_per_launch": by if by > 0 else None,
+                            "achieved_GBps": round(gbps, 1) if gbps else None,
+                            "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4) if gbps else None,
+                            "bound": "hbm" if by >= 1 << 20 else "latency"})
         out = {
-            "metric": "sampled transitions/sec (= learner steps/sec x B x T), IQN-LSTM B=512 T=80 84x84x4",
+            "metric": spec["metric"],
             "value": world * B * T * args.steps / dt,
             "unit": "transitions/s",
             "learner_steps_per_sec": args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "step_ms": {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
+                        "p90": float(np.percentile(step_ms, 90)), "source": "HIP events at step boundaries, rank 0"},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.amp == "none" else "bf16(network autocast)+f32(hot path)",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[3] atari_iqn_lstm: recurrent IQN, prioritized sequence replay",
-                "mbatch_per_gpu": B, "nstep_train": T, "burn_in": P, "nstep_target": n,
-                "frame": "(4,84,84) u8", "lstm_state": "2x512 f32 per transition",
+                "workload": spec["workload"] + (" [%s scaling: %s]" % (
+                    args.scaling, "global batch split over ranks" if args.scaling == "strong" else "per-rank batch fixed")),
+                "mbatch_per_gpu": B, "global_mbatch": B * world, "nstep_train": T, "burn_in": P, "nstep_target": n,
+                "frame": "(4,84,84) u8",
                 "replay_transitions_per_gpu": hist_stats["total_items"],
                 "active_sequences_per_gpu": hist_stats["active_sequences"],
-                "envs_per_gpu": args.envs, "acted_transitions_per_step_per_gpu": acted / args.steps,
+                "tree_capacity": hist_stats["tree_capacity"] if per else None,
+                "envs_per_gpu": envs, "acted_transitions_per_step_per_gpu": acted / args.steps,
                 "acting_policy_forward_in_step": not args.no_acting,
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world,
@@ -352,9 +470,16 @@ def main():
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches": launches,
-                "traffic": traffic},
+                "traffic": traffic, "traffic_source": traffic_src},
+            "roofline_all": {
+                "how": "%d extra steps after the timed region with a HIP event pair around every librltime_hip launch "
+                       "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
+                       "latency-bound kernels (tree / sampling / bookkeeping) report us per call only" % (args.profile_steps, HBM_PEAK_GBPS),
+                "ms_per_step_with_events": prof_step_ms, "kernels": kernels} if kernels else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config == "iqn_lstm":
+            out["config"]["lstm_state"] = "2x512 f32 per transition"
+        if world == 1 and not args.no_cpu_baseline and args.config == "iqn_lstm":
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
@@ -363,7 +488,7 @@ def main():
         print(json.dumps(out), flush=True)
     trainer.actors = real_actors
     hist.close()
-    if world > 1 or force_dist:
+    if dp is not None:
         dist.destroy_process_group()
 
 

@@ -195,6 +195,18 @@ int mirl_replay_load(mirl_replay* h, const char* path_host);
  * synchronises the device.                                                    */
 int mirl_replay_profile(mirl_replay* h, int32_t enable, int64_t* launches, double* total_ms);
 
+/* Per-kernel timing of EVERY librltime_hip launch (any entry point of this
+ * header) with HIP event pairs on the launch stream, accounted per kernel name
+ * together with the algorithmic bytes of each launch, for
+ * the per-kernel roofline table bench.py prints.  level 0 = off (default),
+ * 2 = on.  collect() synchronises the device and folds the finished event pairs
+ * into the per-kernel totals; get(i) reads entry i < *n_kernels.                 */
+int mirl_profile_set(int32_t level);
+int mirl_profile_collect(int32_t* n_kernels);
+int mirl_profile_get(int32_t i, char* name_host, int32_t name_cap, int64_t* calls,
+                     double* total_ms, double* algorithmic_bytes);
+int mirl_profile_reset(void);
+
 /* ---- introspection / test hooks (host results; these DO synchronise) ------- */
 int mirl_replay_stats(mirl_replay* h, int64_t* total_items, int64_t* active_sequences,
                       int64_t* train_quota, int64_t* tree_capacity, int64_t* n_slots);

@@ -110,6 +110,10 @@ _SIGNATURES = {
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
     "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_replay_profile": [_vp, _i32, _P(_i64), _P(_f64)],
+    "mirl_profile_set": [_i32],
+    "mirl_profile_collect": [_P(_i32)],
+    "mirl_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_f64), _P(_f64)],
+    "mirl_profile_reset": [],
     "mirl_replay_save": [_vp, C.c_char_p],
     "mirl_replay_load": [_vp, C.c_char_p],
     "mirl_replay_uniform_total": [_vp, _P(_i64)],
@@ -175,6 +179,21 @@ def require_gpu():
         raise MirlError(
             "librltime_hip: no HIP device visible. The rltime_amd hot path runs "
             "only on an AMD GPU (MI355X / gfx950); there is no CPU fallback.")
+
+
+def profile_table():
+    """Collect the per-kernel event timings gathered since the last reset:
+    [{name, calls, total_ms, algorithmic_bytes}] (mirl_profile_*)."""
+    n = C.c_int32()
+    check(lib.mirl_profile_collect(C.byref(n)), "mirl_profile_collect")
+    out = []
+    for i in range(n.value):
+        name = C.create_string_buffer(96)
+        calls, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        check(lib.mirl_profile_get(i, name, 96, C.byref(calls), C.byref(ms), C.byref(by)), "mirl_profile_get")
+        out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
+                    "algorithmic_bytes": by.value})
+    return out
 
 
 def np_ptr(a):

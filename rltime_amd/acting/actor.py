@@ -181,6 +181,12 @@ class Actor(ActingInterface):
             # (4) actor.py:128: next input state (+ the next action when replayed from the graph)
             fields, pending = None, None
             if self._use_graph:
+                rec = [layer for layer in self._policy.model.layers if layer.is_recurrent()]
+                # GraphedStep re-binds layer.last_state to its static carry and advances
+                # it through warm-up forwards and a capture whose kernels never run; if
+                # the capture fails the eager fallback must continue from THIS state
+                saved = None if self._graphed is not None else \
+                    [None if layer.last_state is None else tuple(t.clone() for t in layer.last_state) for layer in rec]
                 try:
                     if self._graphed is None:
                         self._graphed = GraphedStep(self, obs, dones)
@@ -191,6 +197,9 @@ class Actor(ActingInterface):
                     import logging
                     logging.getLogger().warning("acting graph capture failed (%s); running eagerly", e)
                     self._use_graph, self._graphed = False, None
+                    if saved is not None:
+                        for layer, keep in zip(rec, saved):
+                            layer.last_state = keep
             if fields is None:
                 states = self._policy.make_input_state(obs, dones)
                 fields = _pack_state(states)

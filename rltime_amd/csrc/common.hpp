@@ -79,4 +79,61 @@ class StagingRing {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---------------------------------------------------------------------------
+// Per-kernel timing with HIP events ON THE LAUNCH STREAM (mirl_profile_*).
+// level 0: off (one predictable branch per launch); level >= 2: every
+// librltime_hip launch is bracketed by an event pair and accounted under its
+// kernel name together with the ALGORITHMIC bytes the call site states for it
+// (DESIGN.md section 3), so that bench.py can print achieved GB/s per kernel
+// against the HBM roofline.  Event pairs are resolved by mirl_profile_collect()
+// (which synchronises); nothing in the hot path waits.
+struct ProfEntry { std::string name; int64_t calls = 0; double ms = 0.0, bytes = 0.0; };
+class Profiler {
+ public:
+  int level = 0;
+  std::vector<ProfEntry> entries;
+  struct Pending { int idx; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  int index_of(const char* name) {
+    for (size_t i = 0; i < entries.size(); ++i) if (entries[i].name == name) return (int)i;
+    entries.push_back(ProfEntry{name}); return (int)entries.size() - 1;
+  }
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+  }
+  void collect() {
+    (void)hipDeviceSynchronize();
+    for (Pending& p : pending) {
+      float ms = 0.f;
+      if (p.a && p.b && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { entries[(size_t)p.idx].ms += ms; ++entries[(size_t)p.idx].calls; }
+      if (p.a) pool.push_back(p.a);
+      if (p.b) pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void reset() { collect(); entries.clear(); }
+};
+Profiler& profiler();
+
+struct ProfScope {
+  int idx = -1; hipEvent_t a = nullptr; hipStream_t st;
+  ProfScope(const char* name, double bytes, hipStream_t s) : st(s) {
+    Profiler& p = profiler();
+    if (p.level < 2) return;
+    idx = p.index_of(name);
+    p.entries[(size_t)idx].bytes += bytes;
+    a = p.get();
+    (void)hipEventRecord(a, st);
+  }
+  ~ProfScope() {
+    if (idx < 0) return;
+    Profiler& p = profiler();
+    hipEvent_t b = p.get();
+    (void)hipEventRecord(b, st);
+    p.pending.push_back(Profiler::Pending{idx, a, b});
+  }
+};
+
 }  // namespace mirl

@@ -69,6 +69,7 @@ extern "C" int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const floa
                                   float* h_out, float* c_out, float* h_next, float* c_next, void* stream) {
   if (B <= 0 || H <= 0 || !gates || !c_in || !h_next || !c_next) return fail(MIRL_ERR_ARG, "bad lstm_cell_fwd arguments");
   int64_t n = (int64_t)B * H;
+  ProfScope ps("k_lstm_cell_fwd", (double)n * 4.0 * (4 + 1 + 4 + 2 + (h_out ? 1 : 0) + (c_out ? 1 : 0)), (hipStream_t)stream);
   hipLaunchKernelGGL(k_lstm_cell_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)B, (int)H, gates, c_in,
                      keep_next, h_out, c_out, h_next, c_next);
   MIRL_LAUNCH_CHECK();
@@ -79,6 +80,7 @@ extern "C" int mirl_lstm_cell_bwd(int32_t B, int32_t H, float* gates, const floa
                                   const float* dh_rec, float* dc_rec, const float* keep_next, int32_t first, void* stream) {
   if (B <= 0 || H <= 0 || !gates || !c_t || !c_in || !dc_rec || (!first && !dh_rec)) return fail(MIRL_ERR_ARG, "bad lstm_cell_bwd arguments");
   int64_t n = (int64_t)B * H;
+  ProfScope ps("k_lstm_cell_bwd", (double)n * 4.0 * (4 + 2 + (d_out ? 1 : 0) + (first ? 0 : 2) + 4 + 1), (hipStream_t)stream);
   hipLaunchKernelGGL(k_lstm_cell_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)B, (int)H, gates, c_t,
                      c_in, d_out, dh_rec, dc_rec, keep_next, (int)first);
   MIRL_LAUNCH_CHECK();

@@ -222,6 +222,7 @@ using namespace mirl;
 extern "C" int mirl_q_target_dqn(int64_t M, int32_t A, const float* q_target, const float* q_select, const float* returns,
                                  const float* nsteps, const float* masks, double gamma, double vf_eps, float* targets, void* stream) {
   if (M <= 0 || A <= 0 || !q_target || !q_select || !returns || !nsteps || !masks || !targets) return fail(MIRL_ERR_ARG, "bad q_target_dqn arguments");
+  ProfScope ps("k_target_dqn", (double)M * (2.0 * A * 4 + 16), (hipStream_t)stream);
   hipLaunchKernelGGL(k_target_dqn, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, q_target, q_select,
                      returns, nsteps, masks, (float)gamma, vf_eps, targets);
   MIRL_LAUNCH_CHECK();
@@ -234,6 +235,7 @@ extern "C" int mirl_q_target_iqn(int64_t M, int32_t Nt, int32_t Ns, int32_t A, c
   if (M <= 0 || A <= 0 || Nt <= 0 || Ns <= 0 || !z_target || !z_select || !returns || !nsteps || !masks || !targets) return fail(MIRL_ERR_ARG, "bad q_target_iqn arguments");
   size_t lds = sizeof(float) * 4 * ((size_t)Ns * A + A);
   if (lds > 64 * 1024) return fail(MIRL_ERR_ARG, "q_target_iqn: Ns*A too large for the LDS strip");
+  ProfScope ps("k_target_iqn", (double)M * (((double)Nt + Ns) * A * 4 + Nt * 4 + 12), (hipStream_t)stream);
   hipLaunchKernelGGL(k_target_iqn, dim3((unsigned)((M + 3) / 4)), dim3(256), lds, (hipStream_t)stream, M, (int)Nt, (int)Ns, (int)A,
                      z_target, z_select, returns, nsteps, masks, (float)gamma, vf_eps, targets);
   MIRL_LAUNCH_CHECK();
@@ -243,6 +245,7 @@ extern "C" int mirl_q_target_iqn(int64_t M, int32_t Nt, int32_t Ns, int32_t A, c
 extern "C" int mirl_loss_dqn(int64_t M, int32_t A, const float* q, const int64_t* actions, const float* targets, const float* weights,
                              double kappa, int32_t mode, double row_scale, float* row_loss, float* dq, float* td, void* stream) {
   if (M <= 0 || A <= 0 || !q || !actions || !targets || !row_loss || !dq || !td) return fail(MIRL_ERR_ARG, "bad loss_dqn arguments");
+  ProfScope ps("k_loss_dqn", (double)M * (2.0 * A * 4 + 8 + 4 + (weights ? 4 : 0) + 8), (hipStream_t)stream);
   hipLaunchKernelGGL(k_loss_dqn, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, (int)A, q, actions, targets, weights,
                      (float)kappa, (int)mode, (float)row_scale, row_loss, dq, td);
   MIRL_LAUNCH_CHECK();
@@ -253,6 +256,7 @@ extern "C" int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const 
                              const float* targets, const float* weights, double kappa, double row_scale, float* row_loss, float* dz,
                              float* abs_td, void* stream) {
   if (M <= 0 || A <= 0 || N <= 0 || Nt <= 0 || !z || !taus || !actions || !targets || !row_loss || !dz || !abs_td) return fail(MIRL_ERR_ARG, "bad loss_iqn arguments");
+  ProfScope ps("k_loss_iqn", (double)M * (2.0 * N * A * 4 + N * 4 + Nt * 4 + 8 + (weights ? 4 : 0) + 8), (hipStream_t)stream);
   if (N <= 64 && Nt <= 64 && (64 % N) == 0) {
     hipLaunchKernelGGL(k_loss_iqn_wave, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, M, (int)N, (int)Nt, (int)A, z, taus,
                        actions, targets, weights, (float)kappa, (float)row_scale, row_loss, dz, abs_td);

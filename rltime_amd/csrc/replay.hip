@@ -46,6 +46,7 @@ struct Dev {                 // passed by value to kernels
   int32_t* slot_env; int64_t* slot_base; uint8_t* flag;
   int32_t* dirty; int32_t* dirty_count;
   int64_t* first; int64_t* count;
+  int32_t* bad;              // host-coherent flag: a sampled leaf was inactive (reference: assert, prioritized_replay_history.py:306)
   const double* gpow;        // gamma ** k, k < N, computed by the host libm like Python's float.__pow__
   double alpha, mwf, eps;
 };
@@ -242,10 +243,11 @@ k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, u
     const int64_t base = d.slot_base[idx];
     int64_t start = base - d.P;
     if (e >= 0) start = refine_start(d, e, start);
+    else *(volatile int32_t*)d.bad = 1;               // surfaced as MIRL_ERR_STATE by the next host call
     env_out[i] = e; start_out[i] = start;
     if (base_out) base_out[i] = base;                  // losses stay attached to the unshifted sequence
     // weight = ((leaf / p_sum) * total_items) ** (-beta)
-    double w = pow((d.tv[pos] / total.v) * active, -beta);
+    double w = e >= 0 ? pow((d.tv[pos] / total.v) * active, -beta) : 0.0;   // an inactive row trains with weight 0
     w_tmp[i] = w;
     local_max = w > local_max ? w : local_max;
   }
@@ -400,7 +402,8 @@ k_gather_scalars(Dev d, int B, int R, int overlapped, const int32_t* __restrict_
   if (i >= (int64_t)rows * B) return;
   const int r = (int)(i / B), b = (int)(i % B);
   int32_t e = env[b];
-  if (e < 0 || e >= d.E) e = 0;
+  const bool inactive = e < 0 || e >= d.E;        // rows stay in bounds but report no loss index
+  if (inactive) e = 0;
   const int64_t s0 = start[b];
   if (r < R && o.initials) {
     int64_t src = row_src_off(d, overlapped, r, e, s0);
@@ -429,7 +432,7 @@ k_gather_scalars(Dev d, int B, int R, int overlapped, const int32_t* __restrict_
   if (o.policy) for (int a = 0; a < d.A; ++a) o.policy[i * d.A + a] = d.policy[sl * d.A + a];
   if (o.weights) o.weights[i] = weight[b];
   if (o.loss_indices) {
-    if (r < d.P) { o.loss_indices[2 * i] = -1; o.loss_indices[2 * i + 1] = -1; }
+    if (r < d.P || inactive) { o.loss_indices[2 * i] = -1; o.loss_indices[2 * i + 1] = -1; }
     else {
       o.loss_indices[2 * i] = (int64_t)(e + d.env_base);
       o.loss_indices[2 * i + 1] = loss_start ? loss_start[b] + (r - d.P) : off;
@@ -488,6 +491,74 @@ k_recalc_flagged(Dev d) {
   d.dirty[at] = (int32_t)s;
 }
 
+// Same as k_recalc_flagged for 8 <= T <= 128 (one NumPy pairwise block): one
+// WAVE per sequence instead of one lane walking T strided losses.  The T loss
+// slots are read coalesced into LDS; lanes 0..7 keep NumPy's eight interleaved
+// accumulators r0..r7 (np_pairwise_block: r_j = a[j] + a[8+j] + a[16+j] + ...),
+// three shuffle steps combine them in NumPy's association
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), lane 0 adds the n%8 tail; the max is a
+// wave shuffle reduction.  Values and kinds are those of np_emul.h::seq_priority.
+template <class T_>
+__device__ __forceinline__ void wave_pairwise(const float* sl, int n, int lane, bool as_f64_fresh, T_& sum, T_& mx) {
+  auto g = [&](int t) -> T_ { float l = sl[t]; return (as_f64_fresh && l < 0.0f) ? (T_)1.0 : (T_)l; };
+  T_ m = g(lane < n ? lane : 0);
+  for (int t = lane + 64; t < n; t += 64) { T_ x = g(t); m = x > m ? x : m; }
+  for (int o = 32; o > 0; o >>= 1) { T_ x = __shfl_xor(m, o); m = x > m ? x : m; }
+  mx = m;
+  const int j = lane & 7, full = n - (n % 8);
+  T_ r = g(j);
+  for (int i = 8; i < full; i += 8) r = r + g(i + j);
+  r = r + __shfl_down(r, 1);          // lanes 0,2,4,6: r0+r1, r2+r3, r4+r5, r6+r7
+  r = r + __shfl_down(r, 2);          // lanes 0,4
+  r = r + __shfl_down(r, 4);          // lane 0
+  for (int i = full; i < n; ++i) r = r + g(i);
+  sum = r;                            // valid on lane 0
+}
+
+__global__ void __launch_bounds__(256)
+k_recalc_flagged_wave(Dev d) {
+  __shared__ float s_loss[4][128];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + w;
+  bool live = s < d.n_slots && d.flag[s];
+  int32_t e = live ? d.slot_env[s] : -1;
+  float* sl = s_loss[w];
+  const int n = d.T;
+  if (live && e >= 0) {
+    const int64_t base = d.slot_base[s], ring0 = (int64_t)e * d.C;
+    for (int t = lane; t < n; t += 64) sl[t] = d.loss[ring0 + (base + t) % d.C];
+  }
+  __syncthreads();
+  if (!live) return;
+  if (lane == 0) d.flag[s] = 0;
+  if (e < 0) return;
+  bool fresh = false;
+  for (int t = lane; t < n; t += 64) fresh |= sl[t] < 0.0f;
+  fresh = __any(fresh);
+  TV p;
+  if (fresh) {                         // a Python-float 1.0 in the list -> float64 array
+    double sum, mx;
+    wave_pairwise<double>(sl, n, lane, true, sum, mx);
+    double mean = sum / (double)n;
+    double a = d.mwf * mx, b = (1.0 - d.mwf) * mean;
+    double mixed = a + b;
+    p.v = pow(mixed, d.alpha); p.k = K64;
+  } else {
+    float sum, mx;
+    wave_pairwise<float>(sl, n, lane, false, sum, mx);
+    float mean = (float)((double)sum / (double)n);
+    float a = (float)d.mwf * mx, b = (float)(1.0 - d.mwf) * mean;
+    float mixed = a + b;
+    p.v = (double)(float)pow((double)mixed, (double)(float)d.alpha); p.k = K32;
+  }
+  if (lane == 0) {
+    d.tv[d.cap + s] = p.v; d.tk[d.cap + s] = p.k;
+    if (d.tmin) d.tmin[d.cap + s] = p.v;
+    int at = atomicAdd(d.dirty_count, 1);
+    d.dirty[at] = (int32_t)s;
+  }
+}
+
 __global__ void k_copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -516,6 +587,21 @@ using namespace mirl;
 
 namespace mirl {
 std::string& last_error_ref() { static thread_local std::string e; return e; }
+Profiler& profiler() { static Profiler p; return p; }
+}
+
+extern "C" int mirl_profile_set(int32_t level) { profiler().level = level; return MIRL_OK; }
+extern "C" int mirl_profile_collect(int32_t* n_kernels) { profiler().collect(); if (n_kernels) *n_kernels = (int32_t)profiler().entries.size(); return MIRL_OK; }
+extern "C" int mirl_profile_reset(void) { profiler().reset(); return MIRL_OK; }
+extern "C" int mirl_profile_get(int32_t i, char* name_host, int32_t name_cap, int64_t* calls, double* total_ms, double* algorithmic_bytes) {
+  Profiler& p = profiler();
+  if (i < 0 || (size_t)i >= p.entries.size() || !name_host || name_cap <= 0) return fail(MIRL_ERR_ARG, "bad profile_get arguments");
+  const ProfEntry& e = p.entries[(size_t)i];
+  snprintf(name_host, (size_t)name_cap, "%s", e.name.c_str());
+  if (calls) *calls = e.calls;
+  if (total_ms) *total_ms = e.ms;
+  if (algorithmic_bytes) *algorithmic_bytes = e.bytes;
+  return MIRL_OK;
 }
 
 struct mirl_replay {
@@ -528,8 +614,10 @@ struct mirl_replay {
   double* w_tmp = nullptr; int64_t w_tmp_cap = 0;
   std::vector<void*> allocs;
   double* gpow_dev = nullptr;
+  int32_t* bad_host = nullptr;
   int gather_nt = 0;
   int gather_variant = 1, gather_order = 0;
+  int recalc_wave = 1;
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
@@ -557,6 +645,7 @@ extern "C" int mirl_replay_destroy(mirl_replay* h) {
   if (!h) return MIRL_OK;
   (void)hipDeviceSynchronize();
   h->staging.destroy();
+  if (h->bad_host) (void)hipHostFree(h->bad_host);
   for (void* p : h->allocs) (void)hipFree(p);
   delete h;
   return MIRL_OK;
@@ -601,6 +690,12 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
     if (e != hipSuccess) { mirl_replay_destroy(h); return fail(MIRL_ERR_HIP, hipGetErrorString(e)); }
     d.gpow = h->gpow_dev;
   }
+  {
+    hipError_t e = hipHostMalloc((void**)&h->bad_host, sizeof(int32_t), hipHostMallocDefault);
+    if (e != hipSuccess) { mirl_replay_destroy(h); return fail(MIRL_ERR_HIP, hipGetErrorString(e)); }
+    *h->bad_host = 0;
+    d.bad = h->bad_host;
+  }
   if (d.per) {
     TRY(dev_alloc(h, &d.loss, slots));
     TRY(dev_alloc(h, &d.prio_index, slots, 0xFF));
@@ -629,6 +724,7 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   h->gather_nt = nt ? atoi(nt) : 1;
   if (const char* v = getenv("MIRL_GATHER_VARIANT")) h->gather_variant = atoi(v);
   if (const char* v = getenv("MIRL_GATHER_ORDER")) h->gather_order = atoi(v);
+  if (const char* v = getenv("MIRL_RECALC_WAVE")) h->recalc_wave = atoi(v);
   MIRL_HIP(hipDeviceSynchronize());
   *out = h;
   return MIRL_OK;
@@ -640,6 +736,7 @@ static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s
   int vec = (row_bytes % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)src) % 16 == 0);
   int chunks = vec ? row_bytes / 16 : row_bytes;
   int gx = (chunks + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+  ProfScope ps(row_bytes >= 8192 ? "k_scatter_rows(frames)" : "k_scatter_rows(small rows)", 2.0 * K * row_bytes, st);
   hipLaunchKernelGGL(k_scatter_rows, dim3(gx, K), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)ring, s_env, s_off,
                      h->d.C, row_bytes, stride, vec);
   MIRL_LAUNCH_CHECK();
@@ -677,18 +774,22 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   rc = scatter(h, in->extra, d.extra, s_env, s_off, K, d.X * 4, (int64_t)d.X * 4, st); if (rc) return rc;
   rc = scatter(h, in->state, d.state, s_env, s_off, K, d.S * 4, (int64_t)d.S * 4, st); if (rc) return rc;
   rc = scatter(h, in->policy, d.policy, s_env, s_off, K, d.A * 4, (int64_t)d.A * 4, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_ingest_scalars, dim3((K + 255) / 256), dim3(256), 0, st, d, K, s_env, s_off,
-                     in->initials, in->actions, in->rewards, in->dones);
+  {
+    ProfScope ps("k_ingest_scalars", 2.0 * K * (13 + (d.per ? 16 : 0)), st);
+    hipLaunchKernelGGL(k_ingest_scalars, dim3((K + 255) / 256), dim3(256), 0, st, d, K, s_env, s_off,
+                       in->initials, in->actions, in->rewards, in->dones);
+  }
   MIRL_LAUNCH_CHECK();
   int nt = (int)p.table_ops.size(), ne = (int)p.env_ops.size(), nl = d.per ? (int)p.leaf_ops.size() : 0;
   if (!d.per) nt = 0;
   int nmax = nt > ne ? nt : ne; nmax = nl > nmax ? nl : nmax;
   if (nmax) {
+    ProfScope ps("k_plan_apply", 0.0, st);
     hipLaunchKernelGGL(k_plan_apply, dim3((nmax + 255) / 256), dim3(256), 0, st, d, nt, (const TableOp*)(db + o_tab),
                        ne, (const EnvOp*)(db + o_eop), nl, (const LeafOp*)(db + o_lop));
     MIRL_LAUNCH_CHECK();
   }
-  if (nl) { hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d); MIRL_LAUNCH_CHECK(); }
+  if (nl) { ProfScope ps("k_tree_fix(ingest)", 0.0, st); hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d); MIRL_LAUNCH_CHECK(); }
   return h->staging.mark(st);
 }
 
@@ -732,6 +833,10 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
   hipStream_t st = (hipStream_t)stream;
   Book& bk = h->book;
   Dev& d = h->d;
+  if (h->bad_host && *h->bad_host) {
+    *h->bad_host = 0;
+    return fail(MIRL_ERR_STATE, "an earlier sample call drew an inactive tree leaf (prioritized_replay_history.py:306 asserts base_sample is not None); those rows were given weight 0 and no loss index");
+  }
   int rc = bk.charge_quota(B);                       // replay_history.py:176-181 (even when None is returned)
   if (rc) { last_error_ref() = bk.err; return rc; }
   ++h->sample_calls;
@@ -755,8 +860,11 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
       h->allocs.push_back(p); h->w_tmp = p; h->w_tmp_cap = B;
     }
     double beta = anneal_beta(bk.cfg, train_progress);
-    hipLaunchKernelGGL(k_per_sample, dim3(1), dim3(1024), 0, st, d, (int)B, u_dev, seed, h->sample_calls,
-                       (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, loss_start, weight, h->w_tmp, stats);
+    {
+      ProfScope ps("k_per_sample", (double)B * d.log2cap * 9.0, st);
+      hipLaunchKernelGGL(k_per_sample, dim3(1), dim3(1024), 0, st, d, (int)B, u_dev, seed, h->sample_calls,
+                         (double)bk.active, beta, bk.cfg.global_importance_scaling, slot, env, start, loss_start, weight, h->w_tmp, stats);
+    }
     MIRL_LAUNCH_CHECK();
     if (rng_host) return h->staging.mark(st);
     return MIRL_OK;
@@ -782,9 +890,12 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
     memcpy(hb + o_pick, picks, sizeof(int64_t) * (size_t)B);
   }
   rc = h->staging.upload(total, st); if (rc) return rc;
-  hipLaunchKernelGGL(k_uniform_sample, dim3((B + 255) / 256), dim3(256), 0, st, d, (int)B,
-                     rng_host ? (const int64_t*)(db + o_pick) : (const int64_t*)nullptr, seed, h->sample_calls,
-                     (int)nc, (const int64_t*)(db + o_cum), (const int32_t*)(db + o_env), slot, env, start, loss_start, weight);
+  {
+    ProfScope ps("k_uniform_sample", 0.0, st);
+    hipLaunchKernelGGL(k_uniform_sample, dim3((B + 255) / 256), dim3(256), 0, st, d, (int)B,
+                       rng_host ? (const int64_t*)(db + o_pick) : (const int64_t*)nullptr, seed, h->sample_calls,
+                       (int)nc, (const int64_t*)(db + o_cum), (const int32_t*)(db + o_env), slot, env, start, loss_start, weight);
+  }
   MIRL_LAUNCH_CHECK();
   return h->staging.mark(st);
 }
@@ -797,6 +908,9 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = h->prof && ring == (const void*)h->d.frames;
   if (timed) { MIRL_HIP(hipEventCreate(&e0)); MIRL_HIP(hipEventCreate(&e1)); MIRL_HIP(hipEventRecord(e0, st)); }
+  {
+  ProfScope ps(ring == (const void*)h->d.frames ? "k_gather_rows(frames)" : (ring == (const void*)h->d.state ? "k_gather_rows(recurrent state)" : "k_gather_rows(extra)"),
+               2.0 * (double)blocks * row_bytes, st);
   if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16)      // small rows (recurrent state) keep the 256-lane shape
     hipLaunchKernelGGL(k_gather_rows_v1, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
@@ -806,6 +920,7 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   else
     hipLaunchKernelGGL(k_gather_rows<0>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);
+  }
   MIRL_LAUNCH_CHECK();
   if (timed) { MIRL_HIP(hipEventRecord(e1, st)); h->prof_events.push_back(std::make_pair(e0, e1)); }
   return MIRL_OK;
@@ -970,8 +1085,11 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
   if (!d.A) o.policy = nullptr;
   int rows = h->rows > d.L ? h->rows : d.L;
   int64_t n = (int64_t)rows * B;
-  hipLaunchKernelGGL(k_gather_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, (int)B, h->rows, h->overlapped,
-                     env, start, loss_start, weight, o);
+  {
+    ProfScope ps("k_gather_scalars", (double)d.L * B * (5.0 * d.N + 24.0 + (o.weights ? 4 : 0) + (o.loss_indices ? 16 : 0) + 8.0 * d.A) + (double)rows * B * 8.0, st);
+    hipLaunchKernelGGL(k_gather_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d, (int)B, h->rows, h->overlapped,
+                       env, start, loss_start, weight, o);
+  }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
@@ -985,13 +1103,22 @@ extern "C" int mirl_replay_update_losses(mirl_replay* h, int64_t count, const in
   Dev& d = h->d;
   uint64_t epoch = h->epoch++;
   unsigned g = (unsigned)((count + 255) / 256);
-  hipLaunchKernelGGL(k_loss_stamp, dim3(g), dim3(256), 0, st, d, count, indices, epoch);
+  { ProfScope ps("k_loss_stamp", (double)count * 24.0, st);
+    hipLaunchKernelGGL(k_loss_stamp, dim3(g), dim3(256), 0, st, d, count, indices, epoch); }
   MIRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_loss_write, dim3(g), dim3(256), 0, st, d, count, indices, losses, epoch);
+  { ProfScope ps("k_loss_write", (double)count * 32.0, st);
+    hipLaunchKernelGGL(k_loss_write, dim3(g), dim3(256), 0, st, d, count, indices, losses, epoch); }
   MIRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_recalc_flagged, dim3((unsigned)((d.n_slots + 255) / 256)), dim3(256), 0, st, d);
+  if (d.T >= 8 && d.T <= 128 && h->recalc_wave) {
+    ProfScope ps("k_recalc_flagged_wave", (double)d.n_slots + (double)count * 4.0 * 2, st);
+    hipLaunchKernelGGL(k_recalc_flagged_wave, dim3((unsigned)((d.n_slots + 3) / 4)), dim3(256), 0, st, d);
+  } else {
+    ProfScope ps("k_recalc_flagged", (double)d.n_slots + (double)count * 4.0 * 2, st);
+    hipLaunchKernelGGL(k_recalc_flagged, dim3((unsigned)((d.n_slots + 255) / 256)), dim3(256), 0, st, d);
+  }
   MIRL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d);
+  { ProfScope ps("k_tree_fix(update_losses)", 0.0, st);
+    hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d); }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

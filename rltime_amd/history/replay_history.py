@@ -112,6 +112,11 @@ class ReplayHistoryBuffer(History):
         super().__init__(**kwargs)
         _lib.require_gpu()
         self.size = size
+        if train_frequency and float(train_frequency) != int(train_frequency):
+            # the reference adds it to the quota as a number (replay_history.py:90-91,
+            # :73 int(-quota / train_frequency)); the shard keeps an integer quota
+            raise ValueError("train_frequency must be a whole number of trained samples per acted "
+                             "sample (got %r)" % (train_frequency,))
         self.train_frequency = train_frequency
         self.avoid_episode_crossing = avoid_episode_crossing
         self._num_envs = num_envs

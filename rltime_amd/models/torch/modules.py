@@ -28,6 +28,14 @@ def _frames_to_f32_nhwc(x, scale):
     return out
 
 
+def _lead_strides(lead, inner):
+    out, acc = [], inner
+    for n in reversed(lead):
+        out.append(acc)
+        acc *= n
+    return tuple(reversed(out))
+
+
 class BaseModule(nn.Module):
     """modules/base.py:4-13."""
 
@@ -59,8 +67,28 @@ class CNN(BaseModule):
         if channels_last:
             self.to(memory_format=torch.channels_last)
 
-    def forward(self, x, **kwargs):
-        if self.channels_last and self.scale and x.is_cuda and x.dtype == torch.uint8 \
+    def prepare_input(self, x):
+        """The input conversion of forward() on its own (uint8 NCHW [..., C, H, W] ->
+        float32 * scale in NHWC memory, csrc/convert.hip), for callers that feed
+        several passes from one gathered block and want to convert it ONCE
+        (MultiStepTrainer._prepare_frames).  Returns None when the fused path does
+        not apply; the result is handed back through forward(prepared=True)."""
+        if not (self.channels_last and self.scale and isinstance(x, torch.Tensor) and x.is_cuda
+                and x.dtype == torch.uint8 and x.dim() >= 4 and x.is_contiguous()
+                and not torch.is_autocast_enabled()):
+            return None
+        lead = tuple(x.shape[:-3])
+        flat = _frames_to_f32_nhwc(x.reshape((-1,) + tuple(x.shape[-3:])), self.scale)
+        # logical [..., C, H, W] view of the NHWC buffer (each frame is channels_last)
+        c, h, w = x.shape[-3:]
+        return flat.as_strided(lead + (c, h, w), _lead_strides(lead, c * h * w) + (1, w * c, c))
+
+    def forward(self, x, prepared=False, **kwargs):
+        if prepared:
+            # already float32 * scale; NHWC memory unless an index op re-laid it out
+            if self.channels_last and not x.is_contiguous(memory_format=torch.channels_last):
+                x = x.contiguous(memory_format=torch.channels_last)
+        elif self.channels_last and self.scale and x.is_cuda and x.dtype == torch.uint8 \
                 and x.dim() == 4 and x.is_contiguous() and not torch.is_autocast_enabled():
             x = _frames_to_f32_nhwc(x, self.scale)       # one fused HIP pass (csrc/convert.hip)
         elif self.channels_last:

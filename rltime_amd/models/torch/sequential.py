@@ -106,6 +106,10 @@ class SequentialModel(nn.Module):
         # pass and the double-Q selection pass, multi_step_trainer.py)
         shared = inp.get("x_features")
         first_out = shared.get(id(self)) if isinstance(shared, dict) else None
+        # optional: the main observation already converted for layer 0 (float32 *
+        # scale, NHWC) by CNN.prepare_input — one conversion of the gathered block
+        # serves every pass of a learner step
+        prepared = inp.get("x_prepared")
         extra = None
         if isinstance(x, (tuple, list)):
             x, extra = x[0], torch.cat([v.reshape(v.shape[0], -1) for v in x[1:]], dim=-1)
@@ -123,6 +127,8 @@ class SequentialModel(nn.Module):
             result["layer_inputs"].append(x)
             if i == 0 and first_out is not None:
                 x = first_out
+            elif i == 0 and prepared is not None and self.extra_input_layer != 0 and 0 not in self.layer_pre_processors:
+                x = layer(prepared, timesteps=timesteps, prepared=True, **inp.get("layer0_state", {}))
             else:
                 x = layer(x, timesteps=timesteps, **inp.get("layer%d_state" % i, {}))
             if stop_after is not None and i == stop_after:

@@ -1,63 +1,135 @@
-"""Data-parallel glue for one process per GPU (torch.distributed, backend
-"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Data-parallel glue for one process per GPU (torch.distributed; backend
+"nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests and in the 2-ranks-on-
+one-GPU test).
 
 The replay shards by environment: rank r owns envs [r*E/R, (r+1)*E/R), their
 rings, their priority tree and free list, ingests only those transitions,
-samples B/R... sequences locally and gathers locally — no frame ever crosses
-xGMI (the reference has no multi-GPU path at all).  Only
-three things are exchanged per learner step:
+samples its share of the batch locally and gathers locally — no frame ever
+crosses xGMI (the reference has no multi-GPU path at all).
+Exchanged per learner step:
 
-  1. gradients: one flat fp32 bucket, all-reduce(SUM) / R, between backward and
-     the clip/Adam step (the hook TorchTrainer._reduce_gradients calls);
+  1. gradients: ONE flat fp32 bucket that the parameters' .grad tensors are views
+     of (no pack / unpack copies), all-reduce(AVG) between backward and the
+     clip / Adam step (the hook TorchTrainer._reduce_gradients calls).  8.1 M
+     parameters = 32.5 MB: ~0.2 ms on xGMI against a 180 ms step, so it is one
+     blocking collective rather than a bucketed overlap;
   2. 3 doubles per rank — (sum of priorities, active sequences, local max raw
-     weight) — all-gathered to turn shard-local importance weights into the
-     weights one global tree would have produced, including the batch-max
-     normalisation (prioritized_replay_history.py:327,353-354);
-  3. optionally logged scalars.
-Everything operates on tensors of whatever device the process group serves."""
+     weight) — exchanged (all-reduce of a zero-padded (R, 3) buffer, so the same
+     code serves RCCL and gloo) to turn shard-local importance weights into the
+     weights ONE tree over the union of the shards would have produced,
+     including the batch-max normalisation
+     (prioritized_replay_history.py:327,353-354);
+  3. one host int per loop iteration over a gloo side group — "my shard could
+     form a batch" — so that ranks only enter the collectives together
+     (lock-step guard; no device synchronisation involved).
+Target-network sync, learning-rate and epsilon schedules are replicated
+deterministically (same acted-step counters on every rank), no communication.
+"""
+import copy
+import os
+
 import torch
 import torch.distributed as dist
 
 
-def shard_config(config, rank, world):
-    """Split acting envs and replay capacity evenly over `world` ranks."""
-    import copy
+def shard_config(config, rank, world, scaling="strong"):
+    """Per-rank view of a whole-job config.  Envs and replay capacity are always
+    split evenly (rank r owns envs [r*E/R, (r+1)*E/R)).  scaling="strong": the
+    configured mbatch_size is the GLOBAL batch and every rank trains B/R
+    sequences; "weak": every rank keeps the
+    configured mbatch_size, envs and replay size (the job grows with R)."""
+    assert scaling in ("strong", "weak")
     cfg = copy.deepcopy(config)
-    envs = cfg["acting"]["actor_envs"]
-    assert envs % world == 0, "actor_envs must divide by the number of ranks"
-    cfg["acting"]["actor_envs"] = envs // world
-    cfg["acting"]["env_base"] = rank * (envs // world)
-    hm = cfg["training"]["args"]["history_mode"]
+    acting = cfg.setdefault("acting", {})
+    envs = acting.get("actor_envs", 1)
+    targs = cfg["training"]["args"]
+    hm = targs.setdefault("history_mode", {})
     hm.setdefault("args", {})
-    hm["args"]["size"] = hm["args"]["size"] // world
+    if scaling == "strong":
+        assert envs % world == 0, "actor_envs must divide by the number of ranks"
+        per = envs // world
+        acting["total_envs"] = envs
+        if "size" in hm["args"]:
+            hm["args"]["size"] = hm["args"]["size"] // world
+        mb = targs.get("mbatch_size")
+        if mb:
+            assert mb % world == 0, "mbatch_size must divide by the number of ranks"
+            targs["mbatch_size"] = mb // world
+    else:
+        per = envs
+        acting["total_envs"] = envs * world
+    acting["actor_envs"] = per
+    acting["env_base"] = rank * per
     return cfg
 
 
 class DataParallel:
-    def __init__(self, group=None):
+    def __init__(self, group=None, host_group=None, force=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._flat = None
-        import os
-        self.force = bool(os.environ.get("BENCH_FORCE_DIST"))   # run the collectives even at world 1
+        self._params = None
+        # run the collectives even at world 1 (exercises the RCCL path on one GPU)
+        self.force = bool(os.environ.get("BENCH_FORCE_DIST")) if force is None else force
+        self.host_group = host_group
+        self._backend = dist.get_backend(group)
 
-    def all_reduce_gradients(self, module):
-        grads = [p.grad for p in module.parameters() if p.grad is not None]
-        if not grads or (self.world == 1 and not self.force):
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    # -- parameters / gradients ---------------------------------------------------
+    def broadcast_parameters(self, module, src=0):
+        """Identical initial weights (and buffers) on every rank."""
+        if not self.active:
             return
-        n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
-            self._flat = torch.empty(n, dtype=grads[0].dtype, device=grads[0].device)
-        views = []
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src, group=self.group)
+
+    def attach(self, module):
+        """Make every parameter's .grad a view of one flat bucket.  Autograd then
+        accumulates straight into the bucket and the all-reduce needs no copies;
+        zero_grad() must zero the bucket (TorchTrainer does) instead of dropping
+        the .grad tensors."""
+        params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         at = 0
-        for g in grads:
-            views.append(self._flat[at:at + g.numel()].view_as(g))
-            at += g.numel()
-        torch._foreach_copy_(views, grads)
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.div_(self.world)
-        torch._foreach_copy_(grads, views)
+        for p in params:
+            p.grad = flat[at:at + p.numel()].view_as(p)
+            at += p.numel()
+        self._flat, self._params = flat, params
+        return flat
+
+    def zero_grad(self):
+        self._flat.zero_()
+
+    def all_reduce_gradients(self, module=None):
+        if not self.active:
+            return
+        if self._flat is None:
+            raise RuntimeError("DataParallel.attach(module) must run before the first backward")
+        p = self._params[-1]            # a set_to_none zero_grad elsewhere would silently detach the views
+        assert p.grad is not None and p.grad.untyped_storage().data_ptr() == self._flat.untyped_storage().data_ptr(), \
+            "parameter .grad no longer aliases the gradient bucket"
+        if self._backend == "nccl":
+            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._flat.div_(self.world)
+
+    # -- importance weights ---------------------------------------------------------
+    def exchange_rows(self, mine):
+        """mine: 1-D float64 device tensor -> (R, len) tensor holding every rank's
+        row (all-reduce of a zero-padded buffer: supported for device tensors by
+        both RCCL and gloo, unlike all_gather)."""
+        buf = torch.zeros((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
+        buf[self.rank] = mine
+        if self.world > 1 or self.force:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
 
     def globalize_weights(self, weights, p_sum, n_active, max_raw, beta):
         """weights: shard-normalised importance weights (any shape); p_sum,
@@ -65,16 +137,51 @@ class DataParallel:
         Returns weights normalised as if all shards were one tree:
             w_global_i = (p_i * N_g / P_g)^-beta / max_j(...)
         using w_local_i * max_raw = (p_i * N_l / P_l)^-beta."""
-        if self.world == 1 and not self.force:
+        if not self.active:
             return weights
         mine = torch.stack([p_sum.double().reshape(()),
                             torch.as_tensor(float(n_active), dtype=torch.float64, device=p_sum.device),
                             max_raw.double().reshape(())])
-        allr = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(allr, mine, group=self.group)
-        allr = torch.stack(allr)                                   # (R, 3)
+        allr = self.exchange_rows(mine)                            # (R, 3)
         P_g, N_g = allr[:, 0].sum(), allr[:, 1].sum()
         k = ((N_g * allr[:, 0]) / (allr[:, 1] * P_g)) ** (-beta)   # raw_global = raw_local * k_r
         top = (allr[:, 2] * k).max()
         scale = (allr[self.rank, 2] * k[self.rank] / top)
         return weights * scale.to(weights.dtype)
+
+    # -- lock-step guard -------------------------------------------------------------
+    def all_ready(self, ready):
+        """True when EVERY rank reports ready.  A host-side exchange (gloo side
+        group, CPU tensor): whether a shard can form a batch is decided by host
+        bookkeeping, so no device synchronisation is involved."""
+        if not self.active or self.world == 1:
+            return bool(ready)
+        flag = torch.tensor([1 if ready else 0], dtype=torch.int32)
+        group = self.host_group if self.host_group is not None else self.group
+        if self.host_group is None and self._backend == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+
+
+def init_from_env(backend=None, device=None):
+    """Process-group setup for a torchrun launch (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment).  Returns (rank, world, local_rank, DataParallel
+    or None).  backend None = "nccl" (RCCL); a gloo side group carries the
+    host-side lock-step flag."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    force = bool(os.environ.get("BENCH_FORCE_DIST"))
+    if world == 1 and not force:
+        return rank, world, local, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    backend = backend or "nccl"
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = device if device is not None else torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    host_group = dist.new_group(backend="gloo") if (backend == "nccl" and world > 1) else None
+    return rank, world, local, DataParallel(host_group=host_group, force=force)

@@ -2,6 +2,16 @@
 
     python -m rltime_amd.train synthetic_atari_iqn_lstm.json --num-envs 64 \
         --conf-update '{"training": {"args": {"total_steps": 200000}}}'
+
+One process per GPU (the reference has no multi-GPU path):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m rltime_amd.train synthetic_atari_iqn_lstm.json [--scaling strong|weak]
+
+Every rank reads RANK / LOCAL_RANK / WORLD_SIZE, takes its shard of the config
+(rltime_amd.parallel.shard_config: envs and replay split by env id; "strong" =
+the configured mbatch_size is the global batch), joins the RCCL process group and
+trains data-parallel; rank 0 logs.
 """
 import argparse
 import json
@@ -34,15 +44,22 @@ def create_actors(config, device="cuda", device_acting=True, use_graph=False):
                  base_env_id=acting.get("env_base", 0), total_env_ids=acting.get("total_envs"))
 
 
-def train(config, logger=None, device="cuda", device_acting=True):
-    """train.py:26-63."""
+def train(config, logger=None, device="cuda", device_acting=True, data_parallel=None, use_graph=False,
+          resume=None, on_trainer=None):
+    """train.py:26-63.  `data_parallel`: rltime_amd.parallel.DataParallel when this
+    process is one rank of a multi-GPU job (config already sharded)."""
     logger = logger or NullLogger(echo=True)
     logger.log_config(config)
-    actors = create_actors(config, device, device_acting)
+    actors = create_actors(config, device, device_acting, use_graph=use_graph)
     training = config["training"]
     trainer_cls = get_registered_type("trainers", training["type"])
     trainer = trainer_cls(logger=logger, actors=actors, model_config=config["model"],
                           policy_args=config.get("policy_args", {}))
+    trainer.data_parallel = data_parallel
+    if resume:
+        trainer.resume_from = resume
+    if on_trainer is not None:
+        on_trainer(trainer)
     try:
         trainer.train(**training["args"])
     finally:
@@ -50,8 +67,11 @@ def train(config, logger=None, device="cuda", device_acting=True):
     return trainer
 
 
-def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=None, log_name=None):
-    """train.py:66-111."""
+def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=None, log_name=None,
+                      scaling="strong", backend=None, resume=None, seed=None):
+    """train.py:66-111, plus the one-process-per-GPU launch."""
+    import torch
+    from rltime_amd import parallel
     config = load_config(path)
     validate_config(config)
     if env is not None:
@@ -60,8 +80,28 @@ def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=N
         config.setdefault("acting", {})["actor_envs"] = num_envs
     if conf_update:
         deep_dictionary_update(config, conf_update)
-    logger = DirectoryLogger.create_new(log_dir, log_name) if log_dir else NullLogger(echo=True)
-    return train(config, logger)
+    rank, world, local, dp = parallel.init_from_env(backend=backend)
+    device = "cuda"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+        device = torch.device("cuda", torch.cuda.current_device())
+    if dp is not None:
+        config = parallel.shard_config(config, rank, world, scaling)
+    if seed is not None:
+        import random
+        import numpy as np
+        random.seed(seed + rank); np.random.seed(seed + rank); torch.manual_seed(seed + rank)
+    if rank == 0 and log_dir:
+        logger = DirectoryLogger.create_new(log_dir, log_name)
+    else:
+        logger = NullLogger(echo=(rank == 0))
+    try:
+        return train(config, logger, device=device, data_parallel=dp, resume=resume)
+    finally:
+        if dp is not None:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
 
 
 def main():
@@ -72,9 +112,16 @@ def main():
     ap.add_argument("--log-dir")
     ap.add_argument("--log-name")
     ap.add_argument("--conf-update", type=json.loads)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="multi-GPU: strong = mbatch_size / envs / replay size are whole-job values split over "
+                         "the ranks; weak = every rank keeps the configured values")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--resume", default=None, help="directory written by a previous run's checkpoints (true resume)")
+    ap.add_argument("--seed", type=int, default=None)
     a = ap.parse_args()
     logging.basicConfig(level=logging.INFO)
-    train_from_config(a.config, a.num_envs, a.env, a.conf_update, a.log_dir, a.log_name)
+    train_from_config(a.config, a.num_envs, a.env, a.conf_update, a.log_dir, a.log_name,
+                      scaling=a.scaling, backend=a.backend, resume=a.resume, seed=a.seed)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,7 @@ class PolicyTrainer:
         self.target_update_freq = 0
         self.value_log = ValueLog()
         self._gpu_spans = []
+        self.data_parallel = None       # rltime_amd.parallel.DataParallel when one process per GPU
 
     # -- hooks for subclasses ------------------------------------------------
     @staticmethod
@@ -46,6 +47,14 @@ class PolicyTrainer:
         self.policy = make()
         # a separate target network only when a sync period is configured
         self.target_policy = make() if self.target_update_freq else self.policy
+        if self.data_parallel is not None and self.data_parallel.active:
+            # every rank starts from rank 0's two networks (the reference initialises the
+            # target network separately, policy_trainer.py:58-60) and accumulates
+            # gradients straight into one all-reduce bucket
+            self.data_parallel.broadcast_parameters(self.policy)
+            if self.target_policy is not self.policy:
+                self.data_parallel.broadcast_parameters(self.target_policy)
+            self.data_parallel.attach(self.policy)
         self.actors.set_actor_policy(self.policy)
 
     def sync_target(self):

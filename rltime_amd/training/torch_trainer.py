@@ -53,7 +53,11 @@ class TorchTrainer(MultiStepTrainer):
         """torch_trainer.py:177-199.  The norm is one fused device reduction and
         the clip a device-side scale: no host synchronisation per step (the
         reference does ~2 x #parameters `.item()` calls, torch_policy.py:70-78)."""
-        self.optimizer.zero_grad(set_to_none=True)
+        dp = getattr(self, "data_parallel", None)
+        if dp is not None and dp._flat is not None:
+            dp.zero_grad()                  # .grad tensors are views of the all-reduce bucket
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         self._compute_grads(*args, **kwargs)
         self._reduce_gradients()
         params = [p for p in self.policy.parameters() if p.grad is not None]

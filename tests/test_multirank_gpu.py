@@ -1,0 +1,196 @@
+"""GPU: the N>1 path of THE LOOP, executed for real — two ranks, each a full
+trainer process (device actor, its own replay shard, sampling, gather, burn-in,
+IQN targets, forward/backward, gradient all-reduce, clip + Adam, priority
+update), both on cuda:0 over gloo (RCCL refuses two ranks on one device; the
+code path is the one RCCL serves on a multi-GPU node: rltime_amd/parallel.py
+only uses all_reduce / broadcast, which both backends support for device
+tensors).
+
+Checked:
+  (i)  the parameters are bit-identical across the ranks after every learner step
+       (different initial seeds per rank: the broadcast and the gradient bucket
+       must make them so);
+  (ii) the globalised importance weights equal what ONE reference tree over the
+       union of both shards' leaves gives (oracle.sumtree.SumTree built from the
+       leaves read back with mirl_replay_tree_nodes, weights by
+       prioritized_replay_history.py:327,353-354), for every step;
+  (iii) the torchrun entry of rltime_amd.train runs at world 1 with the
+       collectives forced.
+"""
+import copy
+import hashlib
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CNN = {"type": "cnn", "args": {"layers": [{"filters": 8, "kernel": 4, "stride": 2},
+                                          {"filters": 8, "kernel": 3, "stride": 1}]}}
+CONFIG = {
+    "acting": {"actor_envs": 8, "exploration": {"type": "epsilon_greedy", "args": {
+        "eps_start": 1.0, "eps_final": 0.05, "exploration_fraction": 0.5}}},
+    "env": "synthetic-atari", "env_args": {"frame_shape": [2, 20, 20], "n_actions": 4, "done_prob": 0.02},
+    "model": {"type": "sequential", "args": {"layer_configs": [
+        CNN, {"type": "lstm", "args": {"num_units": 16}}, {"type": "fc", "args": {"fc_size": 32}}]}},
+    "policy_args": {"dueling": True, "embedding_dim": 8, "num_sampling_quantiles": 4},
+    "training": {"type": "iqn", "args": {
+        "clip_rewards": False, "vf_scale_epsilon": 1e-3, "gamma": 0.99, "mbatch_size": 8, "nstep_train": 8,
+        "burn_in_timesteps": 4, "nstep_target": 2, "lr": 1e-3, "double_q": True, "rnn_bootstrap": True,
+        "clip_grad": 10.0, "target_update_freq": 96, "total_steps": 10 ** 9, "log_freq": 10 ** 9,
+        "warmup_steps": 0,
+        "history_mode": {"type": "prioritized_replay", "args": {
+            "size": 1200, "train_frequency": 4, "alpha": 0.9, "beta": 0.6, "max_weight_factor": 0.9}}}},
+}
+STEPS = 12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import random
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.general.type_registry import get_registered_type
+    from rltime_amd.parallel import DataParallel, shard_config
+    from rltime_amd.train import create_actors
+    dp = DataParallel()
+    cfg = shard_config(copy.deepcopy(CONFIG), rank, world, "strong")
+    assert cfg["acting"]["actor_envs"] == 4 and cfg["training"]["args"]["mbatch_size"] == 4
+    random.seed(10 + rank); np.random.seed(20 + rank); torch.manual_seed(30 + rank)   # noqa: E702
+    actors = create_actors(cfg, "cuda", device_acting=True)
+    trainer = get_registered_type("trainers", "iqn")(
+        logger=NullLogger(), actors=actors, model_config=cfg["model"], policy_args=cfg["policy_args"])
+    trainer.data_parallel = dp
+    trainer.setup(**cfg["training"]["args"])
+    hist = trainer.history_buffer
+    T = cfg["training"]["args"]["nstep_train"]
+    rec = {"hash": [], "w": [], "slots": [], "leaf_v": [], "leaf_k": [], "active": [], "beta": [], "target_hash": []}
+    inner = trainer._weights
+
+    def tap(extra):
+        w = inner(extra)
+        v, k, _ = hist.tree_nodes()
+        cap = len(v) // 2
+        rec["w"].append(w.reshape(T, -1)[0].double().cpu().numpy())
+        rec["slots"].append(hist.last_sample["slot"].cpu().numpy().astype(np.int64))
+        rec["leaf_v"].append(v[cap:].copy())
+        rec["leaf_k"].append(k[cap:].copy())
+        rec["active"].append(hist.stats()["active_sequences"])
+        rec["beta"].append(hist.last_beta)
+        return w
+    trainer._weights = tap
+
+    def digest(policy):
+        flat = torch.cat([p.detach().reshape(-1) for p in policy.parameters()])
+        return hashlib.sha1(flat.cpu().numpy().tobytes()).hexdigest()
+
+    rec["hash"].append(digest(trainer.policy))            # after the broadcast, before any step
+    rec["target_hash"].append(digest(trainer.target_policy))
+    done, guard = 0, 0
+    while done < STEPS:
+        guard += 1
+        assert guard < 400, "no learner step was reached"
+        if trainer.loop_iteration():
+            done += 1
+            rec["hash"].append(digest(trainer.policy))
+            rec["target_hash"].append(digest(trainer.target_policy))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+             hash=np.array(rec["hash"]), target_hash=np.array(rec["target_hash"]),
+             w=np.stack(rec["w"]), slots=np.stack(rec["slots"]), leaf_v=np.stack(rec["leaf_v"]),
+             leaf_k=np.stack(rec["leaf_k"]), active=np.array(rec["active"]), beta=np.array(rec["beta"]),
+             steps=trainer.steps)
+    hist.close()
+    dist.destroy_process_group()
+
+
+def _kinded(v, k):
+    """(value, kind) as stored on the device -> the scalar object the reference's
+    list-of-scalars tree would hold (csrc/np_emul.h: 0 weak python float, 1 f32, 2 f64)."""
+    if k == 1:
+        return np.float32(v)
+    if k == 2:
+        return np.float64(v)
+    return float(v)
+
+
+def test_two_ranks_full_loop_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle.sumtree import SumTree
+    world = 2
+    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % i)) for i in range(world)]
+    # (i) replicas stay bit-identical (initial broadcast included), and they moved
+    assert list(r[0]["hash"]) == list(r[1]["hash"])
+    assert list(r[0]["target_hash"]) == list(r[1]["target_hash"])
+    assert len(set(r[0]["hash"])) == STEPS + 1
+    assert len(set(r[0]["target_hash"])) > 1                      # the target sync fired on both
+    assert int(r[0]["steps"]) == int(r[1]["steps"])
+    # (ii) importance weights == one reference tree over the union of the shards
+    assert r[0]["w"].shape[0] == STEPS
+    worst = 0.0
+    for s in range(STEPS):
+        n0 = r[0]["leaf_v"][s].shape[0]
+        leaves = [_kinded(v, k) for i in range(world) for v, k in zip(r[i]["leaf_v"][s], r[i]["leaf_k"][s])]
+        cap = 1
+        while cap < len(leaves):
+            cap *= 2
+        tree = SumTree(cap)
+        for j, x in enumerate(leaves):
+            if x != 0:
+                tree.set_leaf(j, x)
+        p_sum = tree.total()
+        active = int(r[0]["active"][s] + r[1]["active"][s])
+        beta = float(r[0]["beta"][s])
+        assert beta == float(r[1]["beta"][s])
+        raw = [np.array([((tree.leaf(int(sl) + i * n0) / p_sum) * active) ** (-beta) for sl in r[i]["slots"][s]],
+                        dtype=np.float64) for i in range(world)]
+        top = max(x.max() for x in raw)
+        for i in range(world):
+            want = raw[i] / top
+            np.testing.assert_allclose(r[i]["w"][s], want, rtol=5e-6, atol=0)
+            worst = max(worst, float(np.max(np.abs(r[i]["w"][s] - want) / want)))
+        assert max(r[0]["w"][s].max(), r[1]["w"][s].max()) == pytest.approx(1.0, rel=1e-6)
+    print("max rel deviation of globalised weights vs union-tree oracle: %.2e" % worst)
+
+
+def test_train_entry_under_torchrun_world1_forced_collectives(tmp_path):
+    """`python -m torch.distributed.run ... -m rltime_amd.train` (the product entry,
+    not bench.py): process-group init, config sharding, parameter broadcast,
+    bucketed gradient all-reduce and the importance-weight exchange all execute
+    (BENCH_FORCE_DIST=1 keeps them on at world 1; gloo so that it also runs next
+    to another process on the same GPU)."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", PYTHONPATH=ROOT)
+    upd = {"acting": {"actor_envs": 8},
+           "env_args": {"frame_shape": [2, 20, 20], "n_actions": 4},
+           "model": CONFIG["model"], "policy_args": CONFIG["policy_args"],
+           "training": {"args": dict(CONFIG["training"]["args"], total_steps=600, log_freq=200, warmup_steps=100,
+                                     lr_anneal=False)}}
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "-m", "rltime_amd.train", "synthetic_atari_iqn_lstm.json", "--backend", "gloo", "--seed", "3",
+           "--log-dir", str(tmp_path), "--log-name", "run", "--conf-update", json.dumps(upd)]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    rows = [json.loads(line) for line in open(tmp_path / "run" / "train.json")]
+    assert rows and rows[-1]["this_interval"]["steps_trained"] > 0

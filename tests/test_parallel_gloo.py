@@ -26,15 +26,23 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from rltime_amd.parallel import DataParallel
     dp = DataParallel()
-    # 1. gradient bucket
-    torch.manual_seed(0)
+    # 1. parameter broadcast + gradient bucket (the .grad tensors are views of it)
+    torch.manual_seed(rank)                                   # ranks start from different weights
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    dp.broadcast_parameters(net)
+    start = [p.detach().clone() for p in net.parameters()]
+    flat = dp.attach(net)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(11, 5, generator=g)
-    net(x).pow(2).mean().backward()
+    for _ in range(2):                                        # second pass: zero_grad keeps the views alive
+        dp.zero_grad()
+        net(x).pow(2).mean().backward()
+    assert all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in net.parameters())
     local = [p.grad.clone() for p in net.parameters()]
     dp.all_reduce_gradients(net)
     reduced = [p.grad.clone() for p in net.parameters()]
+    # 3. lock-step guard: ready only when every rank is
+    guard = (dp.all_ready(True), dp.all_ready(rank == 0), dp.all_ready(False))
     # 2. importance weights: every rank holds a shard of priorities, samples some
     beta = 0.6
     rs = np.random.RandomState(7)
@@ -48,7 +56,7 @@ def _worker(rank, world, port, out):
     P_g, N_g = prios[0].sum() + prios[1].sum(), 65
     raw_all = np.concatenate([(prios[r][picks[r]] / P_g * N_g) ** (-beta) for r in range(2)])
     want = (prios[rank][pk] / P_g * N_g) ** (-beta) / raw_all.max()
-    out[rank] = dict(local=local, reduced=reduced, w=w.numpy(), want=want)
+    out[rank] = dict(local=local, reduced=reduced, w=w.numpy(), want=want, start=start, guard=guard)
     dist.destroy_process_group()
 
 
@@ -59,6 +67,9 @@ def test_two_rank_exchange():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
+    for a, b in zip(r0["start"], r1["start"]):
+        assert torch.equal(a, b)                              # rank 0's weights everywhere
+    assert r0["guard"] == r1["guard"] == (True, False, False)
     for a, b, m0, m1 in zip(r0["local"], r1["local"], r0["reduced"], r1["reduced"]):
         assert torch.allclose(m0, (a + b) / 2, atol=1e-7)
         assert torch.equal(m0, m1)
@@ -71,8 +82,16 @@ def test_shard_config():
     from rltime_amd.general.config import load_config
     from rltime_amd.parallel import shard_config
     cfg = load_config("synthetic_atari_iqn_lstm.json")
-    shards = [shard_config(cfg, r, 8) for r in range(8)]
+    shards = [shard_config(cfg, r, 8) for r in range(8)]          # strong: whole-job values split
     assert [s["acting"]["actor_envs"] for s in shards] == [32] * 8
     assert [s["acting"]["env_base"] for s in shards] == [32 * r for r in range(8)]
+    assert [s["acting"]["total_envs"] for s in shards] == [256] * 8
     assert shards[3]["training"]["args"]["history_mode"]["args"]["size"] == 125000
+    assert shards[3]["training"]["args"]["mbatch_size"] == 64       # global B=512
     assert cfg["acting"]["actor_envs"] == 256       # input untouched
+    weak = [shard_config(cfg, r, 4, "weak") for r in range(4)]     # weak: every rank keeps the configured job
+    assert [s["acting"]["actor_envs"] for s in weak] == [256] * 4
+    assert [s["acting"]["env_base"] for s in weak] == [0, 256, 512, 768]
+    assert weak[1]["acting"]["total_envs"] == 1024
+    assert weak[2]["training"]["args"]["mbatch_size"] == 512
+    assert weak[2]["training"]["args"]["history_mode"]["args"]["size"] == 1000000
