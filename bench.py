@@ -285,7 +285,20 @@ def cpu_baseline(args, seconds):
 
     learner_step(2)                                           # untimed warm-up (allocator, MKL)
     one_s, one_b, one_spent = leg(1, [(4, 1), (16, 1)], seconds * 0.6)
-    all_s, all_b, all_spent = leg(nproc, [(32, 1)], seconds * 0.4)
+    # "all cores": torch intra-op threads capped at 32 — the LSTMCell time loop is a chain of
+    # small GEMMs; with one thread per logical core of a 256-core host the same step measured
+    # 33x SLOWER than 1 thread (profiles/README.md, round 2).  B=4 first; B=16 only if the
+    # threads actually help, so a pathological setting cannot eat minutes of the budget.
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = nproc
+    many = max(2, min(usable, 32))
+    all_s, all_b, all_spent = leg(many, [(4, 1)], seconds * 0.2)
+    if all_b[4][0] < one_b[4][0]:
+        s2, b2, sp2 = leg(many, [(16, 1)], seconds * 0.2)
+        all_s, all_spent = s2, all_spent + sp2
+        all_b.update(b2)
     torch.set_num_threads(1)
     # acting share (actor.py:108-147): policy forward on a 32-env vector step, 1 thread
     EA = 32
@@ -304,10 +317,10 @@ def cpu_baseline(args, seconds):
         "value": B_full * T / (one_s + extra), "unit": "transitions/s", "cores": 1, "kind": "port",
         "learner_steps_per_sec": 1.0 / (one_s + extra),
         "host_nproc": nproc,
-        "all_cores": {"value": B_full * T / (all_s + extra), "unit": "transitions/s", "cores": nproc,
+        "all_cores": {"value": B_full * T / (all_s + extra), "unit": "transitions/s", "cores": many, "usable_cores": usable,
                       "learner_steps_per_sec": 1.0 / (all_s + extra),
                       "sample": "same oracle path with torch.set_num_threads(%d): %s, scaled x%d to B=512; acting/ingest shares as in the 1-thread leg"
-                                % (nproc, fmt(all_b), B_full // max(all_b))},
+                                % (many, fmt(all_b), B_full // max(all_b))},
         "sample": "oracle (reference algorithm restated, config D: T=80, burn-in 40, n=2, torch-CPU fp32, 1 thread like the "
                   "reference's torch.set_num_threads(1)): %s; the largest B scaled linearly x%d to B=512 (%.1f s of CPU work); "
                   "+ acting %.0f and ingest %.0f transitions/s for the step's %d acted transitions; host has %d logical cores"

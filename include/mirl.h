@@ -277,6 +277,37 @@ int mirl_lstm_cell_bwd(int32_t B, int32_t H, float* gates, const float* c_t, con
  * [N][C][HW] -> dst float32 [N][HW][C] = src * scale, one pass.                  */
 int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale,
                             float* dst, void* stream);
+/* the same with explicit launch shape (tuning probe): per_wg = 1024-pixel tiles per
+ * workgroup (0 = heuristic), flags bit 0 = cached loads, bit 1 = cached stores
+ * (default: non-temporal both ways).                                              */
+int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale,
+                               float* dst, int32_t per_wg, int32_t flags, void* stream);
+
+/* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
+ * All tensors row-major (rows, C), channel / feature index fastest (NHWC
+ * activations, (M, features) matrices).  One HBM pass each; column sums are
+ * two-stage and deterministic.
+ *
+ * y <- relu(y + bias) in place: the `F.relu(conv(x))` epilogue of
+ * rltime/models/torch/modules/cnn.py:47-49 after a bias-less convolution.        */
+int mirl_bias_relu_rows(int64_t rows, int32_t C, float* y, const float* bias, void* stream);
+/* number of partial-sum blocks the two-stage column sums use for `rows` rows
+ * (the caller allocates partial[blocks][C])                                        */
+int mirl_colsum_blocks(int64_t rows, int32_t C, int32_t* blocks);
+/* backward of relu(. + bias): g = dy * (y > 0) and db[c] = sum_r g[r][c] in one read
+ * of dy and y.  C = 4 * 2^k <= 1024.                                               */
+int mirl_relu_bwd_bias_rows(int64_t rows, int32_t C, const float* dy, const float* y, float* g,
+                            float* db, float* partial, int32_t blocks, void* stream);
+/* IQN cosine embedding (rltime/policies/torch/iqn.py:78-81): phi[r][i] =
+ * cos(tau[r] * freq[i]), freq = embedding_range * pi (float32), D % 4 == 0.       */
+int mirl_cos_embed(int64_t rows, int32_t D, const float* tau, const float* freq, float* phi, void* stream);
+/* IQN feature product (iqn.py:84,102): out[m*N+n][c] = x[m][c] * emb[m*N+n][c].   */
+int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const float* emb, float* out, void* stream);
+/* its backward fused with the ReLU mask and bias gradient of the embedding layer
+ * (emb = relu(pre)):  d_pre = emb > 0 ? g * x[m] : 0,  dx[m] = sum_n g * emb,
+ * db[c] = sum_r d_pre[r][c].                                                       */
+int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g, const float* emb, const float* x,
+                     float* d_pre, float* dx, float* db, float* partial, int32_t blocks, void* stream);
 
 /* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
 int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);

@@ -31,6 +31,7 @@ typedef float cv_f32x4 __attribute__((ext_vector_type(4)));
 // One workgroup walks `per_wg` consecutive tiles of one frame.  The tile lives in
 // a double-buffered LDS slab (one barrier per tile) and the next tile's 16 B are
 // already in flight in a register while the current one is stored.
+template <int NTL, int NTS>
 __global__ void __launch_bounds__(256)
 k_frames_to_f32_nhwc4(int64_t N, int HW, int tiles, int per_wg, const uint8_t* __restrict__ src, float scale,
                       float* __restrict__ dst) {
@@ -43,16 +44,20 @@ k_frames_to_f32_nhwc4(int64_t N, int HW, int tiles, int per_wg, const uint8_t* _
   const int plane = tid >> 6, chunk = tid & 63;
   const uint8_t* g_plane = src + (n * 4 + plane) * (int64_t)HW;
   cv_u32x4 cur = {0u, 0u, 0u, 0u};
-  if (t0 * MIRL_CV_TILE + chunk * 16 < HW)
-    cur = __builtin_nontemporal_load((const cv_u32x4*)(g_plane + t0 * MIRL_CV_TILE) + chunk);
+  if (t0 * MIRL_CV_TILE + chunk * 16 < HW) {
+    const cv_u32x4* p = (const cv_u32x4*)(g_plane + t0 * MIRL_CV_TILE) + chunk;
+    cur = NTL ? __builtin_nontemporal_load(p) : *p;
+  }
   for (int t = t0; t < t1; ++t) {
     const int p_tile = t * MIRL_CV_TILE;
     const int left = HW - p_tile;                     // pixels of this tile (multiple of 16)
     cv_u32x4* slab = s_tile[t & 1];
     slab[plane * 64 + chunk] = cur;
     __syncthreads();
-    if (t + 1 < t1 && p_tile + MIRL_CV_TILE + chunk * 16 < HW)
-      cur = __builtin_nontemporal_load((const cv_u32x4*)(g_plane + p_tile + MIRL_CV_TILE) + chunk);
+    if (t + 1 < t1 && p_tile + MIRL_CV_TILE + chunk * 16 < HW) {
+      const cv_u32x4* p = (const cv_u32x4*)(g_plane + p_tile + MIRL_CV_TILE) + chunk;
+      cur = NTL ? __builtin_nontemporal_load(p) : *p;
+    }
     const uint8_t* sb = (const uint8_t*)slab;
     cv_f32x4* out = (cv_f32x4*)(dst + (n * (int64_t)HW + p_tile) * 4);
 #pragma unroll
@@ -64,7 +69,7 @@ k_frames_to_f32_nhwc4(int64_t N, int HW, int tiles, int per_wg, const uint8_t* _
         v.y = (float)sb[MIRL_CV_TILE + pix] * scale;
         v.z = (float)sb[2 * MIRL_CV_TILE + pix] * scale;
         v.w = (float)sb[3 * MIRL_CV_TILE + pix] * scale;
-        __builtin_nontemporal_store(v, out + pix);
+        if (NTS) __builtin_nontemporal_store(v, out + pix); else out[pix] = v;
       }
     }
   }
@@ -86,24 +91,39 @@ k_frames_to_f32_nhwc_any(int64_t N, int C, int HW, const uint8_t* __restrict__ s
 }
 }  // namespace mirl
 
-extern "C" int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale, float* dst, void* stream) {
+// per_wg: tiles per workgroup (0 = heuristic); flags bit 0: plain (cached) loads,
+// bit 1: plain stores instead of non-temporal ones (tools/convert_probe.py sweeps them).
+extern "C" int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale, float* dst,
+                                          int32_t per_wg, int32_t flags, void* stream) {
   if (N <= 0 || C <= 0 || HW <= 0 || !src || !dst) return mirl::fail(MIRL_ERR_ARG, "bad frames_to_f32_nhwc arguments");
-  mirl::ProfScope ps("k_frames_to_f32_nhwc", (double)N * C * HW * 5.0, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  mirl::ProfScope ps("k_frames_to_f32_nhwc", (double)N * C * HW * 5.0, st);
   if (C == 4 && (HW % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
     const int tiles = (HW + MIRL_CV_TILE - 1) / MIRL_CV_TILE;
     // few frames (the acting step): one tile per workgroup to fill the chip;
     // a learner batch: one workgroup per frame, the tile loop hides the latency
-    static const int forced = getenv("MIRL_CONVERT_PER_WG") ? atoi(getenv("MIRL_CONVERT_PER_WG")) : 0;
-    int per_wg = forced > 0 ? forced : (N * tiles < 16384 ? 1 : tiles);
+    if (per_wg <= 0) per_wg = N * tiles < 16384 ? 1 : tiles;
     if (per_wg > tiles) per_wg = tiles;
     const int64_t blocks = N * ((tiles + per_wg - 1) / per_wg);
     if (blocks >= (1LL << 31)) return mirl::fail(MIRL_ERR_ARG, "frames_to_f32_nhwc: too many frames for one launch");
-    hipLaunchKernelGGL(mirl::k_frames_to_f32_nhwc4, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, N, (int)HW, tiles, per_wg, src, scale, dst);
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (flags & 3) {
+      case 0: hipLaunchKernelGGL((mirl::k_frames_to_f32_nhwc4<1, 1>), grid, block, 0, st, N, (int)HW, tiles, (int)per_wg, src, scale, dst); break;
+      case 1: hipLaunchKernelGGL((mirl::k_frames_to_f32_nhwc4<0, 1>), grid, block, 0, st, N, (int)HW, tiles, (int)per_wg, src, scale, dst); break;
+      case 2: hipLaunchKernelGGL((mirl::k_frames_to_f32_nhwc4<1, 0>), grid, block, 0, st, N, (int)HW, tiles, (int)per_wg, src, scale, dst); break;
+      default: hipLaunchKernelGGL((mirl::k_frames_to_f32_nhwc4<0, 0>), grid, block, 0, st, N, (int)HW, tiles, (int)per_wg, src, scale, dst); break;
+    }
   } else {
     const int64_t n = N * HW;
     if ((n + 255) / 256 >= (1LL << 31)) return mirl::fail(MIRL_ERR_ARG, "frames_to_f32_nhwc: too many pixels for one launch");
-    hipLaunchKernelGGL(mirl::k_frames_to_f32_nhwc_any, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, (int)C, (int)HW, src, scale, dst);
+    hipLaunchKernelGGL(mirl::k_frames_to_f32_nhwc_any, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, N, (int)C, (int)HW, src, scale, dst);
   }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
+}
+
+extern "C" int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale, float* dst, void* stream) {
+  static const int per_wg = getenv("MIRL_CONVERT_PER_WG") ? atoi(getenv("MIRL_CONVERT_PER_WG")) : 0;
+  static const int flags = getenv("MIRL_CONVERT_FLAGS") ? atoi(getenv("MIRL_CONVERT_FLAGS")) : 0;
+  return mirl_frames_to_f32_nhwc_ex(N, C, HW, src, scale, dst, per_wg, flags, stream);
 }

@@ -1,0 +1,302 @@
+// nnops.hip — the non-contraction glue around the network's GEMMs / convolutions.
+//
+// The dense contractions of the policy (conv, LSTM, linear) stay on
+// MIOpen / hipBLASLt (MFMA); what surrounds them in the reference
+// (rltime/models/torch/modules/cnn.py:47-49 `F.relu(conv(x))`,
+// rltime/policies/torch/iqn.py:67-106 cos-embedding * state features, the
+// autograd passes PyTorch generates for them) is pure streaming work over
+// multi-GB activations, one HBM pass per PyTorch op.  These kernels do each
+// group in ONE pass:
+//   k_bias_relu_rows       y <- relu(y + b)            in place, after a bias-less conv / GEMM
+//   k_relu_bwd_bias_rows   g = dy * (y > 0), db += colsum(g)     (mask + bias-gradient in one read)
+//   k_cos_embed            phi[r][i] = cos(tau[r] * (i+1) pi)    (iqn.py:78-81)
+//   k_iqn_mul_bwd          backward of  out = x[m] * relu_emb[m*N+n]  fused with the ReLU mask
+//                          of the embedding layer and its bias gradient
+// All tensors are viewed as row-major (rows, C) with the channel / feature index
+// fastest (NHWC activations, (M, features) matrices); every global access is
+// 16 B per lane on a linear address stream.  Column sums are two-stage and
+// deterministic (fixed partition, fixed order — no float atomics), so repeated
+// runs give bit-identical gradients.
+#include "common.hpp"
+
+namespace mirl {
+
+typedef float nn_f4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+k_bias_relu_rows(nn_f4* __restrict__ y, const nn_f4* __restrict__ bias, int64_t n4, int CQ) {
+  // 4 quads per lane, all loads before the first store
+  int64_t i = ((int64_t)blockIdx.x * 256 * 4) + threadIdx.x;
+  nn_f4 v[4]; bool h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { h[k] = i + k * 256 < n4; if (h[k]) v[k] = y[i + k * 256]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!h[k]) continue;
+    const int64_t q = i + k * 256;
+    nn_f4 b = bias[(CQ & (CQ - 1)) ? (int)(q % CQ) : (int)(q & (CQ - 1))];   // C/4 is a power of two for every shipped model
+    nn_f4 r = v[k] + b;
+    r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+    y[i + k * 256] = r;
+  }
+}
+
+// generic C (not a multiple of 4): scalar
+__global__ void __launch_bounds__(256)
+k_bias_relu_rows_any(float* __restrict__ y, const float* __restrict__ bias, int64_t n, int C) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = y[i] + bias[i % C];
+  y[i] = r > 0.f ? r : 0.f;
+}
+
+// Block b streams rows [b*rpb, (b+1)*rpb): the linear quad index advances by 256
+// per iteration and 256 % CQ == 0, so a lane keeps its column quad for the whole
+// sweep and accumulates its column sums in registers.
+__global__ void __launch_bounds__(256)
+k_relu_bwd_bias_rows(const nn_f4* __restrict__ dy, const nn_f4* __restrict__ y, nn_f4* __restrict__ g,
+                     nn_f4* __restrict__ partial, int64_t rows, int CQ, int64_t rpb) {
+  __shared__ nn_f4 s_acc[256];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  const int64_t lo = r0 * CQ, hi = r1 * CQ;
+  nn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t i = lo + tid;
+  for (; i + 768 < hi; i += 1024) {
+    nn_f4 a0 = dy[i], a1 = dy[i + 256], a2 = dy[i + 512], a3 = dy[i + 768];
+    nn_f4 b0 = y[i], b1 = y[i + 256], b2 = y[i + 512], b3 = y[i + 768];
+#define MIRL_MASK(a, b) a.x = b.x > 0.f ? a.x : 0.f; a.y = b.y > 0.f ? a.y : 0.f; a.z = b.z > 0.f ? a.z : 0.f; a.w = b.w > 0.f ? a.w : 0.f;
+    MIRL_MASK(a0, b0) MIRL_MASK(a1, b1) MIRL_MASK(a2, b2) MIRL_MASK(a3, b3)
+    g[i] = a0; g[i + 256] = a1; g[i + 512] = a2; g[i + 768] = a3;
+    acc = acc + a0; acc = acc + a1; acc = acc + a2; acc = acc + a3;
+  }
+  for (; i < hi; i += 256) {
+    nn_f4 a0 = dy[i], b0 = y[i];
+    MIRL_MASK(a0, b0)
+    g[i] = a0;
+    acc = acc + a0;
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < CQ) {
+    nn_f4 t = s_acc[tid];
+    for (int k = tid + CQ; k < 256; k += CQ) t = t + s_acc[k];
+    partial[(int64_t)blockIdx.x * CQ + tid] = t;
+  }
+}
+
+// db[c] = sum over blocks, fixed order
+__global__ void __launch_bounds__(256)
+k_colsum_partials(const float* __restrict__ partial, float* __restrict__ out, int blocks, int C) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s = s + partial[(int64_t)b * C + c];
+  out[c] = s;
+}
+
+// phi[r][i] = cos(tau[r] * w[i]),  w[i] = (i+1) * pi rounded to f32 (the
+// `embedding_range * np.pi` tensor of iqn.py:78).  One lane per 4 features.
+__global__ void __launch_bounds__(256)
+k_cos_embed(const float* __restrict__ tau, const nn_f4* __restrict__ w, nn_f4* __restrict__ phi, int64_t n4, int DQ) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float t = tau[i / DQ];
+  const nn_f4 ww = w[i % DQ];
+  nn_f4 r;
+  r.x = cosf(ww.x * t); r.y = cosf(ww.y * t); r.z = cosf(ww.z * t); r.w = cosf(ww.w * t);
+  phi[i] = r;
+}
+
+// out[(m*N+n)][c] = x[m][c] * emb[(m*N+n)][c]   (iqn.py:84,102 without the repeated copy of x).
+// Same walk as the backward below: a workgroup takes whole groups m, lane (rl, cq)
+// rows n = rl, rl + RL, ... of the group, so x[m] is read once per lane and no
+// index division is needed.
+__global__ void __launch_bounds__(256)
+k_iqn_mul_fwd(const nn_f4* __restrict__ x, const nn_f4* __restrict__ emb, nn_f4* __restrict__ out,
+              int64_t M, int N, int CQ, int64_t gpb) {
+  const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
+  const int64_t m0 = (int64_t)blockIdx.x * gpb;
+  int64_t m1 = m0 + gpb; if (m1 > M) m1 = M;
+  const int64_t st = (int64_t)RL * CQ;
+  for (int64_t m = m0; m < m1; ++m) {
+    const nn_f4 xv = x[m * CQ + cq];
+    const int64_t base = m * N * (int64_t)CQ + cq;
+    int n = rl;
+    for (; n + 3 * RL < N; n += 4 * RL) {
+      const int64_t i0 = base + (int64_t)n * CQ;
+      nn_f4 e0 = emb[i0], e1 = emb[i0 + st], e2 = emb[i0 + 2 * st], e3 = emb[i0 + 3 * st];
+      out[i0] = e0 * xv; out[i0 + st] = e1 * xv; out[i0 + 2 * st] = e2 * xv; out[i0 + 3 * st] = e3 * xv;
+    }
+    for (; n < N; n += RL) { const int64_t i0 = base + (int64_t)n * CQ; out[i0] = emb[i0] * xv; }
+  }
+}
+
+// Backward of the product above fused with the ReLU mask of the embedding layer
+// (emb = relu(pre)) and its bias gradient.  One workgroup walks whole groups m
+// (the N quantile rows of one state, contiguous): lane (rl, cq) takes rows
+// n = rl, rl + RL, ... of the group for column quad cq.
+//   d_pre[r][c] = emb[r][c] > 0 ? g[r][c] * x[m][c] : 0
+//   dx[m][c]    = sum_n g[r][c] * emb[r][c]          (fixed order: lanes, then LDS)
+//   partial[b]  = column sums of d_pre over the block's groups
+__global__ void __launch_bounds__(256)
+k_iqn_mul_bwd(const nn_f4* __restrict__ g, const nn_f4* __restrict__ emb, const nn_f4* __restrict__ x,
+              nn_f4* __restrict__ d_pre, nn_f4* __restrict__ dx, nn_f4* __restrict__ partial,
+              int64_t M, int N, int CQ, int64_t gpb) {
+  __shared__ nn_f4 s_dx[256];
+  __shared__ nn_f4 s_db[256];
+  const int tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
+  const int64_t m0 = (int64_t)blockIdx.x * gpb;
+  int64_t m1 = m0 + gpb; if (m1 > M) m1 = M;
+  nn_f4 db = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t m = m0; m < m1; ++m) {
+    const nn_f4 xv = x[m * CQ + cq];
+    nn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int64_t base = m * N * (int64_t)CQ + cq;
+    int n = rl;
+    for (; n + 3 * RL < N; n += 4 * RL) {
+      const int64_t i0 = base + (int64_t)n * CQ, st = (int64_t)RL * CQ;
+      nn_f4 g0 = g[i0], g1 = g[i0 + st], g2 = g[i0 + 2 * st], g3 = g[i0 + 3 * st];
+      nn_f4 e0 = emb[i0], e1 = emb[i0 + st], e2 = emb[i0 + 2 * st], e3 = emb[i0 + 3 * st];
+      acc = acc + g0 * e0; acc = acc + g1 * e1; acc = acc + g2 * e2; acc = acc + g3 * e3;
+      nn_f4 p0 = g0 * xv, p1 = g1 * xv, p2 = g2 * xv, p3 = g3 * xv;
+      MIRL_MASK(p0, e0) MIRL_MASK(p1, e1) MIRL_MASK(p2, e2) MIRL_MASK(p3, e3)
+      d_pre[i0] = p0; d_pre[i0 + st] = p1; d_pre[i0 + 2 * st] = p2; d_pre[i0 + 3 * st] = p3;
+      db = db + p0; db = db + p1; db = db + p2; db = db + p3;
+    }
+    for (; n < N; n += RL) {
+      const int64_t i0 = base + (int64_t)n * CQ;
+      nn_f4 g0 = g[i0], e0 = emb[i0];
+      acc = acc + g0 * e0;
+      nn_f4 p0 = g0 * xv;
+      MIRL_MASK(p0, e0)
+      d_pre[i0] = p0;
+      db = db + p0;
+    }
+    if (RL > 1) {
+      __syncthreads();                       // previous group's readers are done
+      s_dx[tid] = acc;
+      __syncthreads();
+      if (rl == 0) {
+        nn_f4 t = s_dx[cq];
+        for (int k = 1; k < RL; ++k) t = t + s_dx[k * CQ + cq];
+        dx[m * CQ + cq] = t;
+      }
+    } else {
+      dx[m * CQ + cq] = acc;
+    }
+  }
+  __syncthreads();
+  s_db[tid] = db;
+  __syncthreads();
+  if (rl == 0) {
+    nn_f4 t = s_db[cq];
+    for (int k = 1; k < RL; ++k) t = t + s_db[k * CQ + cq];
+    partial[(int64_t)blockIdx.x * CQ + cq] = t;
+  }
+}
+
+static inline bool pow2_quads(int C) { int cq = C / 4; return (C % 4) == 0 && cq >= 1 && cq <= 256 && (256 % cq) == 0; }
+static inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+}  // namespace mirl
+
+using namespace mirl;
+
+extern "C" int mirl_bias_relu_rows(int64_t rows, int32_t C, float* y, const float* bias, void* stream) {
+  if (rows <= 0 || C <= 0 || !y || !bias) return fail(MIRL_ERR_ARG, "bad bias_relu_rows arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = rows * C;
+  ProfScope ps("k_bias_relu_rows", 2.0 * n * 4, st);
+  if ((C % 4) == 0 && aligned16(y) && aligned16(bias)) {
+    const int64_t n4 = n / 4, blocks = (n4 + 1023) / 1024;
+    if (blocks >= (1LL << 31)) return fail(MIRL_ERR_ARG, "bias_relu_rows: tensor too large for one launch");
+    hipLaunchKernelGGL(k_bias_relu_rows, dim3((unsigned)blocks), dim3(256), 0, st, (nn_f4*)y, (const nn_f4*)bias, n4, C / 4);
+  } else {
+    const int64_t blocks = (n + 255) / 256;
+    if (blocks >= (1LL << 31)) return fail(MIRL_ERR_ARG, "bias_relu_rows: tensor too large for one launch");
+    hipLaunchKernelGGL(k_bias_relu_rows_any, dim3((unsigned)blocks), dim3(256), 0, st, y, bias, n, (int)C);
+  }
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_colsum_blocks(int64_t rows, int32_t C, int32_t* blocks) {
+  if (!blocks) return fail(MIRL_ERR_ARG, "null argument");
+  // enough workgroups to fill 256 CUs several times over, each with >= 64 rows
+  int64_t b = (rows + 63) / 64;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  *blocks = (int32_t)b;
+  (void)C;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_relu_bwd_bias_rows(int64_t rows, int32_t C, const float* dy, const float* y, float* g, float* db,
+                                       float* partial, int32_t blocks, void* stream) {
+  if (rows <= 0 || C <= 0 || !dy || !y || !g || !db || !partial || blocks <= 0) return fail(MIRL_ERR_ARG, "bad relu_bwd_bias_rows arguments");
+  if (!pow2_quads(C) || !aligned16(dy) || !aligned16(y) || !aligned16(g) || !aligned16(partial))
+    return fail(MIRL_ERR_ARG, "relu_bwd_bias_rows: C must be 4 * a power of two <= 1024 and pointers 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rpb = (rows + blocks - 1) / blocks;
+  {
+    ProfScope ps("k_relu_bwd_bias_rows", 3.0 * rows * C * 4, st);
+    hipLaunchKernelGGL(k_relu_bwd_bias_rows, dim3((unsigned)blocks), dim3(256), 0, st, (const nn_f4*)dy, (const nn_f4*)y, (nn_f4*)g,
+                       (nn_f4*)partial, rows, C / 4, rpb);
+  }
+  MIRL_LAUNCH_CHECK();
+  {
+    ProfScope ps("k_colsum_partials", (double)blocks * C * 4, st);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
+  }
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_cos_embed(int64_t rows, int32_t D, const float* tau, const float* freq, float* phi, void* stream) {
+  if (rows <= 0 || D <= 0 || (D % 4) || !tau || !freq || !phi || !aligned16(freq) || !aligned16(phi))
+    return fail(MIRL_ERR_ARG, "bad cos_embed arguments (embedding_dim must be a multiple of 4)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n4 = rows * (D / 4), blocks = (n4 + 255) / 256;
+  if (blocks >= (1LL << 31)) return fail(MIRL_ERR_ARG, "cos_embed: tensor too large for one launch");
+  ProfScope ps("k_cos_embed", (double)rows * (D * 4 + 4), st);
+  hipLaunchKernelGGL(k_cos_embed, dim3((unsigned)blocks), dim3(256), 0, st, tau, (const nn_f4*)freq, (nn_f4*)phi, n4, D / 4);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const float* emb, float* out, void* stream) {
+  if (M <= 0 || N <= 0 || C <= 0 || !x || !emb || !out) return fail(MIRL_ERR_ARG, "bad iqn_mul_fwd arguments");
+  if (!pow2_quads(C) || !aligned16(x) || !aligned16(emb) || !aligned16(out))
+    return fail(MIRL_ERR_ARG, "iqn_mul_fwd: C must be 4 * a power of two <= 1024 and pointers 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = M < 4096 ? M : 4096;
+  const int64_t gpb = (M + blocks - 1) / blocks;
+  ProfScope ps("k_iqn_mul_fwd", (2.0 * M * N + M) * C * 4, st);
+  hipLaunchKernelGGL(k_iqn_mul_fwd, dim3((unsigned)blocks), dim3(256), 0, st, (const nn_f4*)x, (const nn_f4*)emb, (nn_f4*)out, M, (int)N, C / 4, gpb);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g, const float* emb, const float* x,
+                                float* d_pre, float* dx, float* db, float* partial, int32_t blocks, void* stream) {
+  if (M <= 0 || N <= 0 || C <= 0 || !g || !emb || !x || !d_pre || !dx || !db || !partial || blocks <= 0)
+    return fail(MIRL_ERR_ARG, "bad iqn_mul_bwd arguments");
+  if (!pow2_quads(C) || !aligned16(g) || !aligned16(emb) || !aligned16(x) || !aligned16(d_pre) || !aligned16(dx) || !aligned16(partial))
+    return fail(MIRL_ERR_ARG, "iqn_mul_bwd: C must be 4 * a power of two <= 1024 and pointers 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t gpb = (M + blocks - 1) / blocks;
+  {
+    ProfScope ps("k_iqn_mul_bwd", (3.0 * M * N + 2.0 * M) * C * 4, st);
+    hipLaunchKernelGGL(k_iqn_mul_bwd, dim3((unsigned)blocks), dim3(256), 0, st, (const nn_f4*)g, (const nn_f4*)emb, (const nn_f4*)x,
+                       (nn_f4*)d_pre, (nn_f4*)dx, (nn_f4*)partial, M, (int)N, C / 4, gpb);
+  }
+  MIRL_LAUNCH_CHECK();
+  {
+    ProfScope ps("k_colsum_partials", (double)blocks * C * 4, st);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
+  }
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}

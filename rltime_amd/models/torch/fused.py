@@ -1,12 +1,67 @@
-"""Linear + ReLU with the activation in the GEMM epilogue (hipBLASLt) on the GPU.
+"""Fused network glue on the GPU (csrc/nnops.hip + hipBLASLt epilogues).
 
-`relu(x @ W^T + b)` over the IQN head's 1.3 M-row activations is one GEMM plus a
-full extra read+write pass for the ReLU in stock PyTorch.  `torch._addmm_activation`
-runs bias + ReLU inside the hipBLASLt epilogue; it has no autograd formula, so the
-backward is spelled out here (mask by the saved output, two GEMMs, one bias
-reduction) — the same math as autograd's linear + relu."""
+The contractions stay on MIOpen / hipBLASLt; these autograd functions replace
+the streaming PyTorch ops around them — each of which is a full HBM pass over a
+multi-GB activation at the benchmark shapes — by single-pass HIP kernels, with
+the backward spelled out (the same math autograd derives for the plain
+expressions; parity tests in tests/test_fused_gpu.py compare against those):
+
+  linear_relu        relu(x @ W^T + b): ReLU in the GEMM epilogue; backward = one
+                     mask + bias-gradient pass, two GEMMs
+  conv_bias_relu     relu(conv2d(x, W) + b) (cnn.py:47-49): bias-less MIOpen conv,
+                     one in-place bias+ReLU pass; backward = one mask + bias-gradient
+                     pass, MIOpen data / weight gradients
+  cos_embed          IQN cosine features (iqn.py:78-81) in one kernel
+  quantile_product   x[m] * relu(phi @ Wq^T + bq)[m, n] (iqn.py:82-102) with a
+                     backward that never materialises g*x / g*emb / the mask
+"""
+import ctypes as C
+
 import torch
 import torch.nn.functional as F
+
+
+def _lib():
+    from rltime_amd import _lib as L
+    return L
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pow2_quads(c):
+    q = c // 4
+    return c % 4 == 0 and 1 <= q <= 256 and 256 % q == 0
+
+
+def _fusable(*tensors):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors) and not torch.is_autocast_enabled()
+
+
+def bias_relu_rows_(y, bias, channels):
+    """y viewed as (rows, channels) row-major <- relu(y + bias), in place."""
+    L = _lib()
+    L.check(L.lib.mirl_bias_relu_rows(y.numel() // channels, channels, _p(y), _p(bias), _stream()), "mirl_bias_relu_rows")
+    return y
+
+
+def relu_bwd_bias_rows(dy, y, channels):
+    """-> (g = dy * (y > 0), db = column sums of g) for row-major (rows, channels) views."""
+    L = _lib()
+    rows = y.numel() // channels
+    blocks = C.c_int32()
+    L.check(L.lib.mirl_colsum_blocks(rows, channels, C.byref(blocks)))
+    g = torch.empty_like(y)
+    db = torch.empty(channels, dtype=torch.float32, device=y.device)
+    partial = torch.empty((blocks.value, channels), dtype=torch.float32, device=y.device)
+    L.check(L.lib.mirl_relu_bwd_bias_rows(rows, channels, _p(dy), _p(y), _p(g), _p(db), _p(partial), blocks.value,
+                                          _stream()), "mirl_relu_bwd_bias_rows")
+    return g, db
 
 
 class _LinearReLU(torch.autograd.Function):
@@ -19,15 +74,159 @@ class _LinearReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         x, weight, out = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(grad.contiguous(), out, 0.0)
+        n = out.shape[1]
+        if _pow2_quads(n) and out.is_contiguous():
+            g, db = relu_bwd_bias_rows(grad.contiguous(), out, n)
+        else:
+            g = torch.ops.aten.threshold_backward(grad.contiguous(), out, 0.0)
+            db = g.sum(0) if ctx.needs_input_grad[2] else None
         dx = g.mm(weight) if ctx.needs_input_grad[0] else None
         dw = g.t().mm(x) if ctx.needs_input_grad[1] else None
-        db = g.sum(0) if ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        return dx, dw, (db if ctx.needs_input_grad[2] else None)
 
 
 def linear_relu(x, weight, bias):
     """relu(F.linear(x, weight, bias)) for 2-D x."""
-    if x.is_cuda and x.dim() == 2 and x.dtype == weight.dtype and not torch.is_autocast_enabled():
+    if x.dim() == 2 and x.dtype == weight.dtype and _fusable(x, weight):
         return _LinearReLU.apply(x, weight, bias)
     return F.relu(F.linear(x, weight, bias))
+
+
+class _ConvBiasReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        y = F.conv2d(x, weight, None, stride)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        bias_relu_rows_(y, bias, y.shape[1])          # NHWC memory: (N*H*W, C) rows
+        ctx.stride = stride
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight, y = ctx.saved_tensors
+        c = y.shape[1]
+        grad = grad.contiguous(memory_format=torch.channels_last)
+        if _pow2_quads(c):
+            g, db = relu_bwd_bias_rows(grad, y, c)     # same NHWC strides as y (empty_like preserves them)
+        else:
+            g = torch.ops.aten.threshold_backward(grad, y, 0.0)
+            db = g.sum((0, 2, 3))
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False])
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def conv_bias_relu(x, conv):
+    """relu(conv(x)) for an nn.Conv2d (valid padding, no dilation / groups) on NHWC input."""
+    if (_fusable(x, conv.weight) and conv.bias is not None and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and conv.weight.is_contiguous(memory_format=torch.channels_last)):
+        return _ConvBiasReLU.apply(x, conv.weight, conv.bias, tuple(conv.stride))
+    return F.relu(conv(x))
+
+
+def cos_embed(taus, freq):
+    """cos(freq * taus[:, None]) -> (len(taus), len(freq)); freq = embedding_range * pi as float32."""
+    D = freq.shape[0]
+    if D % 4 == 0 and _fusable(taus, freq) and taus.is_contiguous():
+        L = _lib()
+        out = torch.empty((taus.shape[0], D), dtype=torch.float32, device=taus.device)
+        L.check(L.lib.mirl_cos_embed(taus.shape[0], D, _p(taus), _p(freq), _p(out), _stream()), "mirl_cos_embed")
+        return out
+    return torch.cos(freq * taus.unsqueeze(1))
+
+
+class _QuantileProduct(torch.autograd.Function):
+    """out[m*N+n] = x[m] * relu(phi[m*N+n] @ Wq^T + bq)."""
+
+    @staticmethod
+    def forward(ctx, x, phi, weight, bias, n):
+        L = _lib()
+        emb = torch._addmm_activation(bias, phi, weight.t(), use_gelu=False)
+        M, Cf = x.shape
+        out = torch.empty_like(emb)
+        L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
+        ctx.n = n
+        ctx.save_for_backward(x, phi, weight, emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = _lib()
+        x, phi, weight, emb = ctx.saved_tensors
+        M, Cf = x.shape
+        grad = grad.contiguous()
+        blocks = min(M, 2048)
+        d_pre = torch.empty_like(emb)
+        dx = torch.empty_like(x)
+        db = torch.empty(Cf, dtype=torch.float32, device=x.device)
+        partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
+        L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
+                                       blocks, _stream()), "mirl_iqn_mul_bwd")
+        dw = d_pre.t().mm(phi) if ctx.needs_input_grad[2] else None
+        return (dx if ctx.needs_input_grad[0] else None), None, dw, (db if ctx.needs_input_grad[3] else None), None
+
+
+def quantile_product(x, phi, weight, bias, n):
+    """x (M, C), phi (M*n, D) -> (M*n, C): x[m] * relu(linear(phi))[m*n + j]   (iqn.py:82-102)."""
+    if (x.dim() == 2 and _fusable(x, phi, weight) and _pow2_quads(x.shape[1]) and x.is_contiguous()
+            and phi.is_contiguous() and not phi.requires_grad):
+        return _QuantileProduct.apply(x, phi, weight, bias, n)
+    emb = linear_relu(phi, weight, bias)
+    return (x.unsqueeze(1) * emb.reshape(x.shape[0], n, -1)).reshape(x.shape[0] * n, -1)
+
+
+class _DuelingTail(torch.autograd.Function):
+    """The dueling head's two parallel hidden layers as ONE GEMM.
+
+    reference: the model's last FC layer h = relu(x W1^T + b1) feeding the
+    advantage outputs a = h Wo^T + bo (policies/torch/dqn.py:101-112), and in
+    parallel the value branch hv = relu(x Wv^T + bv), v = hv Wq^T + bq
+    (dqn.py:50-66,74-87).  Both hidden layers read the same (rows, F) input — at
+    the IQN benchmark shape 1.31 M x 512 floats = 2.7 GB — so they run as one
+    (rows, H1 + Hv) GEMM with the ReLU in its epilogue; the backward builds the
+    gradient of that joint activation in place (two small GEMMs into its two column
+    blocks), masks it and reduces the bias gradients in one pass, and produces
+    dx with one GEMM instead of two GEMMs and an add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, wo, bo, wv, bv, wq, bq):
+        h1 = w1.shape[0]
+        both = torch._addmm_activation(torch.cat([b1, bv]), x, torch.cat([w1, wv], 0).t(), use_gelu=False)
+        a = torch.addmm(bo, both[:, :h1], wo.t())
+        v = torch.addmm(bq, both[:, h1:], wq.t())
+        ctx.h1 = h1
+        ctx.save_for_backward(x, w1, wo, wv, wq, both)
+        return a, v
+
+    @staticmethod
+    def backward(ctx, ga, gv):
+        x, w1, wo, wv, wq, both = ctx.saved_tensors
+        h1 = ctx.h1
+        ga, gv = ga.contiguous(), gv.contiguous()
+        d_both = torch.empty_like(both)
+        torch.mm(ga, wo, out=d_both[:, :h1])
+        torch.mm(gv, wq, out=d_both[:, h1:])
+        width = both.shape[1]
+        if _pow2_quads(width):
+            g, db = relu_bwd_bias_rows(d_both, both, width)
+        else:
+            g = torch.ops.aten.threshold_backward(d_both, both, 0.0)
+            db = g.sum(0)
+        dx = g.mm(torch.cat([w1, wv], 0)) if ctx.needs_input_grad[0] else None
+        dw = g.t().mm(x)
+        dwo = ga.t().mm(both[:, :h1])
+        dwq = gv.t().mm(both[:, h1:])
+        return dx, dw[:h1], db[:h1], dwo, ga.sum(0), dw[h1:], db[h1:], dwq, gv.sum(0)
+
+
+def dueling_tail(x, fc, out_layer, value_hidden, value_layer):
+    """-> (advantage outputs, value outputs) for nn.Linear modules; x 2-D."""
+    if x.dim() == 2 and _fusable(x, fc.weight) and x.is_contiguous():
+        return _DuelingTail.apply(x, fc.weight, fc.bias, out_layer.weight, out_layer.bias,
+                                  value_hidden.weight, value_hidden.bias, value_layer.weight, value_layer.bias)
+    h = F.relu(fc(x))
+    return out_layer(h), value_layer(F.relu(value_hidden(x)))

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import linear_relu
+from .fused import conv_bias_relu, linear_relu
 from .utils import conv2d, conv_out_size, init_weight, linear
 
 
@@ -100,7 +100,7 @@ class CNN(BaseModule):
             # x.float() * scale, cnn.py:44-45)
             x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale
         for layer in self.layers:
-            x = F.relu(layer(x))
+            x = conv_bias_relu(x, layer) if self.channels_last else F.relu(layer(x))
         return x
 
 

@@ -95,10 +95,13 @@ class SequentialModel(nn.Module):
         idx = [i for i, layer in enumerate(self.layers) if layer.is_recurrent()]
         return idx[-1] if idx else None
 
-    def forward(self, inp, timesteps, stop_after=None):
+    def forward(self, inp, timesteps, stop_after=None, skip_last=False):
         """sequential.py:167-210 -> {"output", "layer_inputs", + pre-processor extras}.
         stop_after=i ends the pass after layer i (used by the burn-in, which only
-        needs the recurrent state and not the head)."""
+        needs the recurrent state and not the head).  skip_last=True runs
+        everything up to and including the last layer's pre-processor but not the
+        layer itself: "output" is then that layer's input (the policy head fuses
+        the last layer with its own parallel branch, DQNPolicy.predict)."""
         inp = make_tensor(inp, self.device())
         x = inp["x"]
         # optional: output of layer 0 computed earlier for exactly these rows by
@@ -125,6 +128,8 @@ class SequentialModel(nn.Module):
                 x, more = self.layer_pre_processors[i](x)
                 result.update(more)
             result["layer_inputs"].append(x)
+            if skip_last and i == len(self.layers) - 1:
+                break
             if i == 0 and first_out is not None:
                 x = first_out
             elif i == 0 and prepared is not None and self.extra_input_layer != 0 and 0 not in self.layer_pre_processors:

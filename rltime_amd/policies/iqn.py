@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .dqn import DQNPolicy
-from rltime_amd.models.torch.fused import linear_relu
+from rltime_amd.models.torch.fused import cos_embed, quantile_product
 from rltime_amd.models.torch.utils import linear
 
 
@@ -26,12 +26,13 @@ class IQNPolicy(DQNPolicy):
         batch = x.shape[0]
         x = x.reshape(batch, -1)
         quantiles = torch.rand(batch * n, device=self.embedding_range.device)
-        emb = torch.cos(self.embedding_range * np.pi * quantiles.unsqueeze(1))
-        emb = linear_relu(emb, self.quantile_layer.weight, self.quantile_layer.bias)
-        # iqn.py:84,102: interleaved repeat of x times the embedding, grouped
-        # (batch, n).  Broadcasting gives the same values without materialising
-        # the repeated (batch*n, state) copy of x.
-        out = (x.unsqueeze(1) * emb.reshape(batch, n, -1)).reshape(batch * n, -1)
+        # iqn.py:78-81: cos(pi * i * tau) features, one kernel; same roundings as
+        # torch.cos((embedding_range * pi) * tau[:, None])
+        phi = cos_embed(quantiles, self.embedding_range * np.pi)
+        # iqn.py:82-102: relu(linear(phi)) times the interleaved repeat of x, grouped
+        # (batch, n) — without materialising the repeated (batch*n, state) copy of x,
+        # and with a single-pass backward (models/torch/fused.py)
+        out = quantile_product(x, phi, self.quantile_layer.weight, self.quantile_layer.bias, n)
         return out, {"quantiles": quantiles}
 
     def _shape_action_outputs(self, output):
@@ -39,6 +40,9 @@ class IQNPolicy(DQNPolicy):
 
     def _predict_postprocess(self, output, model_output):
         return super()._predict_postprocess(output, model_output), model_output["quantiles"]
+
+    def _tail_postprocess(self, output, model_output):
+        return output, model_output["quantiles"]
 
     def _actor_predict_postprocess(self, pred):
         assert pred[0].shape[1] == self.num_sampling_quantiles

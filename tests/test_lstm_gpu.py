@@ -78,7 +78,13 @@ def test_linear_relu_epilogue_matches_autograd():
             np.testing.assert_allclose(a.cpu() / scale, c.cpu() / scale, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(3, 4, 84, 84), (5, 4, 7, 9), (2, 1, 20, 20), (7, 3, 6, 6), (1000, 4, 84, 84)])
+@pytest.mark.parametrize("shape", [
+    (3, 4, 84, 84),        # LDS-tiled kernel, one tile per workgroup (few frames)
+    (2400, 4, 84, 84),     # LDS-tiled kernel, one workgroup per frame walking its 7 tiles (last one partial)
+    (5, 4, 16, 16),        # a single partial tile
+    (9, 4, 36, 36),        # two tiles, second partial
+    (2600, 4, 64, 64),     # exactly 4 full tiles per frame
+    (5, 4, 7, 9), (2, 1, 20, 20), (7, 3, 6, 6), (6, 2, 20, 20), (1000, 4, 84, 84)])   # generic shapes / sizes
 def test_fused_frame_conversion_is_exact(shape):
     """u8 NCHW -> f32 NHWC * (1/255) in one pass == x.float() * scale (cnn.py:44-45), bit for bit."""
     from rltime_amd.models.torch.modules import _frames_to_f32_nhwc
@@ -89,3 +95,30 @@ def test_fused_frame_conversion_is_exact(shape):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
 
+
+
+def test_prepared_input_feeds_the_same_values():
+    """CNN.prepare_input converts a whole time-major (R, B, C, H, W) block once; row
+    slices of it, flattened like the trainer does, must drive the model to exactly
+    the outputs of the raw uint8 slices (same conv inputs, same kernels)."""
+    from rltime_amd.models.torch.sequential import SequentialModel
+    from rltime_amd.spaces import Box
+    torch.manual_seed(0)
+    layers = [{"type": "cnn", "args": {"channels_last": True, "layers": [
+        {"filters": 8, "kernel": 4, "stride": 2}, {"filters": 8, "kernel": 3, "stride": 1}]}},
+        {"type": "fc", "args": {"fc_size": 16}}]
+    model = SequentialModel(Box(0, 255, (4, 20, 20), np.uint8), layers).cuda()
+    R, B = 7, 5
+    block = torch.randint(0, 256, (R, B, 4, 20, 20), dtype=torch.uint8, device="cuda")
+    prep = model.layers[0].prepare_input(block)
+    assert prep.shape == block.shape and prep.dtype == torch.float32
+    assert torch.equal(prep, block.float() * (1.0 / 255.0))
+    flat = lambda x: x.reshape((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))   # noqa: E731
+    for lo, hi in ((0, 5), (2, 7), (3, 4)):
+        raw = {"x": flat(block[lo:hi]), "layer0_state": {}, "layer1_state": {}}
+        pre = dict(raw, x_prepared=flat(prep[lo:hi]))
+        assert pre["x_prepared"].is_contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            a = model(raw, 1)["output"]
+            b = model(pre, 1)["output"]
+        assert torch.equal(a, b)

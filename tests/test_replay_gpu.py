@@ -168,6 +168,23 @@ def test_per_sequences_vs_oracle_recurrent():
     print("PER leaves differing from the reference by 1 ulp: %d / %d" % (m["leaf"], m["leaves"]))
 
 
+@pytest.mark.parametrize("T,P,n", [(9, 3, 2), (20, 5, 3), (80, 40, 2), (128, 4, 1)])
+def test_wave_per_sequence_priorities_vs_oracle(T, P, n):
+    """k_recalc_flagged_wave (8 <= T <= 128: one wave per sequence, NumPy's eight
+    interleaved accumulators kept in lanes 0..7, shuffle-combined in NumPy's
+    association) against the reference restatement: leaf kinds exact, values
+    <= 1 ulp, for sequence lengths with and without an n % 8 tail, fresh (Python
+    float 1.0 -> float64 path) and fully-updated (float32 path) sequences."""
+    E = 4
+    per_env = T + P + n + 3 * (T - T // 2) + 8
+    m = _run_pair(40 + T, E, [("feed", per_env), ("draw", 31, 0.0), ("draw", 32, 0.1), ("feed", T // 2 + 3),
+                              ("draw", 33, 0.4), ("draw", 34, 0.6), ("feed", T), ("draw", 35, 0.9)],
+                  dict(size=E * (per_env + 2 * T), train_frequency=0, nstep_target=n, nstep_train=T, prefix_steps=P,
+                       alpha=0.9, beta=0.6, max_weight_factor=0.9),
+                  0.99, True, dict(frame_shape=(1, 8, 8), lstm_units=4, n_actions=4, done_prob=0.03), 4)
+    assert m["draws"] == 5
+
+
 def test_per_t1_vs_oracle_rainbow_shape():
     """Rainbow-shaped: T=1, n=3, f32 tree regime, beta anneal, many updates."""
     script = [("feed", 50)]

@@ -132,3 +132,38 @@ def test_graph_captured_acting_matches_eager():
         assert torch.equal(a[0], b[0])
         assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6)
         assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-6)
+
+
+def test_failed_graph_capture_falls_back_to_the_eager_state(monkeypatch):
+    """If HIP-graph capture of the acting step fails, the eager fallback must
+    continue from the recurrent state the actor had BEFORE the capture attempt
+    (GraphedStep re-binds layer.last_state to a static carry and advances it
+    through warm-up forwards): the sample stream must equal pure eager acting."""
+    from rltime_amd.acting.actor import Actor
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    from rltime_amd.policies.dqn import DQNPolicy
+    model = {"type": "sequential", "args": {"layer_configs": [
+        CNN, {"type": "lstm", "args": {"num_units": 16}}, {"type": "fc", "args": {"fc_size": 32}}]}}
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        env = SyntheticAtariVecEnv(8, frame_shape=(2, 20, 20), n_actions=4, seed=3)
+        pol = DQNPolicy.create(model_config=model, observation_space=env.observation_space,
+                               action_space=env.action_space, dueling=True)
+        actor = Actor(env, device=True, use_graph=use_graph)
+        actor.set_actor_policy(pol)
+        batch = actor.get_samples(8 * 6)
+        return actor, [(s["actions"].cpu(), s["policy"].cpu(), s["state"].cpu()) for s in batch.vector_steps]
+
+    _, eager = run(False)
+
+    class Boom(torch.cuda.CUDAGraph):
+        def __new__(cls, *a, **k):
+            raise RuntimeError("capture unsupported (forced by the test)")
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", Boom)
+    actor, fallen = run(True)
+    assert actor._use_graph is False and actor._graphed is None      # it did fall back
+    for a, b in zip(eager, fallen):
+        assert torch.equal(a[0], b[0])
+        assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-6)

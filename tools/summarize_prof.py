@@ -28,6 +28,30 @@ def main(out):
             print("%-72s %8s %12.3f %10.2f %6.2f" % (
                 r["Name"][:72], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                 float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+        # time by kernel family, per learner step (the profiled command runs STEPS steps
+        # in total: warm-up + timed; the replay fill and the one-off probes are a few ms)
+        steps = float(os.environ.get("PROF_STEPS", "7"))
+        fam = {}
+        for r in rows:
+            n = r["Name"]
+            if "mirl" in n:
+                k = "librltime_hip"
+            elif n.startswith("Cijk_"):
+                k = "hipBLASLt/rocBLAS GEMM"
+            elif "igemm" in n or "SubTensorOp" in n or "miopen" in n.lower() or "Conv" in n or "gridwise" in n:
+                k = "MIOpen conv"
+            elif "at::native" in n or "at_cuda" in n:
+                k = "PyTorch elementwise/reduce/copy"
+            elif "rocclr" in n:
+                k = "runtime copy/fill"
+            elif "ccl" in n.lower():
+                k = "RCCL"
+            else:
+                k = "other"
+            fam[k] = fam.get(k, 0.0) + float(r["TotalDurationNs"]) / 1e6
+        print("\n-- kernel time by family (ms per step over %g steps; total %.1f ms/step)" % (steps, tot / 1e6 / steps))
+        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]):
+            print("%-40s %10.2f" % (k, v / steps))
         ours = [r for r in rows if r["Name"].startswith("mirl::") or "mirl" in r["Name"]]
         print("\n-- librltime_hip kernels")
         for r in ours:
