@@ -131,6 +131,33 @@ class Actor(ActingInterface):
     def close(self):
         self._vec_env.close()
 
+    # -- resume (training/resume.py) -------------------------------------------
+    def get_state(self):
+        """Recurrent carry, last input state and env generator: what the next
+        get_samples call continues from."""
+        rec = [layer for layer in self._policy.model.layers if layer.is_recurrent()]
+        clone = lambda t: deep_apply(t, lambda x: x.detach().clone().cpu() if isinstance(x, torch.Tensor) else x)  # noqa: E731
+        if self._graphed is not None:
+            carry = [tuple(t.detach().clone().cpu() for t in pair) for pair in self._graphed.carry]
+            last = clone(self._graphed.states)
+        else:
+            carry = [None if layer.last_state is None else tuple(t.detach().clone().cpu() for t in layer.last_state)
+                     for layer in rec]
+            last = clone(self.last_state)
+        env = self._vec_env.get_state() if hasattr(self._vec_env, "get_state") else None
+        return {"progress": self._progress, "carry": carry, "last_state": last, "env": env}
+
+    def set_state(self, state):
+        dev = self._policy.device()
+        rec = [layer for layer in self._policy.model.layers if layer.is_recurrent()]
+        for layer, pair in zip(rec, state["carry"]):
+            layer.last_state = None if pair is None else tuple(t.to(dev) for t in pair)
+        self.last_state = deep_apply(state["last_state"], lambda x: x.to(dev) if isinstance(x, torch.Tensor) else x)
+        self._progress = state["progress"]
+        self._graphed = None                   # the acting graph is re-captured from this state
+        if state["env"] is not None and hasattr(self._vec_env, "set_state"):
+            self._vec_env.set_state(state["env"])
+
     def get_samples(self, min_samples):
         """actor.py:97-149."""
         iters = (max(1, min_samples) + self._num_envs - 1) // self._num_envs

@@ -42,5 +42,12 @@ class SyntheticAtariVecEnv:
         obs, rewards, dones, _ = self.step_device(torch.as_tensor(actions, device=self.device))
         return obs, rewards.double().cpu().numpy(), dones.cpu().numpy(), [dict() for _ in range(self.num_envs)]
 
+    def get_state(self):
+        return {"t": self._t, "generator": self._g.get_state().cpu()}
+
+    def set_state(self, state):
+        self._t = state["t"]
+        self._g.set_state(state["generator"].cpu())
+
     def close(self):
         pass

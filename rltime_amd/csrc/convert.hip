@@ -100,9 +100,11 @@ extern "C" int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, cons
   mirl::ProfScope ps("k_frames_to_f32_nhwc", (double)N * C * HW * 5.0, st);
   if (C == 4 && (HW % 16) == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
     const int tiles = (HW + MIRL_CV_TILE - 1) / MIRL_CV_TILE;
-    // few frames (the acting step): one tile per workgroup to fill the chip;
-    // a learner batch: one workgroup per frame, the tile loop hides the latency
-    if (per_wg <= 0) per_wg = N * tiles < 16384 ? 1 : tiles;
+    // one 1024-pixel tile per workgroup: measured best at the config-D block
+    // (62 464 frames: 1.50 ms = 73 % of the HBM peak with cached loads + non-temporal
+    // stores; 7 tiles per workgroup 1.63 ms, non-temporal loads 1.56 ms —
+    // profiles/r02_convert_variant_sweep.jsonl)
+    if (per_wg <= 0) per_wg = 1;
     if (per_wg > tiles) per_wg = tiles;
     const int64_t blocks = N * ((tiles + per_wg - 1) / per_wg);
     if (blocks >= (1LL << 31)) return mirl::fail(MIRL_ERR_ARG, "frames_to_f32_nhwc: too many frames for one launch");
@@ -124,6 +126,6 @@ extern "C" int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, cons
 
 extern "C" int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale, float* dst, void* stream) {
   static const int per_wg = getenv("MIRL_CONVERT_PER_WG") ? atoi(getenv("MIRL_CONVERT_PER_WG")) : 0;
-  static const int flags = getenv("MIRL_CONVERT_FLAGS") ? atoi(getenv("MIRL_CONVERT_FLAGS")) : 0;
+  static const int flags = getenv("MIRL_CONVERT_FLAGS") ? atoi(getenv("MIRL_CONVERT_FLAGS")) : 1;   // cached loads, nt stores
   return mirl_frames_to_f32_nhwc_ex(N, C, HW, src, scale, dst, per_wg, flags, stream);
 }

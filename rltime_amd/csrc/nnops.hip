@@ -86,14 +86,27 @@ k_relu_bwd_bias_rows(const nn_f4* __restrict__ dy, const nn_f4* __restrict__ y, 
   }
 }
 
-// db[c] = sum over blocks, fixed order
+// db[c] = sum over the per-block partials in a FIXED order: one workgroup per 64
+// columns, its 4 waves take interleaved blocks (b = w, w + 4, ...) with 64
+// coalesced columns per load, then the 4 wave sums are added in wave order.
 __global__ void __launch_bounds__(256)
 k_colsum_partials(const float* __restrict__ partial, float* __restrict__ out, int blocks, int C) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s = s + partial[(int64_t)b * C + c];
-  out[c] = s;
+  if (c < C) {
+    int b = w;
+    for (; b + 12 < blocks; b += 16) {
+      float v0 = partial[(int64_t)b * C + c], v1 = partial[(int64_t)(b + 4) * C + c];
+      float v2 = partial[(int64_t)(b + 8) * C + c], v3 = partial[(int64_t)(b + 12) * C + c];
+      s = s + v0; s = s + v1; s = s + v2; s = s + v3;
+    }
+    for (; b < blocks; b += 4) s = s + partial[(int64_t)b * C + c];
+  }
+  s_part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) out[c] = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
 }
 
 // phi[r][i] = cos(tau[r] * w[i]),  w[i] = (i+1) * pi rounded to f32 (the
@@ -248,7 +261,7 @@ extern "C" int mirl_relu_bwd_bias_rows(int64_t rows, int32_t C, const float* dy,
   MIRL_LAUNCH_CHECK();
   {
     ProfScope ps("k_colsum_partials", (double)blocks * C * 4, st);
-    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
   }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
@@ -295,7 +308,7 @@ extern "C" int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g,
   MIRL_LAUNCH_CHECK();
   {
     ProfScope ps("k_colsum_partials", (double)blocks * C * 4, st);
-    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
   }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;

@@ -356,6 +356,7 @@ k_gather_rows(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out
 // 0.638 ms (5.53 TB/s) vs 0.654 ms for the 256-lane kernel above; a persistent
 // 2048..8192-workgroup variant and a source-contiguous block order were slower
 // (0.66-0.72 ms) at this replay size and were dropped.
+template <int NTL>
 __global__ void __launch_bounds__(512)
 k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
                  const int32_t* __restrict__ env, const int64_t* __restrict__ start,
@@ -373,15 +374,18 @@ k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ 
   const int n = row_bytes >> 4;
   int c = threadIdx.x;
   for (; c + 1536 < n; c += 2048) {
-    u32x4 v0 = __builtin_nontemporal_load(s4 + c), v1 = __builtin_nontemporal_load(s4 + c + 512);
-    u32x4 v2 = __builtin_nontemporal_load(s4 + c + 1024), v3 = __builtin_nontemporal_load(s4 + c + 1536);
+    u32x4 v0, v1, v2, v3;
+    if (NTL) {
+      v0 = __builtin_nontemporal_load(s4 + c); v1 = __builtin_nontemporal_load(s4 + c + 512);
+      v2 = __builtin_nontemporal_load(s4 + c + 1024); v3 = __builtin_nontemporal_load(s4 + c + 1536);
+    } else { v0 = s4[c]; v1 = s4[c + 512]; v2 = s4[c + 1024]; v3 = s4[c + 1536]; }
     __builtin_nontemporal_store(v0, t4 + c); __builtin_nontemporal_store(v1, t4 + c + 512);
     __builtin_nontemporal_store(v2, t4 + c + 1024); __builtin_nontemporal_store(v3, t4 + c + 1536);
   }
   u32x4 w0, w1, w2; bool h0 = c < n, h1 = c + 512 < n, h2 = c + 1024 < n;
-  if (h0) w0 = __builtin_nontemporal_load(s4 + c);
-  if (h1) w1 = __builtin_nontemporal_load(s4 + c + 512);
-  if (h2) w2 = __builtin_nontemporal_load(s4 + c + 1024);
+  if (h0) w0 = NTL ? __builtin_nontemporal_load(s4 + c) : s4[c];
+  if (h1) w1 = NTL ? __builtin_nontemporal_load(s4 + c + 512) : s4[c + 512];
+  if (h2) w2 = NTL ? __builtin_nontemporal_load(s4 + c + 1024) : s4[c + 1024];
   if (h0) __builtin_nontemporal_store(w0, t4 + c);
   if (h1) __builtin_nontemporal_store(w1, t4 + c + 512);
   if (h2) __builtin_nontemporal_store(w2, t4 + c + 1024);
@@ -911,9 +915,14 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   {
   ProfScope ps(ring == (const void*)h->d.frames ? "k_gather_rows(frames)" : (ring == (const void*)h->d.state ? "k_gather_rows(recurrent state)" : "k_gather_rows(extra)"),
                2.0 * (double)blocks * row_bytes, st);
-  if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16)      // small rows (recurrent state) keep the 256-lane shape
-    hipLaunchKernelGGL(k_gather_rows_v1, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
-                       env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
+  if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16) {    // small rows (recurrent state) keep the 256-lane shape
+    if (h->gather_nt == 2)                                          // cached loads, non-temporal stores
+      hipLaunchKernelGGL(k_gather_rows_v1<0>, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                         env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
+    else
+      hipLaunchKernelGGL(k_gather_rows_v1<1>, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
+                         env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);
+  }
   else if (h->gather_nt)
     hipLaunchKernelGGL(k_gather_rows<1>, dim3((unsigned)blocks), dim3(256), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                        env, start, B, h->overlapped, row_bytes, ring_stride, vec);

@@ -39,11 +39,25 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
+def _host_example(state):
+    def leaf(v):
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu().numpy()
+        return np.asarray(v)
+    if isinstance(state, dict):
+        return {k: _host_example(v) for k, v in state.items()}
+    if isinstance(state, (tuple, list)):
+        return type(state)(_host_example(v) for v in state)
+    return leaf(state)
+
+
 class _Layout:
     """Shape of one stored ``next_state`` pytree (sequential.py:128-146:
     {"x": obs | tuple(obs, extra...), "layer{i}_state": {} | {hx, cx, initials}})."""
 
     def __init__(self, state):
+        # one transition's pytree as host arrays: enough to re-create the shard on resume
+        self.example = _host_example(state)
         x = state["x"]
         if isinstance(x, (tuple, list)):
             self.tuple_obs = True
@@ -138,6 +152,7 @@ class ReplayHistoryBuffer(History):
 
     def _create(self, layout, num_envs, env_base, policy_f32):
         self._layout = layout
+        self._example_state = layout.example
         self._num_envs = num_envs
         self._env_base = env_base
         self._policy_f32 = policy_f32

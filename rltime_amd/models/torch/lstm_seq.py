@@ -7,11 +7,11 @@ Same recurrence as the reference's LSTMCell time loop with per-step reset
     gates = W_ih x(t) + b_ih + W_hh h_in + b_hh       (i, f, g, o)
     c(t) = sig(f) c_in + sig(i) tanh(g) ; h(t) = sig(o) tanh(c(t))
 
-but one step costs one rocBLAS GEMM (h_in @ W_hh^T accumulated onto the
-pre-computed input projection) plus one fused HIP kernel
-(csrc/lstm.hip: mirl_lstm_cell_fwd / _bwd).  The weight gradient of W_hh is ONE
-GEMM over all timesteps after the backward sweep, and the gradient w.r.t. the
-input projection is returned without a copy.
+but the input projection of all T steps is ONE GEMM, one step costs one rocBLAS
+GEMM (h_in @ W_hh^T accumulated IN PLACE onto its slice of that projection) plus
+one fused HIP kernel (csrc/lstm.hip: mirl_lstm_cell_fwd / _bwd), and the weight
+gradients of W_ih and W_hh are one GEMM each over all timesteps after the
+backward sweep.
 """
 import ctypes as C
 
@@ -30,16 +30,19 @@ def _stream():
 
 class _LSTMSequence(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gx, w_hh, h0, c0, keep):
-        # gx (T, B, 4H): input projection incl. b_ih + b_hh; keep (T, B)
-        T, B, G = gx.shape
-        H = G // 4
-        gx = gx.float().contiguous()
+    def forward(ctx, x, w_ih, w_hh, bias, h0, c0, keep):
+        # x (T*B, I); bias = b_ih + b_hh (4H); keep (T, B).  The input projection of
+        # ALL timesteps is one GEMM into `gates`; every step then accumulates the
+        # recurrent GEMM onto its slice IN PLACE (no per-step copy of the projection)
+        # and the cell kernel turns the pre-activations into activated gates in place.
+        T, B = keep.shape
+        H = w_hh.shape[1]
+        x = x.float()
         w = w_hh.float().contiguous()
         keep = keep.float().contiguous()
-        need_grad = gx.requires_grad or w_hh.requires_grad
-        dev = gx.device
-        gates = torch.empty_like(gx)
+        need_grad = any(ctx.needs_input_grad[:4])
+        dev = x.device
+        gates = torch.addmm(bias.float(), x, w_ih.float().t()).view(T, B, 4 * H)
         hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)     # masked h inputs; hm[T] = final h
         cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
         out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
@@ -49,20 +52,20 @@ class _LSTMSequence(torch.autograd.Function):
         wt = w.t()
         st = _stream()
         for t in range(T):
-            torch.addmm(gx[t], hm[t], wt, out=gates[t])
+            gates[t].addmm_(hm[t], wt)
             check(lib.mirl_lstm_cell_fwd(
                 B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
                 _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
                 "mirl_lstm_cell_fwd")
         if need_grad:
-            ctx.save_for_backward(gates, c_all, cm, hm, keep, w)
+            ctx.save_for_backward(x, w_ih, gates, c_all, cm, hm, keep, w)
         h_last, c_last = hm[T], cm[T]
         ctx.mark_non_differentiable(h_last, c_last)
         return out, h_last, c_last
 
     @staticmethod
     def backward(ctx, d_out, _dh, _dc):
-        gates, c_all, cm, hm, keep, w = ctx.saved_tensors
+        x, w_ih, gates, c_all, cm, hm, keep, w = ctx.saved_tensors
         T, B, G = gates.shape
         H = G // 4
         d_out = d_out.float().contiguous()
@@ -76,10 +79,14 @@ class _LSTMSequence(torch.autograd.Function):
                 "mirl_lstm_cell_bwd")
             if t > 0:
                 torch.mm(gates[t], w, out=dh_rec)
-        d_w = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H))
-        return gates, d_w, None, None, None
+        dg = gates.reshape(T * B, G)                      # now d loss / d pre-activation
+        d_x = dg.mm(w_ih.float()) if ctx.needs_input_grad[0] else None
+        d_wih = dg.t().mm(x) if ctx.needs_input_grad[1] else None
+        d_whh = dg.t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[2] else None
+        d_b = dg.sum(0) if ctx.needs_input_grad[3] else None
+        return d_x, d_wih, d_whh, d_b, None, None, None
 
 
-def lstm_sequence(gx, w_hh, h0, c0, keep):
-    """-> (out (T,B,H), h_T (B,H), c_T (B,H))."""
-    return _LSTMSequence.apply(gx, w_hh, h0, c0, keep)
+def lstm_sequence(x, w_ih, w_hh, bias, h0, c0, keep):
+    """x (T*B, I) -> (out (T,B,H), h_T (B,H), c_T (B,H)); keep (T, B) = 1 - initials."""
+    return _LSTMSequence.apply(x, w_ih, w_hh, bias, h0, c0, keep)

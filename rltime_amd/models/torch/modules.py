@@ -168,9 +168,8 @@ class LSTM(BaseModule):
         if x.is_cuda and multi == 1 and self.fused:
             # MI355X path: one GEMM + one fused HIP kernel per step (lstm_seq.py)
             from .lstm_seq import lstm_sequence
-            gx = F.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh).reshape(timesteps, batch, -1)
-            out, h_last, c_last = lstm_sequence(gx, cell.weight_hh, hx, cx,
-                                                (1 - initials).reshape(timesteps, batch))
+            out, h_last, c_last = lstm_sequence(x, cell.weight_ih, cell.weight_hh, cell.bias_ih + cell.bias_hh,
+                                                hx, cx, (1 - initials).reshape(timesteps, batch))
             self.last_state = (h_last.detach(), c_last.detach())
             return out.reshape(timesteps * batch, self.num_units)
         keep = (1 - initials).reshape(timesteps, batch, 1)

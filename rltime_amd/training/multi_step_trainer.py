@@ -131,6 +131,9 @@ class MultiStepTrainer(PolicyTrainer):
         self.rnn_steps_train = rnn_steps_train or nstep_train
         assert (not burn_in_timesteps) or self.policy.is_recurrent(), \
             "burn_in_timesteps only makes sense for recurrent policies"
+        if self.resume_from:
+            from . import resume
+            resume.load(self, self.resume_from)
         if getattr(self, "_setup_only", False):
             return
         while not self.train_is_done():
@@ -150,6 +153,12 @@ class MultiStepTrainer(PolicyTrainer):
     def loop_iteration(self):
         """One pass of the while-body of multi_step_trainer.py:245-375.
         Returns True when a learner step was taken."""
+        stepped = self._loop_iteration()
+        if self._full_checkpoint_due:
+            self.save_full_checkpoint()
+        return stepped
+
+    def _loop_iteration(self):
         progress = self.get_train_progress()
         warming_up = self.steps < self.warmup_steps
         env_count = self.actors.get_env_count()

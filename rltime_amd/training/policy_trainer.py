@@ -26,6 +26,9 @@ class PolicyTrainer:
         self.value_log = ValueLog()
         self._gpu_spans = []
         self.data_parallel = None       # rltime_amd.parallel.DataParallel when one process per GPU
+        self.resume_from = None         # directory of a run written with full_checkpoints=True (training/resume.py)
+        self.full_checkpoints = False
+        self._full_checkpoint_due = False
 
     # -- hooks for subclasses ------------------------------------------------
     @staticmethod
@@ -155,6 +158,9 @@ class PolicyTrainer:
             self.sync_target()
         if _crossed(before, self.steps, self.log_freq):
             self._log_checkpoint()
+            # the full (resumable) checkpoint is taken at the end of this loop iteration:
+            # right here the new samples are acted but not yet in the replay
+            self._full_checkpoint_due = self.full_checkpoints
         self._end_timer()
         return samples
 
@@ -173,8 +179,23 @@ class PolicyTrainer:
             {"policy_state": self.policy.get_state(), "train_state": self._get_train_state()}, self.steps)
 
     # -- entry point -----------------------------------------------------------------
+    def save_full_checkpoint(self):
+        """Everything the next loop iteration depends on (training/resume.py), next to
+        the reference-style weights-only checkpoint.p."""
+        from . import resume
+        path = getattr(self.logger, "path", None)
+        if path is None:
+            raise ValueError("full_checkpoints needs a directory logger (train.py --log-dir)")
+        self._resolve_gpu_spans()
+        resume.save(self, path)
+        self._full_checkpoint_due = False
+
     def train(self, total_steps, log_freq=10000, target_update_freq=0, clip_rewards=False,
-              early_stop_steps=None, episode_history_windows=[10, 100], **kwargs):
+              early_stop_steps=None, episode_history_windows=[10, 100], full_checkpoints=False, **kwargs):
+        """policy_trainer.py:284-325.  full_checkpoints (not in the reference): also write
+        a resumable checkpoint (replay shard, optimizer, RNG streams, counters) at every
+        log interval; `python -m rltime_amd.train ... --resume <log dir>` continues it."""
+        self.full_checkpoints = full_checkpoints
         self.total_steps, self.early_stop_steps = total_steps, early_stop_steps
         self.log_freq, self.target_update_freq = log_freq, target_update_freq
         self.clip_rewards = clip_rewards

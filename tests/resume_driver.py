@@ -1,0 +1,74 @@
+"""Subprocess body of tests/test_resume_gpu.py: one training run of the tiny
+recurrent-IQN / prioritized-replay config through rltime_amd.train.train, the
+per-learner-step loss / grad-norm series dumped as JSON."""
+import argparse
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CNN = {"type": "cnn", "args": {"channels_last": True, "layers": [{"filters": 8, "kernel": 4, "stride": 2},
+                                                                {"filters": 8, "kernel": 3, "stride": 1}]}}
+
+
+def config(total, stop, full):
+    return {
+        "acting": {"actor_envs": 8, "exploration": {"type": "epsilon_greedy", "args": {
+            "eps_start": 1.0, "eps_final": 0.05, "exploration_fraction": 0.5}}},
+        "env": "synthetic-atari", "env_args": {"frame_shape": [4, 20, 20], "n_actions": 4, "done_prob": 0.02},
+        "model": {"type": "sequential", "args": {"layer_configs": [
+            CNN, {"type": "lstm", "args": {"num_units": 16}}, {"type": "fc", "args": {"fc_size": 32}}]}},
+        "policy_args": {"dueling": True, "embedding_dim": 8, "num_sampling_quantiles": 4},
+        "training": {"type": "iqn", "args": {
+            "clip_rewards": False, "vf_scale_epsilon": 1e-3, "gamma": 0.99, "mbatch_size": 8, "nstep_train": 8,
+            "burn_in_timesteps": 4, "nstep_target": 2, "lr": 1e-3, "lr_anneal": True, "double_q": True,
+            "rnn_bootstrap": True, "clip_grad": 10.0, "clip_grad_dynamic_alpha": 0.9, "target_update_freq": 160,
+            "total_steps": total, "early_stop_steps": stop, "log_freq": total // 2, "warmup_steps": 0,
+            "full_checkpoints": full,
+            "history_mode": {"type": "prioritized_replay", "args": {
+                "size": 600, "train_frequency": 4, "alpha": 0.9, "beta": 0.6, "beta_anneal": True}}}},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-dir", required=True)
+    ap.add_argument("--name", required=True)
+    ap.add_argument("--total", type=int, required=True)
+    ap.add_argument("--stop", type=int, default=None)
+    ap.add_argument("--full", type=int, default=1)
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    torch.backends.cudnn.deterministic = True          # MIOpen: no atomically-accumulating solvers
+    random.seed(1); np.random.seed(2); torch.manual_seed(3)   # noqa: E702
+    from rltime_amd.general.loggers import DirectoryLogger
+    from rltime_amd.train import train
+    series = {"qloss": [], "grad_norm": [], "steps_at": []}
+
+    def hook(trainer):
+        orig = trainer.value_log.log
+
+        def tap(key, value, *args, **kw):
+            if key in ("qloss", "grad_norm") and kw.get("group") == "train":
+                series[key].append(float(value.item() if hasattr(value, "item") else value))
+                if key == "qloss":
+                    series["steps_at"].append(trainer.steps)
+            return orig(key, value, *args, **kw)
+        trainer.value_log.log = tap
+
+    logger = DirectoryLogger(os.path.join(a.log_dir, a.name), echo=False)
+    trainer = train(config(a.total, a.stop, bool(a.full)), logger, resume=a.resume, on_trainer=hook)
+    series["final_steps"] = trainer.steps
+    series["param_sum"] = float(sum(p.double().sum().item() for p in trainer.policy.parameters()))
+    json.dump(series, open(a.out, "w"))
+
+
+if __name__ == "__main__":
+    main()
