@@ -71,6 +71,17 @@ typedef struct mirl_replay_config {
   int32_t global_importance_scaling; /* :76 */
   int32_t env_ring_slack;   /* extra ring slots per env beyond ceil(size/num_envs)+1 */
   int32_t device;           /* HIP device ordinal */
+  /* Acting-time priority initialisation — NOT in the reference, which lists it as
+   * missing (prioritized_replay_history.py:33-36: new samples enter at the constant
+   * max loss 1.0).  When set (needs policy_f32 = number of actions), every ingested
+   * transition j of an env makes transition j - n's TD error available from STORED
+   * data: delta = Q(s_{j-n})[a_{j-n}] - h(R_n + gamma^n h^-1(max_a Q(s_j)) mask), the
+   * n-step quantities exactly as History._update_nstep builds them and the target
+   * exactly as torch_trainer.py:124-147; it is written through the update_losses
+   * path (same |.|+eps, same fan-out to the overlapped sequences) right after the
+   * vector step was added.  acting_vf_eps <= 0: no value rescaling.               */
+  int32_t acting_priority_init;
+  double  acting_vf_eps;
 } mirl_replay_config;
 
 /* One vector step handed to History.update: `count` transitions, transition k

@@ -52,6 +52,8 @@ class ReplayConfig(C.Structure):
         ("global_importance_scaling", C.c_int32),
         ("env_ring_slack", C.c_int32),
         ("device", C.c_int32),
+        ("acting_priority_init", C.c_int32),
+        ("acting_vf_eps", C.c_double),
     ]
 
 

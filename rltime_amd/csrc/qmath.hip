@@ -12,29 +12,9 @@
 // Floating point, fp32 like the reference (the h^-1 of value rescaling in fp64
 // as torch_trainer.py:59-61 does).  Parity bar: 1e-4 against oracle/qmath.py.
 #include "common.hpp"
+#include "vfscale.hpp"
 
 namespace mirl {
-
-// torch_trainer.py:46-52
-__device__ __forceinline__ float vf_scale(float x, float eps) {
-  float s = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
-  return s * (sqrtf(fabsf(x) + 1.f) - 1.f) + eps * x;
-}
-// torch_trainer.py:54-78 (float64 inside, float32 out)
-__device__ __forceinline__ float vf_unscale(float y, double eps) {
-  double a = fabs((double)y);
-  double x = a / eps - (1.0 / (2.0 * (eps * eps))) * sqrt(4.0 * eps * a + (2.0 * eps + 1.0) * (2.0 * eps + 1.0)) +
-             (2.0 * eps + 1.0) / (2.0 * (eps * eps));
-  double s = y > 0.f ? 1.0 : (y < 0.f ? -1.0 : 0.0);
-  return (float)(x * s);
-}
-// torch_trainer.py:144-147: h(ret + gamma**n * h^-1(v) * mask)
-__device__ __forceinline__ float finish_target(float v, float ret, float disc, float mask, double vf_eps) {
-  if (vf_eps > 0.0) v = vf_unscale(v, vf_eps);
-  float y = ret + disc * v * mask;
-  if (vf_eps > 0.0) y = vf_scale(y, (float)vf_eps);
-  return y;
-}
 
 __global__ void __launch_bounds__(256)
 k_target_dqn(int64_t M, int A, const float* __restrict__ qt, const float* __restrict__ qs,

@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include "book.hpp"
 #include "np_emul.h"
+#include "vfscale.hpp"
 
 #include <cstring>
 #include <cmath>
@@ -563,6 +564,35 @@ k_recalc_flagged_wave(Dev d) {
   }
 }
 
+// Acting-time priority initialisation (mirl_replay_config.acting_priority_init).
+// One lane per ingested transition j: the TD error of transition t = j - n from
+// stored rewards / dones / actions / q-values, emitted as an update_losses row.
+__global__ void __launch_bounds__(256)
+k_acting_td(Dev d, int K, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off, double vf_eps,
+            int64_t* __restrict__ idx, float* __restrict__ loss) {
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int32_t e = s_env[k];
+  const int64_t j = s_off[k], t = j - d.N;
+  idx[2 * k] = -1; idx[2 * k + 1] = -1; loss[k] = 0.f;
+  if (t < d.first[e]) return;
+  const int64_t st = slot_of(d, e, t);
+  double ret = (double)d.rewards[st];                  // History.update / _update_nstep (history.py:71-108,146-147)
+  int mask = d.dones[st] ? 0 : 1;
+  for (int q = 1; q < d.N; ++q) {
+    const int64_t sq = slot_of(d, e, t + q);
+    if (mask) { double term = d.gpow[q] * (double)d.rewards[sq]; ret = ret + term; }
+    if (d.dones[sq]) mask = 0;
+  }
+  const float* qj = d.policy + slot_of(d, e, j) * d.A;
+  float v = qj[0];
+  for (int a = 1; a < d.A; ++a) v = qj[a] > v ? qj[a] : v;
+  const float y = finish_target(v, (float)ret, (float)d.gpow[d.N], (float)mask, vf_eps);
+  const float chosen = d.policy[st * d.A + d.actions[st]];
+  idx[2 * k] = (int64_t)(e + d.env_base); idx[2 * k + 1] = t;
+  loss[k] = chosen - y;
+}
+
 __global__ void k_copy16(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -619,6 +649,7 @@ struct mirl_replay {
   std::vector<void*> allocs;
   double* gpow_dev = nullptr;
   int32_t* bad_host = nullptr;
+  int64_t* td_idx = nullptr; float* td_loss = nullptr; int td_cap = 0;   // acting-time priority scratch
   int gather_nt = 0;
   int gather_variant = 1, gather_order = 0;
   int recalc_wave = 1;
@@ -659,6 +690,8 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   if (!cfg || !out) return fail(MIRL_ERR_ARG, "null argument");
   if (mirl_device_count() <= 0) return fail(MIRL_ERR_NOGPU, "no HIP device visible: librltime_hip needs an AMD GPU (there is no CPU fallback)");
   if (cfg->frame_bytes <= 0) return fail(MIRL_ERR_ARG, "frame_bytes must be > 0");
+  if (cfg->acting_priority_init && (cfg->mode != MIRL_MODE_PER || cfg->policy_f32 <= 0))
+    return fail(MIRL_ERR_ARG, "acting_priority_init needs prioritized replay and stored q-values (policy_f32 = number of actions)");
   MIRL_HIP(hipSetDevice(cfg->device));
   mirl_replay* h = new mirl_replay();
   int rc = h->book.init(*cfg);
@@ -687,9 +720,9 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   TRY(dev_alloc(h, &d.first, (size_t)d.E));
   TRY(dev_alloc(h, &d.count, (size_t)d.E));
   {
-    std::vector<double> g((size_t)d.N);
-    for (int k = 0; k < d.N; ++k) g[(size_t)k] = pow(cfg->gamma, (double)k);   // float.__pow__ -> libm pow
-    TRY(dev_alloc(h, &h->gpow_dev, (size_t)d.N));
+    std::vector<double> g((size_t)d.N + 1);                                        // [N] = gamma ** n for the acting-time TD
+    for (int k = 0; k <= d.N; ++k) g[(size_t)k] = pow(cfg->gamma, (double)k);  // float.__pow__ -> libm pow
+    TRY(dev_alloc(h, &h->gpow_dev, (size_t)d.N + 1));
     hipError_t e = hipMemcpy(h->gpow_dev, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { mirl_replay_destroy(h); return fail(MIRL_ERR_HIP, hipGetErrorString(e)); }
     d.gpow = h->gpow_dev;
@@ -747,6 +780,8 @@ static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s
   return MIRL_OK;
 }
 
+static int update_losses_impl(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, hipStream_t st);
+
 extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream) {
   if (!h || !in || in->count <= 0) return fail(MIRL_ERR_ARG, "bad ingest arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -794,6 +829,25 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
     MIRL_LAUNCH_CHECK();
   }
   if (nl) { ProfScope ps("k_tree_fix(ingest)", 0.0, st); hipLaunchKernelGGL(k_tree_fix, dim3(1), dim3(1024), 0, st, d); MIRL_LAUNCH_CHECK(); }
+  if (h->book.cfg.acting_priority_init && d.per) {
+    // TD errors of the transitions whose n-step target just became available, from
+    // stored q-values, through the update_losses path (see mirl_replay_config)
+    if (h->td_cap < K) {
+      int cap = 256; while (cap < K) cap *= 2;
+      int64_t* pi = nullptr; float* pl = nullptr;
+      MIRL_HIP(hipMalloc((void**)&pi, sizeof(int64_t) * 2 * (size_t)cap));
+      MIRL_HIP(hipMalloc((void**)&pl, sizeof(float) * (size_t)cap));
+      h->allocs.push_back(pi); h->allocs.push_back(pl);
+      h->td_idx = pi; h->td_loss = pl; h->td_cap = cap;
+    }
+    {
+      ProfScope ps("k_acting_td", (double)K * (d.N * 5.0 + 2.0 * d.A * 4 + 28), st);
+      hipLaunchKernelGGL(k_acting_td, dim3((K + 255) / 256), dim3(256), 0, st, d, K, s_env, s_off, h->book.cfg.acting_vf_eps,
+                         h->td_idx, h->td_loss);
+    }
+    MIRL_LAUNCH_CHECK();
+    rc = update_losses_impl(h, K, h->td_idx, h->td_loss, st); if (rc) return rc;
+  }
   return h->staging.mark(st);
 }
 
@@ -954,7 +1008,7 @@ extern "C" int mirl_replay_profile(mirl_replay* h, int32_t enable, int64_t* laun
 // ---- snapshot / resume ------------------------------------------------------------
 namespace {
 const uint64_t kSnapMagic = 0x4D49524C534E4150ull;   // "MIRLSNAP"
-const uint32_t kSnapVersion = 1;
+const uint32_t kSnapVersion = 2;
 
 struct SnapIO {
   FILE* f = nullptr; char* pin = nullptr; size_t pin_bytes = 64u << 20; bool ok = true;
@@ -997,7 +1051,8 @@ bool same_config(const mirl_replay_config& a, const mirl_replay_config& b) {
          a.overlap == b.overlap && a.alpha == b.alpha && a.beta == b.beta && a.eps == b.eps &&
          a.max_weight_factor == b.max_weight_factor && a.beta_anneal_mode == b.beta_anneal_mode &&
          a.beta_anneal_to == b.beta_anneal_to && a.global_importance_scaling == b.global_importance_scaling &&
-         a.env_ring_slack == b.env_ring_slack;
+         a.env_ring_slack == b.env_ring_slack && a.acting_priority_init == b.acting_priority_init &&
+         a.acting_vf_eps == b.acting_vf_eps;
 }
 
 template <class F>
@@ -1103,12 +1158,17 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
   return MIRL_OK;
 }
 
+static int update_losses_impl(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, hipStream_t st);
+
 extern "C" int mirl_replay_update_losses(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, void* stream) {
   if (!h) return fail(MIRL_ERR_ARG, "null handle");
   if (!h->d.per || count <= 0) return MIRL_OK;           // history.py:332-335 no-op for non-prioritized buffers
   if (!indices || !losses) return fail(MIRL_ERR_ARG, "null indices/losses");
   if (count >= (1LL << 32)) return fail(MIRL_ERR_ARG, "too many loss rows");
-  hipStream_t st = (hipStream_t)stream;
+  return update_losses_impl(h, count, indices, losses, (hipStream_t)stream);
+}
+
+static int update_losses_impl(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, hipStream_t st) {
   Dev& d = h->d;
   uint64_t epoch = h->epoch++;
   unsigned g = (unsigned)((count + 255) / 256);

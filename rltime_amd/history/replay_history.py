@@ -168,7 +168,7 @@ class ReplayHistoryBuffer(History):
             overlap=_lib.INT32_MIN, alpha=0.6, beta=0.4, eps=1e-6,
             max_weight_factor=0.9, beta_anneal_mode=0, beta_anneal_to=1.0,
             global_importance_scaling=0, env_ring_slack=self._slack,
-            device=self._device_index)
+            device=self._device_index, acting_priority_init=0, acting_vf_eps=0.0)
         self._per_config(cfg)
         h = C.c_void_p()
         check(lib.mirl_replay_create(C.byref(cfg), C.byref(h)), "mirl_replay_create")
@@ -473,8 +473,19 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
 
     def __init__(self, alpha=0.6, beta=0.4, beta_anneal=False, eps=1e-6,
                  overlap=None, max_weight_factor=0.9,
-                 global_importance_scaling=False, **kwargs):
+                 global_importance_scaling=False, acting_priority_init=False,
+                 acting_priority_vf_eps=None, **kwargs):
+        """acting_priority_init / acting_priority_vf_eps are NOT reference arguments:
+        the reference notes acting-time priority initialisation as missing
+        (prioritized_replay_history.py:33-36).  When enabled, every ingested
+        transition initialises the priority input of the transition n steps before
+        it from the STORED q-values (include/mirl.h, mirl_replay_config) instead
+        of leaving it at the constant maximum 1.0 until the learner first sees it."""
         super().__init__(**kwargs)
+        self._acting_priority_init = bool(acting_priority_init)
+        self._acting_vf_eps = float(acting_priority_vf_eps or 0.0)
+        if self._acting_priority_init and not self._keep_policy:
+            raise ValueError("acting_priority_init needs the stored q-values: keep_policy_outputs must stay True")
         self._alpha, self._beta, self._beta_anneal = alpha, beta, beta_anneal
         self._eps, self._overlap = eps, overlap
         self._max_weight_factor = max_weight_factor
@@ -487,6 +498,8 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
         cfg.max_weight_factor = self._max_weight_factor
         cfg.overlap = _lib.INT32_MIN if self._overlap is None else int(self._overlap)
         cfg.global_importance_scaling = int(bool(self._global_importance_scaling))
+        cfg.acting_priority_init = int(self._acting_priority_init)
+        cfg.acting_vf_eps = self._acting_vf_eps
         if self._beta_anneal is False or self._beta_anneal is None:
             cfg.beta_anneal_mode = 0
         elif self._beta_anneal is True:

@@ -114,8 +114,10 @@ def load(trainer, base_dir):
     if h["last_beta"] is not None:
         hist.last_beta = h["last_beta"]
     if state["actors"] is not None and hasattr(trainer.actors, "set_state"):
+        # includes the training progress the actors were last TOLD about (their epsilon
+        # schedule runs on it; update_actors refreshes it only every
+        # actor_update_frequency_steps, multi_step_trainer.py:369-373)
         trainer.actors.set_state(state["actors"])
-    trainer.update_actors()
     # RNG streams last: nothing above may consume them afterwards
     rng = state["rng"]
     random.setstate(rng["python"])

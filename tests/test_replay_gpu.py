@@ -185,6 +185,51 @@ def test_wave_per_sequence_priorities_vs_oracle(T, P, n):
     assert m["draws"] == 5
 
 
+@pytest.mark.parametrize("T,P,n,vf", [(1, 0, 3, None), (8, 4, 2, 1e-3), (1, 0, 1, 1e-2), (16, 0, 5, None)])
+def test_acting_time_priority_initialisation_vs_oracle(T, P, n, vf):
+    """acting_priority_init (an extension: the reference lists it as missing,
+    prioritized_replay_history.py:33-36) against its restatement on the reference's
+    record structures (oracle.replay.OracleActingPriorityReplay): after every vector
+    step the tree holds the same leaf kinds, leaf values within 1e-6 (one float32
+    TD per transition: sqrt / pow roundings), the same free list; and no leaf input
+    is left at the constant 1.0 once its n-step target exists."""
+    from oracle import replay as orc
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    from tests.golden.streams import scalar_kind
+    E, gamma = 6, 0.97
+    spec = StreamSpec(seed=70 + T + n, num_envs=E, frame_shape=(1, 8, 8), lstm_units=4 if T > 1 else 0,
+                      n_actions=5, done_prob=0.08)
+    hist = dict(size=E * 40, train_frequency=0, nstep_target=n, nstep_train=T, prefix_steps=P,
+                alpha=0.7, beta=0.5, max_weight_factor=0.9)
+    ora = orc.OracleActingPriorityReplay(gamma=gamma, acting_priority_vf_eps=vf, **hist,
+                                         discount_function=orc.make_discount(gamma))
+    dev = PrioritizedReplayHistoryBuffer(**hist, gamma=gamma, acting_priority_init=True, acting_priority_vf_eps=vf)
+    worst = 0.0
+    for i, st in enumerate(vector_steps(spec, 90)):
+        ora.update(as_reference_samples(spec, st))
+        dev.update(as_reference_samples(spec, st))
+        if i % 7 and i < 80:
+            continue
+        v, k, _ = dev.tree_nodes()
+        cap = ora.tree.capacity
+        want = np.array([float(x) for x in ora.tree.nodes[cap:]])
+        wk = np.array([scalar_kind(x) for x in ora.tree.nodes[cap:]], dtype=np.uint8)
+        assert np.array_equal(k[cap:], wk), i
+        np.testing.assert_allclose(v[cap:], want, rtol=1e-6, atol=0, err_msg="step %d" % i)
+        live = want > 0
+        if live.any():
+            worst = max(worst, float(np.max(np.abs(v[cap:][live] - want[live]) / want[live])))
+        assert np.array_equal(dev.free_slots(), np.array(list(ora.free_slots)))
+    # sampling + a learner-side update_losses on top still agree (stratified indices included)
+    random.seed(5)
+    a = ora.get_train_data(4, 0.3)
+    random.seed(5)
+    b = dev.get_train_data(4, 0.3)
+    assert np.array_equal(scenario.to_numpy(b["extra_data"]["loss_indices"]), a["extra_data"]["loss_indices"])
+    print("acting-time priorities: max rel deviation of leaf values %.2e" % worst)
+    dev.close()
+
+
 def test_per_t1_vs_oracle_rainbow_shape():
     """Rainbow-shaped: T=1, n=3, f32 tree regime, beta anneal, many updates."""
     script = [("feed", 50)]
