@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
+    ap.add_argument("--frame-dedup", action="store_true", help="SURVEY 8(f)2: stack-consistent synthetic frames and de-duplicated "
+                    "storage (one 84x84 plane per transition in the ring, stacks rebuilt by the gather)")
     ap.add_argument("--train-arg", action="append", default=[], help="KEY=JSON extra training.args override (experiments)")
     ap.add_argument("--pmc-traffic", default=os.path.join(ROOT, "profiles", "gather_traffic.json"))
     return ap.parse_args()
@@ -109,6 +111,9 @@ def build_config(args, rank, world):
     for kv in args.train_arg:
         k, v = kv.split("=", 1)
         targs[k] = json.loads(v)
+    if args.frame_dedup:
+        targs["history_mode"]["args"]["frame_stack_dedup"] = True
+        config.setdefault("env_args", {})["frame_stack"] = True
     deep_dictionary_update(config, {"acting": {"actor_envs": args.envs or spec["envs"]}, "training": {"args": targs}})
     return shard_config(config, rank, world, args.scaling)
 
@@ -132,9 +137,10 @@ class SyntheticFeeder:
     pre-generated in HBM with the layout of one real acting step, without the
     policy forward."""
 
-    def __init__(self, probe, device, seed):
+    def __init__(self, probe, device, seed, stacked_env=None):
         from rltime_amd.acting.acting_interface import DeviceSamples
         self.cls = DeviceSamples
+        self.stacked_env = stacked_env        # frame de-dup: frames must follow the stack-shift contract
         self.envs, self.env_base, self.example = probe.num_envs, probe.env_base, probe.example_state
         step = probe.vector_steps[0]
         g = torch.Generator(device=device).manual_seed(seed)
@@ -167,7 +173,13 @@ class SyntheticFeeder:
         out = self.cls(self.example, self.envs, self.env_base)
         for _ in range(iters):
             self.t += 1
-            out.append(**self.pool[self.t % len(self.pool)])
+            fields = self.pool[self.t % len(self.pool)]
+            if self.stacked_env is not None:
+                obs, _, dones, _ = self.stacked_env.step_device(None)
+                fields = dict(fields, frames=obs, dones=dones.to(torch.uint8))
+                if "initials" in fields:
+                    fields["initials"] = dones.float()
+            out.append(**fields)
         return out
 
 
@@ -353,7 +365,8 @@ def main():
     t0 = time.time()
     probe = real_actors.get_samples(envs)                    # one real acting step: learns the transition layout
     hist.update(probe)
-    feeder = SyntheticFeeder(probe, device, seed=99 + rank)
+    feeder = SyntheticFeeder(probe, device, seed=99 + rank,
+                             stacked_env=real_actors._vec_env if args.frame_dedup else None)
     trainer.actors = feeder            # pre-generated actor output (no policy forward) for the fill
     per_call = 64 * envs
     fed = envs
@@ -430,6 +443,8 @@ def main():
         F = 4 * 84 * 84
         rows = hist._rows
         algo_bytes = 2.0 * rows * B * F
+        if args.frame_dedup:           # every stack written once, every distinct plane of a window read once
+            algo_bytes = rows * B * F + B * (rows + 3) * (F / 4.0)
         avg_ms = gather_ms / max(launches, 1)
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
         traffic, traffic_src = None, None
@@ -469,7 +484,7 @@ def main():
                 "workload": spec["workload"] + (" [%s scaling: %s]" % (
                     args.scaling, "global batch split over ranks" if args.scaling == "strong" else "per-rank batch fixed")),
                 "mbatch_per_gpu": B, "global_mbatch": B * world, "nstep_train": T, "burn_in": P, "nstep_target": n,
-                "frame": "(4,84,84) u8",
+                "frame": "(4,84,84) u8" + (" stack-consistent, stored de-duplicated (one 84x84 plane per transition)" if args.frame_dedup else ""),
                 "replay_transitions_per_gpu": hist_stats["total_items"],
                 "active_sequences_per_gpu": hist_stats["active_sequences"],
                 "tree_capacity": hist_stats["tree_capacity"] if per else None,
@@ -479,7 +494,7 @@ def main():
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world,
                 "replay_fill_seconds": round(fill_s, 2)},
             "roofline": {
-                "kernel": "k_gather_rows (frames)", "bound": "hbm",
+                "kernel": "k_gather_rows_dedup (frames)" if args.frame_dedup else "k_gather_rows (frames)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches": launches,

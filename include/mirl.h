@@ -82,6 +82,17 @@ typedef struct mirl_replay_config {
    * vector step was added.  acting_vf_eps <= 0: no value rescaling.               */
   int32_t acting_priority_init;
   double  acting_vf_eps;
+  /* Frame de-duplication in storage (the reference notes stacking support in the
+   * buffer as planned but unsupported, history.py:56-59).  stack_planes = P > 1:
+   * state["x"] is a stack of P equal planes, newest LAST, produced by the frame-
+   * stack wrapper's shift contract (env_wrappers/common.py:141-178: every step rolls
+   * the stack by one plane; a reset zero-fills all but the newest).  The ring then
+   * keeps ONE plane per transition (the newest) plus the number of real planes in
+   * its stack, P x less HBM per transition; the gather rebuilds the stacks while it
+   * writes the time-major batch, bit-identical to storing them whole.  Ingest
+   * verifies the contract against the stored planes; a frame that violates it makes
+   * the next host call fail with MIRL_ERR_STATE.  Needs frame_bytes % (16 P) == 0. */
+  int32_t stack_planes;
 } mirl_replay_config;
 
 /* One vector step handed to History.update: `count` transitions, transition k

@@ -54,6 +54,7 @@ class ReplayConfig(C.Structure):
         ("device", C.c_int32),
         ("acting_priority_init", C.c_int32),
         ("acting_vf_eps", C.c_double),
+        ("stack_planes", C.c_int32),
     ]
 
 

@@ -71,6 +71,7 @@ class Book {
   mirl_replay_config cfg;
   int32_t E = 0, T = 1, P = 0, N = 1, L = 1, gap = 1, overlap = 0;
   int64_t C = 0;            // ring slots per env
+  int64_t extra_keep = 0;   // slots behind the oldest live transition that must stay intact (frame de-dup)
   int64_t n_slots = 0;      // prioritized_replay_history.py:109 target_capacity
   int64_t tree_cap = 1;     // :110-112
   bool per = false;
@@ -93,7 +94,10 @@ class Book {
     L = T + P;
     per = c.mode == MIRL_MODE_PER;
     int64_t per_env = (c.size + E - 1) / E;
-    C = per_env + 1 + (c.env_ring_slack > 0 ? c.env_ring_slack : 0);
+    // de-duplicated frame storage rebuilds a stack from the P-1 predecessors' planes:
+    // they must outlive their (logically evicted) transitions
+    extra_keep = c.stack_planes > 1 ? c.stack_planes - 1 : 0;
+    C = per_env + 1 + (c.env_ring_slack > 0 ? c.env_ring_slack : 0) + extra_keep;
     first.assign(E, 0); count.assign(E, 0);
     env_seen.assign(E, 0); env_order.clear();
     fifo.init(c.size);
@@ -160,7 +164,7 @@ class Book {
       }
       fifo.push(e);                                    // replay_history.py:89
       if (cfg.train_frequency) quota += cfg.train_frequency;   // :90-91
-      if (count[e] - first[e] + 1 > C) { err = "per-env ring overflow (raise env_ring_slack: envs are not fed in lock-step)"; return MIRL_ERR_STATE; }
+      if (count[e] - first[e] + 1 + extra_keep > C) { err = "per-env ring overflow (raise env_ring_slack: envs are not fed in lock-step)"; return MIRL_ERR_STATE; }
       if (per) {
         // prioritized_replay_history.py:143-172
         int64_t f = first[e];

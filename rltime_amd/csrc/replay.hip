@@ -47,6 +47,8 @@ struct Dev {                 // passed by value to kernels
   int32_t* slot_env; int64_t* slot_base; uint8_t* flag;
   int32_t* dirty; int32_t* dirty_count;
   int64_t* first; int64_t* count;
+  int32_t planes, plane_bytes;   // frame de-dup: P planes per stack, bytes of one plane (0 = stacks stored whole)
+  uint8_t* depth;            // [E][C] real planes in the stack of each transition's next_state (de-dup)
   int32_t* bad;              // host-coherent flag: a sampled leaf was inactive (reference: assert, prioritized_replay_history.py:306)
   const double* gpow;        // gamma ** k, k < N, computed by the host libm like Python's float.__pow__
   double alpha, mwf, eps;
@@ -64,10 +66,10 @@ __device__ __forceinline__ int64_t slot_of(const Dev& d, int32_t e, int64_t off)
 __global__ void __launch_bounds__(256)
 k_scatter_rows(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
-               int64_t C, int32_t row_bytes, int64_t dst_stride, int vec) {
+               int64_t C, int32_t row_bytes, int64_t dst_stride, int vec, int64_t src_stride) {
   const int k = blockIdx.y;
   const int64_t slot = (int64_t)s_env[k] * C + s_off[k] % C;
-  const uint8_t* s = src + (int64_t)k * row_bytes;
+  const uint8_t* s = src + (int64_t)k * src_stride;
   uint8_t* t = dst + slot * dst_stride;
   if (vec) {
     const int n = row_bytes >> 4;
@@ -94,6 +96,50 @@ k_ingest_scalars(Dev d, int K, const int32_t* __restrict__ s_env, const int64_t*
     d.loss[sl] = MIRL_LOSS_FRESH;     // sample['loss'] = self._max_loss (python 1.0), prioritized_replay_history.py:141
     d.prio_index[sl] = -1;
     d.stamp[sl] = 0ull;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// frame de-duplication (mirl_replay_config.stack_planes)
+// ---------------------------------------------------------------------------
+// One workgroup per ingested transition: how many planes of its stack are real.
+// Plane P-1 is the new one; plane P-1-j must equal the newest plane stored with
+// the env's transition off-j (the wrapper rolled the stack), for j = 1.. until
+// the first mismatch; everything older must then be the zero fill of a reset
+// (env_wrappers/common.py:175-178).  Anything else violates the contract.
+__global__ void __launch_bounds__(256)
+k_dedup_depth(Dev d, const uint8_t* __restrict__ frames, const int32_t* __restrict__ s_env,
+              const int64_t* __restrict__ s_off) {
+  const int k = blockIdx.x;
+  const int32_t e = s_env[k];
+  const int64_t off = s_off[k];
+  const u32x4* stack = (const u32x4*)(frames + (int64_t)k * d.F);
+  const int nq = d.plane_bytes >> 4;
+  int depth = 1;
+  bool chain = true;
+  int violation = 0;
+  for (int j = 1; j < d.planes; ++j) {
+    const u32x4* mine = stack + (int64_t)(d.planes - 1 - j) * nq;
+    int same = 1, zero = 1;
+    const bool have = off - j >= 0;
+    // the env's first transitions have no stored predecessor: their older planes (the
+    // reset observation's) become VIRTUAL predecessors in the ring slots -1, -2, ...
+    // (mod C), which no live transition can occupy before they are out of reach
+    u32x4* theirs = (u32x4*)(d.frames + ((int64_t)e * d.C + ((off - j) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      u32x4 a = mine[q];
+      if (a.x | a.y | a.z | a.w) zero = 0;
+      if (have) { u32x4 b = theirs[q]; if ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) same = 0; }
+      else theirs[q] = a;
+    }
+    same = __syncthreads_and(same);
+    zero = __syncthreads_and(zero);
+    if (chain && same) ++depth;
+    else { chain = false; if (!zero) violation = 1; }
+  }
+  if (threadIdx.x == 0) {
+    d.depth[slot_of(d, e, off)] = (uint8_t)depth;
+    if (violation) *(volatile int32_t*)d.bad = 2;
   }
 }
 
@@ -390,6 +436,42 @@ k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ 
   if (h0) __builtin_nontemporal_store(w0, t4 + c);
   if (h1) __builtin_nontemporal_store(w1, t4 + c + 512);
   if (h2) __builtin_nontemporal_store(w2, t4 + c + 1024);
+}
+
+// out[r][b] = the P-plane stack of ring transition src(r, b), rebuilt from the
+// newest planes of that transition and its P-1 predecessors (zero fill beyond the
+// recorded depth).  Same launch shape as the whole-frame gather: 512 lanes per
+// 28 KB row, 16 B per lane, all loads of the row issued before the first store.
+__global__ void __launch_bounds__(512)
+k_gather_rows_dedup(Dev d, uint8_t* __restrict__ out, const int32_t* __restrict__ env,
+                    const int64_t* __restrict__ start, int B, int overlapped) {
+  const int64_t rb = blockIdx.x;
+  const int r = (int)(rb / B), b = (int)(rb % B);
+  int32_t e = env[b];
+  if (e < 0 || e >= d.E) e = 0;
+  const int64_t o = row_src_off(d, overlapped, r, e, start[b]);
+  const int dep = d.depth[slot_of(d, e, o)];
+  const int nq = d.plane_bytes >> 4, n = nq * d.planes;
+  u32x4* t4 = (u32x4*)(out + rb * (int64_t)d.F);
+  const uint8_t* ring0 = d.frames + (int64_t)e * d.C * d.plane_bytes;
+  u32x4 v[4]; int c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[k] = threadIdx.x + k * 512;
+    v[k] = u32x4{0u, 0u, 0u, 0u};
+    if (c[k] < n) {
+      const int p = c[k] / nq, q = c[k] - p * nq, back = d.planes - 1 - p;
+      if (back < dep) v[k] = __builtin_nontemporal_load((const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (c[k] < n) __builtin_nontemporal_store(v[k], t4 + c[k]);
+  for (int cc = threadIdx.x + 2048; cc < n; cc += 512) {       // stacks larger than 32 KB
+    const int p = cc / nq, q = cc - p * nq, back = d.planes - 1 - p;
+    u32x4 w = u32x4{0u, 0u, 0u, 0u};
+    if (back < dep) w = __builtin_nontemporal_load((const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+    __builtin_nontemporal_store(w, t4 + cc);
+  }
 }
 
 // Per-step scalars of the batch.  One lane per (t, b):
@@ -690,6 +772,8 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   if (!cfg || !out) return fail(MIRL_ERR_ARG, "null argument");
   if (mirl_device_count() <= 0) return fail(MIRL_ERR_NOGPU, "no HIP device visible: librltime_hip needs an AMD GPU (there is no CPU fallback)");
   if (cfg->frame_bytes <= 0) return fail(MIRL_ERR_ARG, "frame_bytes must be > 0");
+  if (cfg->stack_planes > 1 && (cfg->frame_bytes % (16 * cfg->stack_planes)))
+    return fail(MIRL_ERR_ARG, "stack_planes: frame_bytes must be a multiple of 16 * stack_planes");
   if (cfg->acting_priority_init && (cfg->mode != MIRL_MODE_PER || cfg->policy_f32 <= 0))
     return fail(MIRL_ERR_ARG, "acting_priority_init needs prioritized replay and stored q-values (policy_f32 = number of actions)");
   MIRL_HIP(hipSetDevice(cfg->device));
@@ -702,6 +786,10 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   Dev& d = h->d;
   memset(&d, 0, sizeof(d));
   d.E = bk.E; d.F = cfg->frame_bytes; d.Fp = (int32_t)align_up((size_t)cfg->frame_bytes, 16);
+  if (cfg->stack_planes > 1) {
+    d.planes = cfg->stack_planes; d.plane_bytes = cfg->frame_bytes / cfg->stack_planes;
+    d.Fp = d.plane_bytes;                                  // the ring keeps one plane per transition
+  }
   d.X = cfg->extra_f32; d.S = cfg->state_f32; d.A = cfg->policy_f32; d.has_init = cfg->has_initials;
   d.per = bk.per; d.T = bk.T; d.P = bk.P; d.N = bk.N; d.L = bk.L; d.gap = bk.gap; d.env_base = cfg->env_base;
   d.avoid_xing = cfg->avoid_episode_crossing; d.C = bk.C; d.cap = bk.tree_cap; d.n_slots = bk.n_slots;
@@ -717,6 +805,7 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   TRY(dev_alloc(h, &d.policy, slots * (size_t)d.A));
   TRY(dev_alloc(h, &d.rewards, slots));
   TRY(dev_alloc(h, &d.dones, slots));
+  if (d.planes) TRY(dev_alloc(h, &d.depth, slots));
   TRY(dev_alloc(h, &d.first, (size_t)d.E));
   TRY(dev_alloc(h, &d.count, (size_t)d.E));
   {
@@ -768,14 +857,15 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
 }
 
 static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s_env, const int64_t* s_off,
-                   int K, int32_t row_bytes, int64_t stride, hipStream_t st) {
+                   int K, int32_t row_bytes, int64_t stride, hipStream_t st, int64_t src_stride = 0) {
   if (!row_bytes || !src) return MIRL_OK;
-  int vec = (row_bytes % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)src) % 16 == 0);
+  if (!src_stride) src_stride = row_bytes;
+  int vec = (row_bytes % 16 == 0) && (stride % 16 == 0) && (((uintptr_t)src) % 16 == 0) && (src_stride % 16 == 0);
   int chunks = vec ? row_bytes / 16 : row_bytes;
   int gx = (chunks + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
   ProfScope ps(row_bytes >= 8192 ? "k_scatter_rows(frames)" : "k_scatter_rows(small rows)", 2.0 * K * row_bytes, st);
   hipLaunchKernelGGL(k_scatter_rows, dim3(gx, K), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)ring, s_env, s_off,
-                     h->d.C, row_bytes, stride, vec);
+                     h->d.C, row_bytes, stride, vec, src_stride);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
@@ -809,7 +899,20 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   rc = h->staging.upload(total, st); if (rc) return rc;
   const int32_t* s_env = (const int32_t*)(db + o_env);
   const int64_t* s_off = (const int64_t*)(db + o_off);
-  rc = scatter(h, in->frames, d.frames, s_env, s_off, K, d.F, d.Fp, st); if (rc) return rc;
+  if (d.planes) {
+    // de-dup: verify the stack-shift contract against the stored planes, record the
+    // depth, keep the newest plane only
+    if (((uintptr_t)in->frames) % 16) return fail(MIRL_ERR_ARG, "stack_planes: the frames array must be 16-byte aligned");
+    {
+      ProfScope ps("k_dedup_depth", (double)K * (2.0 * d.F - d.plane_bytes), st);
+      hipLaunchKernelGGL(k_dedup_depth, dim3(K), dim3(256), 0, st, d, in->frames, s_env, s_off);
+    }
+    MIRL_LAUNCH_CHECK();
+    rc = scatter(h, in->frames + (size_t)(d.planes - 1) * d.plane_bytes, d.frames, s_env, s_off, K, d.plane_bytes, d.plane_bytes, st, d.F);
+    if (rc) return rc;
+  } else {
+    rc = scatter(h, in->frames, d.frames, s_env, s_off, K, d.F, d.Fp, st); if (rc) return rc;
+  }
   rc = scatter(h, in->extra, d.extra, s_env, s_off, K, d.X * 4, (int64_t)d.X * 4, st); if (rc) return rc;
   rc = scatter(h, in->state, d.state, s_env, s_off, K, d.S * 4, (int64_t)d.S * 4, st); if (rc) return rc;
   rc = scatter(h, in->policy, d.policy, s_env, s_off, K, d.A * 4, (int64_t)d.A * 4, st); if (rc) return rc;
@@ -891,6 +994,10 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
   hipStream_t st = (hipStream_t)stream;
   Book& bk = h->book;
   Dev& d = h->d;
+  if (h->bad_host && *h->bad_host == 2) {
+    *h->bad_host = 0;
+    return fail(MIRL_ERR_STATE, "stack_planes: an ingested frame violates the frame-stack shift contract (env_wrappers/common.py:141-178): its older planes are neither the previous frames nor a reset's zero fill");
+  }
   if (h->bad_host && *h->bad_host) {
     *h->bad_host = 0;
     return fail(MIRL_ERR_STATE, "an earlier sample call drew an inactive tree leaf (prioritized_replay_history.py:306 asserts base_sample is not None); those rows were given weight 0 and no loss index");
@@ -1052,7 +1159,7 @@ bool same_config(const mirl_replay_config& a, const mirl_replay_config& b) {
          a.max_weight_factor == b.max_weight_factor && a.beta_anneal_mode == b.beta_anneal_mode &&
          a.beta_anneal_to == b.beta_anneal_to && a.global_importance_scaling == b.global_importance_scaling &&
          a.env_ring_slack == b.env_ring_slack && a.acting_priority_init == b.acting_priority_init &&
-         a.acting_vf_eps == b.acting_vf_eps;
+         a.acting_vf_eps == b.acting_vf_eps && a.stack_planes == b.stack_planes;
 }
 
 template <class F>
@@ -1067,6 +1174,7 @@ void snap_device_arrays(mirl_replay* h, F&& io) {
   io(d.policy, slots * (size_t)d.A * 4);
   io(d.rewards, slots * 4);
   io(d.dones, slots);
+  io(d.depth, d.planes ? slots : 0);
   io(d.first, (size_t)d.E * 8);
   io(d.count, (size_t)d.E * 8);
   if (d.per) {
@@ -1141,7 +1249,22 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
   hipStream_t st = (hipStream_t)stream;
   Dev& d = h->d;
   int rc;
-  rc = gather_leaf(h, d.frames, out->frames, env, start, B, d.F, d.Fp, st); if (rc) return rc;
+  if (d.planes) {
+    if (((uintptr_t)out->frames) % 16) return fail(MIRL_ERR_ARG, "stack_planes: the frames output must be 16-byte aligned");
+    const int64_t blocks = (int64_t)h->rows * B;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) { MIRL_HIP(hipEventCreate(&e0)); MIRL_HIP(hipEventCreate(&e1)); MIRL_HIP(hipEventRecord(e0, st)); }
+    {
+      // algorithmic bytes: every output stack written once + every distinct plane of a
+      // window read once (rows + P - 1 planes per sequence and state block)
+      ProfScope ps("k_gather_rows_dedup(frames)", (double)blocks * d.F + (double)B * (h->rows + d.planes - 1) * d.plane_bytes, st);
+      hipLaunchKernelGGL(k_gather_rows_dedup, dim3((unsigned)blocks), dim3(512), 0, st, d, out->frames, env, start, B, h->overlapped);
+    }
+    MIRL_LAUNCH_CHECK();
+    if (h->prof) { MIRL_HIP(hipEventRecord(e1, st)); h->prof_events.push_back(std::make_pair(e0, e1)); }
+  } else {
+    rc = gather_leaf(h, d.frames, out->frames, env, start, B, d.F, d.Fp, st); if (rc) return rc;
+  }
   rc = gather_leaf(h, d.extra, out->extra, env, start, B, d.X * 4, (int64_t)d.X * 4, st); if (rc) return rc;
   rc = gather_leaf(h, d.state, out->state, env, start, B, d.S * 4, (int64_t)d.S * 4, st); if (rc) return rc;
   mirl_batch o = *out;

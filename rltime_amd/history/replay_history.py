@@ -122,8 +122,15 @@ class ReplayHistoryBuffer(History):
 
     def __init__(self, size, train_frequency, avoid_episode_crossing=False,
                  num_envs=None, env_base=None, device=None, device_rng=False,
-                 keep_policy_outputs=True, env_ring_slack=0, **kwargs):
+                 keep_policy_outputs=True, env_ring_slack=0, frame_stack_dedup=False, **kwargs):
+        """frame_stack_dedup (not a reference argument; the reference notes buffer-side
+        stacking support as planned, history.py:56-59): True = the observation's leading
+        axis is a frame stack produced by the stack-shift contract of
+        env_wrappers/common.py:141-178 (an int gives the number of planes explicitly);
+        the shard then stores one plane per transition and rebuilds the stacks in the
+        gather (include/mirl.h, mirl_replay_config.stack_planes)."""
         super().__init__(**kwargs)
+        self._dedup = frame_stack_dedup
         _lib.require_gpu()
         self.size = size
         if train_frequency and float(train_frequency) != int(train_frequency):
@@ -168,7 +175,9 @@ class ReplayHistoryBuffer(History):
             overlap=_lib.INT32_MIN, alpha=0.6, beta=0.4, eps=1e-6,
             max_weight_factor=0.9, beta_anneal_mode=0, beta_anneal_to=1.0,
             global_importance_scaling=0, env_ring_slack=self._slack,
-            device=self._device_index, acting_priority_init=0, acting_vf_eps=0.0)
+            device=self._device_index, acting_priority_init=0, acting_vf_eps=0.0,
+            stack_planes=0 if not self._dedup else
+            (int(layout.frame_shape[0]) if self._dedup is True else int(self._dedup)))
         self._per_config(cfg)
         h = C.c_void_p()
         check(lib.mirl_replay_create(C.byref(cfg), C.byref(h)), "mirl_replay_create")

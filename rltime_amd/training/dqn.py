@@ -42,6 +42,7 @@ class DQN(TorchTrainer):
             return
         idx = extra_train_data["loss_indices"]
         assert losses.shape == idx.shape[:1]
+        self._pre_update_losses()
         self.history_buffer.update_losses(idx, losses)
 
     def _weights(self, extra_data):

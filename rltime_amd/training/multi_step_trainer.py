@@ -104,8 +104,12 @@ class MultiStepTrainer(PolicyTrainer):
     def _train(self, gamma, nstep_train, lr, history_mode, mbatch_size=None, nstep_target=None,
                lr_anneal=False, epochs=1, minibatches=1, warmup_steps=0,
                actor_update_frequency_steps=1000, burn_in_timesteps=0, rnn_steps_train=None,
-               rnn_bootstrap=False, async_history=False):
-        """multi_step_trainer.py:152-379."""
+               rnn_bootstrap=False, async_history=False, overlap_acting=False):
+        """multi_step_trainer.py:152-379.  overlap_acting (not in the reference): run the
+        acting + ingest of iteration k+1 on a second HIP stream while iteration k trains
+        (see _loop_iteration_overlapped)."""
+        self.overlap_acting = overlap_acting     # True | "serial" (same schedule on ONE stream: race check)
+        self._ov = None
         self.train_init(lr)
         self.gamma = gamma
         self.lr = self.base_lr = lr
@@ -131,6 +135,8 @@ class MultiStepTrainer(PolicyTrainer):
         self.rnn_steps_train = rnn_steps_train or nstep_train
         assert (not burn_in_timesteps) or self.policy.is_recurrent(), \
             "burn_in_timesteps only makes sense for recurrent policies"
+        if self.overlap_acting and getattr(self.actors, "_device_mode", False):
+            self._ov_setup()
         if self.resume_from:
             from . import resume
             resume.load(self, self.resume_from)
@@ -158,7 +164,133 @@ class MultiStepTrainer(PolicyTrainer):
             self.save_full_checkpoint()
         return stepped
 
+    # -- acting overlapped with learning ------------------------------------------------
+    # The reference's loop is strictly serial: act -> ingest -> sample -> train.  Its
+    # own answer to the idle time is process-level asynchrony (async actors that run
+    # on weights `actor_update_frequency_steps` old, parallel_history.py's 3-deep
+    # prefetch).  The device equivalent is one more HIP stream: the ~40 launch-bound
+    # acting vector steps of iteration k+1 (E=256 policy forwards, epsilon-greedy, env
+    # step, ingest) fill the gaps of iteration k's large GEMMs instead of running
+    # alone for ~18 ms.  Ordering, all by events (no host synchronisation):
+    #   gather(k) done          -> ingest(k+1) may overwrite ring slots / touch the tree
+    #   acting+ingest(k+1) done -> update_losses(k) (tree), Adam(k) -> actor weight copy,
+    #                              sample(k+1)
+    # The actor therefore runs on a copy of the weights that is ONE learner step older
+    # than the reference's synchronous actor would use, and target-network syncs / log
+    # rows triggered by the feed of iteration k+1 are applied at the start of iteration
+    # k+1 (where the reference applies them), not when the feed is enqueued.
+    def _ov_setup(self):
+        ov = self._ov = {}
+        ov["stream"] = torch.cuda.current_stream() if self.overlap_acting == "serial" else torch.cuda.Stream()
+        ov["act_done"] = torch.cuda.Event()
+        ov["gather_done"] = torch.cuda.Event()
+        ov["weights_ready"] = torch.cuda.Event()
+        obs_space, act_space = self.actors.get_spaces()
+        actor_policy = self.create_policy(model_config=self.model_config, observation_space=obs_space,
+                                          action_space=act_space, **self.policy_args)
+        actor_policy.copy_from(self.policy)
+        for p in actor_policy.parameters():
+            p.requires_grad_(False)
+        ov["actor_policy"] = actor_policy
+        self.actors.set_actor_policy(actor_policy)
+        ov["weights_ready"].record()
+        ov["fed"] = False
+        ov["deferred"] = None
+
+    def _ov_feed(self, count):
+        """Acting + ingest for `count` transitions on the acting stream; the step
+        counters advance now, target sync / logging are handed back as deferred work."""
+        ov = self._ov
+        main = torch.cuda.current_stream()
+        ov["stream"].wait_event(ov["weights_ready"])
+        ov["stream"].wait_event(ov["gather_done"])
+        self._start_timer("sample_actors")
+        with torch.cuda.stream(ov["stream"]):
+            samples = self.actors.get_samples(count)
+            if samples:
+                self._process_new_samples(samples)
+                self.history_buffer.update(samples)
+            ov["act_done"].record(ov["stream"])
+        self._end_timer()
+        assert torch.cuda.current_stream() == main
+        if not samples:
+            return
+        from .policy_trainer import _crossed
+        before = self.steps
+        self.steps += len(samples)
+        self.clock.acted += len(samples)
+        ov["deferred"] = (_crossed(before, self.steps, self.target_update_freq),
+                          _crossed(before, self.steps, self.log_freq))
+
+    def _ov_apply_deferred(self):
+        d, self._ov["deferred"] = self._ov["deferred"], None
+        if d is None:
+            return
+        if d[0]:
+            self.sync_target()
+        if d[1]:
+            self._log_checkpoint()
+            self._full_checkpoint_due = self.full_checkpoints
+
+    def _pre_update_losses(self):
+        """Called by the trainers right before history.update_losses: the priority
+        tree must not be touched while the overlapped ingest is still running."""
+        if self._ov is not None:
+            torch.cuda.current_stream().wait_event(self._ov["act_done"])
+
+    def _loop_iteration_overlapped(self):
+        ov = self._ov
+        main = torch.cuda.current_stream()
+        progress = self.get_train_progress()
+        warming_up = self.steps < self.warmup_steps
+        env_count = self.actors.get_env_count()
+        if not ov["fed"]:
+            # prologue (and every time a batch could not be formed): feed in the reference's order
+            need = self.history_buffer.needed_feed_count(self.mbatch_size, env_count)
+            if need is not None:
+                if warming_up:
+                    need = max(need, env_count)
+                ov["gather_done"].record(main)
+                self._ov_feed(need)
+        self._ov_apply_deferred()
+        ov["fed"] = False
+        main.wait_event(ov["act_done"])
+        self._start_timer("get_train_data")
+        train_data = self.history_buffer.get_train_data(self.mbatch_size, train_progress=progress)
+        if self.data_parallel is not None and not self.data_parallel.all_ready(train_data is not None):
+            train_data = None
+        if train_data is None:
+            return False
+        ov["gather_done"].record(main)
+        self._end_timer()
+        if warming_up:
+            return False
+        # the next iteration's acting + ingest, concurrent with this iteration's training
+        need = self.history_buffer.needed_feed_count(self.mbatch_size, env_count)
+        if need is not None:
+            self._ov_feed(need)
+            ov["fed"] = True
+        self.learner_step(train_data, self.nstep_train, self.nstep_target, self.burn_in_timesteps,
+                          self.rnn_steps_train, self.rnn_bootstrap, self.epochs, self.minibatches)
+        # refresh the actor's weight copy (after the acting that is in flight finished with it)
+        main.wait_event(ov["act_done"])
+        ov["actor_policy"].copy_from(self.policy)
+        ov["weights_ready"].record(main)
+        if self.lr_anneal not in (False, None):
+            anneal_to = 0.0 if self.lr_anneal is True else float(self.lr_anneal)
+            self.lr = self.base_lr - progress * (self.base_lr - anneal_to)
+            self.set_lr(self.lr)
+        self.value_log.log("lr", self.lr, group="train")
+        if not self.actor_update_frequency_steps or \
+                self.steps - self._actors_last_update_steps >= self.actor_update_frequency_steps:
+            self.update_actors()
+            self._actors_last_update_steps = self.steps
+        self._end_timer()
+        return True
+
     def _loop_iteration(self):
+        if self._ov is not None and getattr(self.actors, "_device_mode", False):
+            return self._loop_iteration_overlapped()
         progress = self.get_train_progress()
         warming_up = self.steps < self.warmup_steps
         env_count = self.actors.get_env_count()

@@ -13,7 +13,7 @@ import numpy as np
 class StreamSpec:
     def __init__(self, seed, num_envs, frame_shape=(2, 3, 3), lstm_units=0,
                  n_actions=4, done_prob=0.1, fractional_rewards=True,
-                 env_base=0, extra_features=0):
+                 env_base=0, extra_features=0, stacked=False):
         self.seed = seed
         self.num_envs = num_envs
         self.frame_shape = tuple(frame_shape)
@@ -25,6 +25,11 @@ class StreamSpec:
         # >0: tuple observation (frame, extra f32 vector), as the reference's
         # ExtraFeaturesEnvWrapper produces (env_wrappers/common.py)
         self.extra_features = extra_features
+        # True: frames follow the frame-stack wrapper's shift contract (reference
+        # env_wrappers/common.py:141-178 under an auto-resetting vec env): the leading
+        # axis is a window of planes, newest last; every step rolls it by one plane, a
+        # `done` step returns the reset observation (zeros + the new plane)
+        self.stacked = stacked
 
 
 def frame_for(env, offset, shape):
@@ -35,16 +40,44 @@ def frame_for(env, offset, shape):
     return v.astype(np.uint8).reshape(shape)
 
 
+def _advance_stacks(spec, stacks, s, dones):
+    plane = spec.frame_shape[1:]
+    for e in range(spec.num_envs):
+        new = frame_for(spec.env_base + e, s, plane)
+        if dones[e]:
+            stacks[e] = 0                      # WindowedEnv.reset: zeros, then the first frame
+        else:
+            stacks[e, :-1] = stacks[e, 1:]     # np.roll by one plane
+        stacks[e, -1] = new
+
+
 def vector_steps(spec, count, start_step=0):
     """Yield ``count`` vector steps as dicts of (E, ...) arrays.  Step ``s`` of
     env ``e`` is transition offset ``s`` of that env."""
     E = spec.num_envs
     palette = np.array([-1.0, 0.0, 0.0, 0.0, 1.0, 0.5, 0.25, 2.0]) \
         if spec.fractional_rewards else np.array([-1.0, 0.0, 0.0, 1.0])
+    stacks = None
+    if spec.stacked:
+        plane = spec.frame_shape[1:]
+        # reset observation: zeros + the reset frame (identity offset -1); then replay
+        # the steps before start_step (dones are a pure function of (seed, step))
+        stacks = np.zeros((E,) + spec.frame_shape, dtype=np.uint8)
+        for e in range(E):
+            stacks[e, -1] = frame_for(spec.env_base + e, -1, plane)
+        for s in range(start_step):
+            dones = np.random.RandomState((spec.seed * 1000003 + s) % (2 ** 31))
+            dones.randint(0, len(palette), size=E)
+            dones = dones.rand(E) < spec.done_prob
+            _advance_stacks(spec, stacks, s, dones)
     for s in range(start_step, start_step + count):
         rng = np.random.RandomState((spec.seed * 1000003 + s) % (2 ** 31))
+        if spec.stacked:
+            peek = np.random.RandomState((spec.seed * 1000003 + s) % (2 ** 31))
+            peek.randint(0, len(palette), size=E)
+            _advance_stacks(spec, stacks, s, peek.rand(E) < spec.done_prob)
         out = {
-            "frames": np.stack([
+            "frames": stacks.copy() if spec.stacked else np.stack([
                 frame_for(spec.env_base + e, s, spec.frame_shape)
                 for e in range(E)]),
             "rewards": palette[rng.randint(0, len(palette), size=E)],

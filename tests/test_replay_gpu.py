@@ -86,7 +86,7 @@ def test_tree_cases_on_device():
         buf.close()
 
 
-def _run_pair(seed, E, steps_script, hist, gamma, per, spec_kw, B):
+def _run_pair(seed, E, steps_script, hist, gamma, per, spec_kw, B, dev_kw=None):
     """Same seeded stream through the oracle and the HIP buffer."""
     from oracle import replay as orc
     from rltime_amd.history import ReplayHistoryBuffer, PrioritizedReplayHistoryBuffer
@@ -94,7 +94,7 @@ def _run_pair(seed, E, steps_script, hist, gamma, per, spec_kw, B):
     o_cls = orc.OraclePrioritizedReplay if per else orc.OracleReplay
     d_cls = PrioritizedReplayHistoryBuffer if per else ReplayHistoryBuffer
     ora = o_cls(**hist, discount_function=orc.make_discount(gamma))
-    dev = d_cls(**hist, gamma=gamma)
+    dev = d_cls(**hist, gamma=gamma, **(dev_kw or {}))
     step_no = 0
     mism = {"leaf": 0, "leaves": 0, "draws": 0}
     for op in steps_script:
@@ -228,6 +228,51 @@ def test_acting_time_priority_initialisation_vs_oracle(T, P, n, vf):
     assert np.array_equal(scenario.to_numpy(b["extra_data"]["loss_indices"]), a["extra_data"]["loss_indices"])
     print("acting-time priorities: max rel deviation of leaf values %.2e" % worst)
     dev.close()
+
+
+def test_frame_dedup_uniform_atari_frames_vs_oracle():
+    """frame_stack_dedup: the shard keeps ONE 84x84 plane per transition; the oracle
+    (reference algorithm) is fed and stores the whole (4,84,84) stacks of a
+    stack-consistent stream (resets included).  Every gathered batch must be
+    bit-identical, through ring wrap and eviction (size 1024 over 8 envs)."""
+    _run_pair(51, 8, [("feed", 40), ("draw", 1, None), ("feed", 200), ("draw", 2, None),
+                      ("feed", 77), ("draw", 3, None), ("feed", 130), ("draw", 4, None)],
+              dict(size=1024, train_frequency=0, nstep_target=1, nstep_train=1, prefix_steps=0),
+              0.99, False, dict(frame_shape=(4, 84, 84), n_actions=6, done_prob=0.02, stacked=True), 64,
+              dev_kw=dict(frame_stack_dedup=True))
+
+
+@pytest.mark.parametrize("noxing", [False, True])
+def test_frame_dedup_per_sequences_vs_oracle(noxing):
+    """De-duplicated storage under prioritized sequence replay: overlapped
+    (states / target_states views of one block) and separate (avoid_episode_crossing)
+    layouts, recurrent state, eviction; frames, n-step scalars, indices, priorities
+    all as with whole-stack storage."""
+    m = _run_pair(52, 6, [("feed", 60), ("draw", 11, 0.0), ("feed", 30), ("draw", 12, 0.2),
+                          ("draw", 13, 0.3), ("feed", 120), ("draw", 14, 0.5), ("feed", 45),
+                          ("draw", 15, 0.8), ("draw", 16, 1.0)],
+                  dict(size=900, train_frequency=4, nstep_target=2, nstep_train=16, prefix_steps=8,
+                       alpha=0.9, beta=0.6, max_weight_factor=0.9, avoid_episode_crossing=noxing),
+                  0.997, True, dict(frame_shape=(4, 8, 8), lstm_units=32, n_actions=6, done_prob=0.05, stacked=True), 16,
+                  dev_kw=dict(frame_stack_dedup=True))
+    assert m["draws"] == 6
+
+
+def test_frame_dedup_rejects_frames_that_break_the_stack_contract():
+    from rltime_amd import _lib
+    from rltime_amd.history import ReplayHistoryBuffer
+    spec = StreamSpec(seed=9, num_envs=4, frame_shape=(4, 8, 8), n_actions=4, done_prob=0.0, stacked=False)
+    buf = ReplayHistoryBuffer(size=64, train_frequency=0, nstep_target=1, nstep_train=1, gamma=0.9, frame_stack_dedup=True)
+    for st in vector_steps(spec, 6):                    # unrelated frames every step: not a shifted stack
+        buf.update(as_reference_samples(spec, st))
+    np.random.seed(0)
+    with pytest.raises(_lib.MirlError, match="shift contract"):
+        buf.get_train_data(2)
+    buf.close()
+    with pytest.raises(_lib.MirlError, match="multiple of 16"):
+        b2 = ReplayHistoryBuffer(size=64, train_frequency=0, nstep_target=1, nstep_train=1, gamma=0.9, frame_stack_dedup=True)
+        s2 = StreamSpec(seed=9, num_envs=2, frame_shape=(4, 3, 3), stacked=True)
+        b2.update(as_reference_samples(s2, next(vector_steps(s2, 1))))
 
 
 def test_per_t1_vs_oracle_rainbow_shape():
