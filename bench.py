@@ -196,60 +196,62 @@ def seed_priorities(hist, device, chunk=1 << 18):
             hist.update_losses(idx, torch.randn(o.numel(), device=device, generator=g).abs() + 1e-6)
 
 
-def cpu_baseline(args, seconds):
+class CpuPath:
     """The oracle — the reference's algorithm class (per-transition records,
-    np.stack batch assembly, torch-CPU fwd/bwd) — on bounded samples of the
-    config-D workload, scaled linearly in B to B=512.  Headline leg: 1 torch
-    thread, what the reference runs with (models/torch/torch_model.py:25 calls
-    torch.set_num_threads(1)); second leg: all host cores."""
-    from oracle import replay as orc
-    from oracle import qmath
-    from oracle.replay import tree_map
-    from rltime_amd.general.config import load_config
-    from rltime_amd.models.torch.utils import make_tensor
-    from rltime_amd.policies.iqn import IQNPolicy
-    from rltime_amd.spaces import Box, Discrete
-    nproc = os.cpu_count() or 1
-    T, P, n = 80, 40, 2
-    B_full = 512
-    E, H, A = 8, 512, 6
-    config = load_config("synthetic_atari_iqn_lstm.json")
-    torch.set_num_threads(1)
-    mk = lambda: IQNPolicy.create(model_config=config["model"], observation_space=Box(0, 255, (4, 84, 84), np.uint8),  # noqa: E731
-                                  action_space=Discrete(A), cuda=False, **config["policy_args"])
-    policy, target = mk(), mk()
-    opt = torch.optim.Adam(policy.parameters(), eps=1e-5)
-    buf = orc.OraclePrioritizedReplay(
-        size=E * 500, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
-        alpha=0.9, beta=0.6, max_weight_factor=0.9, discount_function=orc.make_discount(0.99))
-    rng = np.random.RandomState(0)
-    frame_pool = [rng.randint(0, 256, (4, 84, 84)).astype(np.uint8) for _ in range(64)]
-    t0 = time.time()
-    fed = 0
-    for s in range(400):
-        samples = []
-        for e in range(E):
-            samples.append({
-                "policy_output": {"actions": int(rng.randint(A))},
-                "next_state": {"x": frame_pool[(s * E + e) % 64].copy(), "layer0_state": {},
-                               "layer1_state": {"hx": rng.randn(H).astype(np.float32), "cx": rng.randn(H).astype(np.float32),
-                                                "initials": np.float32(rng.rand() < 0.002)},
-                               "layer2_state": {}},
-                "reward": float(rng.choice([-1.0, 0.0, 1.0], p=[.1, .8, .1])), "done": bool(rng.rand() < 0.002),
-                "info": {}, "env_id": e})
-        buf.update(samples)
-        fed += E
-    ingest_rate = fed / (time.time() - t0)
+    np.stack batch assembly, torch-CPU fwd/bwd) — set up for the config-D workload
+    (T=80, burn-in 40, n=2, nature CNN + LSTM512 + IQN head).  `learner_step(B)` is
+    one pass of multi_step_trainer.py:278-353 over a batch of B sequences."""
 
-    def flat(x):
-        return x.reshape((x.shape[0] * x.shape[1],) + x.shape[2:])
+    T, P, n, E, H, A = 80, 40, 2, 8, 512, 6
 
-    def tt(tree):
-        return make_tensor(tree, "cpu")
+    def __init__(self, fill_steps=400):
+        from oracle import replay as orc
+        from rltime_amd.general.config import load_config
+        from rltime_amd.policies.iqn import IQNPolicy
+        from rltime_amd.spaces import Box, Discrete
+        T, P, n, E, H, A = self.T, self.P, self.n, self.E, self.H, self.A
+        config = load_config("synthetic_atari_iqn_lstm.json")
+        torch.set_num_threads(1)
+        mk = lambda: IQNPolicy.create(model_config=config["model"], observation_space=Box(0, 255, (4, 84, 84), np.uint8),  # noqa: E731
+                                      action_space=Discrete(A), cuda=False, **config["policy_args"])
+        self.policy, self.target = mk(), mk()
+        self.opt = torch.optim.Adam(self.policy.parameters(), eps=1e-5)
+        self.buf = orc.OraclePrioritizedReplay(
+            size=E * 500, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
+            alpha=0.9, beta=0.6, max_weight_factor=0.9, discount_function=orc.make_discount(0.99))
+        self.rng = rng = np.random.RandomState(0)
+        frame_pool = [rng.randint(0, 256, (4, 84, 84)).astype(np.uint8) for _ in range(64)]
+        t0 = time.time()
+        fed = 0
+        for s in range(fill_steps):
+            samples = []
+            for e in range(E):
+                samples.append({
+                    "policy_output": {"actions": int(rng.randint(A))},
+                    "next_state": {"x": frame_pool[(s * E + e) % 64].copy(), "layer0_state": {},
+                                   "layer1_state": {"hx": rng.randn(H).astype(np.float32), "cx": rng.randn(H).astype(np.float32),
+                                                    "initials": np.float32(rng.rand() < 0.002)},
+                                   "layer2_state": {}},
+                    "reward": float(rng.choice([-1.0, 0.0, 1.0], p=[.1, .8, .1])), "done": bool(rng.rand() < 0.002),
+                    "info": {}, "env_id": e})
+            self.buf.update(samples)
+            fed += E
+        self.ingest_rate = fed / (time.time() - t0)
 
-    f32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.float32))  # noqa: E731
+    def learner_step(self, Bs):
+        from oracle import qmath
+        from oracle.replay import tree_map
+        from rltime_amd.models.torch.utils import make_tensor
+        T, P = self.T, self.P
+        buf, policy, target, opt = self.buf, self.policy, self.target, self.opt
 
-    def learner_step(Bs):
+        def flat(x):
+            return x.reshape((x.shape[0] * x.shape[1],) + x.shape[2:])
+
+        def tt(tree):
+            return make_tensor(tree, "cpu")
+
+        f32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.float32))  # noqa: E731
         buf.train_quota = 0
         batch = buf.get_train_data(Bs, 0.5)
         for pol, key in ((policy, "states"), (target, "target_states")):      # multi_step_trainer.py:90-131
@@ -274,6 +276,28 @@ def cpu_baseline(args, seconds):
         torch.nn.utils.clip_grad_norm_(policy.parameters(), 40.0)
         opt.step()
         buf.update_losses(data["extra_data"]["loss_indices"], rep.numpy())
+
+    def acting_rate(self, EA=32, reps=5):
+        """actor.py:108-147: policy forward on a 32-env vector step, 1 thread."""
+        H = self.H
+        act_state = {"x": self.rng.randint(0, 256, (EA, 4, 84, 84)).astype(np.uint8), "layer0_state": {},
+                     "layer1_state": {"hx": np.zeros((EA, H), np.float32), "cx": np.zeros((EA, H), np.float32),
+                                      "initials": np.zeros(EA, np.float32)}, "layer2_state": {}}
+        self.policy.actor_predict(act_state, 1)
+        t2 = time.time()
+        for _ in range(reps):
+            self.policy.actor_predict(act_state, 1)
+        return reps * EA / (time.time() - t2)
+
+
+def cpu_baseline(args, seconds):
+    """CpuPath on bounded samples, scaled linearly in B to B=512.  Headline leg: 1
+    torch thread, what the reference runs with (models/torch/torch_model.py:25 calls
+    torch.set_num_threads(1)); second leg: more host cores."""
+    nproc = os.cpu_count() or 1
+    B_full, T = 512, CpuPath.T
+    cpu = CpuPath()
+    learner_step, ingest_rate = cpu.learner_step, cpu.ingest_rate
 
     def leg(threads, plan, budget):
         """plan: [(B, max steps)] -> seconds per B=512 learner step from the largest B that ran."""
@@ -312,18 +336,10 @@ def cpu_baseline(args, seconds):
         all_s, all_spent = s2, all_spent + sp2
         all_b.update(b2)
     torch.set_num_threads(1)
-    # acting share (actor.py:108-147): policy forward on a 32-env vector step, 1 thread
-    EA = 32
-    act_state = {"x": rng.randint(0, 256, (EA, 4, 84, 84)).astype(np.uint8), "layer0_state": {},
-                 "layer1_state": {"hx": np.zeros((EA, H), np.float32), "cx": np.zeros((EA, H), np.float32),
-                                  "initials": np.zeros(EA, np.float32)}, "layer2_state": {}}
-    policy.actor_predict(act_state, 1)
-    t2 = time.time()
-    for _ in range(5):
-        policy.actor_predict(act_state, 1)
-    act_rate = 5 * EA / (time.time() - t2)
+    act_rate = cpu.acting_rate()
     acted_per_step = B_full * T / 4                        # train_frequency=4
     extra = acted_per_step / ingest_rate + acted_per_step / act_rate
+    P, n = CpuPath.P, CpuPath.n
     fmt = lambda d: ", ".join("B=%d: %.2f s/step (%d run%s)" % (b, t, k, "" if k == 1 else "s") for b, (t, k) in sorted(d.items()))  # noqa: E731
     return {
         "value": B_full * T / (one_s + extra), "unit": "transitions/s", "cores": 1, "kind": "port",
@@ -335,7 +351,8 @@ def cpu_baseline(args, seconds):
                                 % (many, fmt(all_b), B_full // max(all_b))},
         "sample": "oracle (reference algorithm restated, config D: T=80, burn-in 40, n=2, torch-CPU fp32, 1 thread like the "
                   "reference's torch.set_num_threads(1)): %s; the largest B scaled linearly x%d to B=512 (%.1f s of CPU work); "
-                  "+ acting %.0f and ingest %.0f transitions/s for the step's %d acted transitions; host has %d logical cores"
+                  "+ acting %.0f and ingest %.0f transitions/s for the step's %d acted transitions; host has %d logical cores; "
+                  "oracle / reference time ratio at identical inputs: BASELINE.md (tools/ref_vs_oracle_cpu.py)"
                   % (fmt(one_b), B_full // max(one_b), one_spent + all_spent, act_rate, ingest_rate, acted_per_step, nproc)}
 
 

@@ -25,7 +25,7 @@ class IQNPolicy(DQNPolicy):
         n = self.num_sampling_quantiles
         batch = x.shape[0]
         x = x.reshape(batch, -1)
-        quantiles = torch.rand(batch * n, device=self.embedding_range.device)
+        quantiles = self._draw_taus(batch * n)
         # iqn.py:78-81: cos(pi * i * tau) features, one kernel; same roundings as
         # torch.cos((embedding_range * pi) * tau[:, None])
         phi = cos_embed(quantiles, self.embedding_range * np.pi)
@@ -34,6 +34,17 @@ class IQNPolicy(DQNPolicy):
         # and with a single-pass backward (models/torch/fused.py)
         out = quantile_product(x, phi, self.quantile_layer.weight, self.quantile_layer.bias, n)
         return out, {"quantiles": quantiles}
+
+    def _draw_taus(self, count):
+        """iqn.py:76: tau ~ U(0,1) on the policy device.  `tau_source` (a callable
+        count -> tensor) replaces the draw: parity tests replay the tau stream the
+        reference drew on the CPU, which a device generator cannot reproduce."""
+        source = getattr(self, "tau_source", None)
+        if source is not None:
+            taus = source(count)
+            assert taus.shape == (count,)
+            return taus.to(self.embedding_range.device, torch.float32)
+        return torch.rand(count, device=self.embedding_range.device)
 
     def _shape_action_outputs(self, output):
         return output.reshape(-1, self.num_sampling_quantiles, output.shape[-1]), 2

@@ -702,6 +702,105 @@ def run_e2e_case():
 
 
 # --------------------------------------------------------------------------
+# End-to-end pin of the HEADLINE algorithm: recurrent IQN (dueling, double-Q,
+# rnn_bootstrap, burn-in) on prioritized sequence replay, trained by the unmodified
+# reference on CPU.  IQN draws its quantile fractions with torch.rand on the policy
+# device (policies/torch/iqn.py:76), so a GPU run cannot reproduce the stream; the
+# fixture therefore records every tau tensor the reference drew, in call order, and
+# the test replays them through IQNPolicy's tau hook.
+# --------------------------------------------------------------------------
+E2E_IQN = dict(
+    spec=E2E["spec"], model=E2E["model"],
+    policy_args={"dueling": True, "cuda": False, "embedding_dim": 8, "num_sampling_quantiles": 4},
+    train=dict(E2E["train"], vf_scale_epsilon=None),
+    seed=6)
+
+
+def run_e2e_iqn_case():
+    import copy
+    import gym
+    import io
+    from rltime.acting.acting_interface import ActingInterface
+    from rltime.training.torch.iqn import IQN as RefIQN
+    spec = StreamSpec(**E2E_IQN["spec"])
+
+    class ScriptedActor(ActingInterface):
+        def __init__(self):
+            super().__init__(gym.spaces.Box(0, 255, spec.frame_shape, dtype=np.uint8),
+                             gym.spaces.Discrete(spec.n_actions))
+            self.t = 0
+
+        def get_env_count(self):
+            return spec.num_envs
+
+        def set_actor_policy(self, p):
+            pass
+
+        def update_state(self, progress, policy_state=None):
+            pass
+
+        def close(self):
+            pass
+
+        def get_samples(self, min_samples):
+            iters = (max(1, min_samples) + spec.num_envs - 1) // spec.num_envs
+            out = []
+            for step in vector_steps(spec, iters, start_step=self.t):
+                out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
+            self.t += iters
+            return out
+
+    class Quiet:
+        def log_result(self, *a, **k):
+            pass
+
+        def save_checkpoint(self, *a, **k):
+            pass
+
+    random.seed(E2E_IQN["seed"]); np.random.seed(E2E_IQN["seed"]); torch.manual_seed(E2E_IQN["seed"])
+    tr = RefIQN(logger=Quiet(), actors=ScriptedActor(), model_config=E2E_IQN["model"],
+                policy_args=E2E_IQN["policy_args"])
+    series = {"qloss": [], "grad_norm": []}
+    orig = tr.value_log.log
+
+    def tap(key, value, *a, **k):
+        if key in series and k.get("group") == "train":
+            series[key].append(float(value))
+        return orig(key, value, *a, **k)
+    tr.value_log.log = tap
+    init = {}
+    real_init = tr.init_policies
+    taus, real_rand = [], torch.rand
+
+    def init_and_snapshot():
+        real_init()
+        for key, pol in (("online", tr.policy), ("target", tr.target_policy)):
+            f = io.BytesIO()
+            torch.save(pol.state_dict(), f)
+            init[key] = np.frombuffer(f.getvalue(), dtype=np.uint8)
+
+        def logged_rand(*a, **k):            # only the IQN quantile draws call torch.rand from here on
+            out = real_rand(*a, **k)
+            taus.append(out.detach().cpu().numpy().copy())
+            return out
+        torch.rand = logged_rand
+    tr.init_policies = init_and_snapshot
+    try:
+        tr.train(**copy.deepcopy(E2E_IQN["train"]))
+    finally:
+        torch.rand = real_rand
+    assert all(t.ndim == 1 for t in taus)
+    out = {"config": np.array(json.dumps(E2E_IQN)), "qloss": np.array(series["qloss"]),
+           "grad_norm": np.array(series["grad_norm"]),
+           "init_online": init["online"], "init_target": init["target"],
+           "tau_sizes": np.array([len(t) for t in taus], dtype=np.int64),
+           "taus": np.concatenate(taus).astype(np.float32)}
+    np.savez_compressed(os.path.join(HERE, "e2e_iqn_lstm_per.npz"), **out)
+    print("e2e IQN case: %d learner steps, %d tau draws (%d values), qloss[0..3]=%s" % (
+        len(series["qloss"]), len(taus), out["taus"].size, series["qloss"][:4]))
+
+
+# --------------------------------------------------------------------------
 # Schedules: epsilon-greedy (exploration/epsilon_greedy.py:64-99) and the linear
 # anneal used for beta / LR (general/utils.py:85-103)
 # --------------------------------------------------------------------------
@@ -767,6 +866,7 @@ if __name__ == "__main__":
     run_qmath_cases()
     run_model_cases()
     run_e2e_case()
+    run_e2e_iqn_case()
     run_schedule_cases()
     run_config_cases()
     print("golden fixtures written to", HERE)

@@ -141,3 +141,87 @@ def test_shared_online_cnn_gives_the_same_trajectory():
         runs.append(series)
     assert len(runs[0]) == len(runs[1]) > 40
     np.testing.assert_allclose(runs[0][:60], runs[1][:60], rtol=2e-4, atol=1e-6)
+
+
+def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
+    """The headline algorithm end to end: recurrent IQN (dueling, double-Q,
+    rnn_bootstrap, burn-in) + prioritized sequence replay, trained by the unmodified
+    reference on CPU (tests/golden/generate.py: run_e2e_iqn_case).  The reference
+    draws its quantile fractions with torch.rand on the CPU; the fixture holds every
+    tau tensor in call order and this run replays them through IQNPolicy.tau_source
+    (burn_in_full_forward=True: the reference's burn-in runs the whole head and so
+    consumes taus, multi_step_trainer.py:104-117).  Same tolerance as the DQN-LSTM
+    series: 2e-3 over the first 40 Adam steps of a CPU-fp32 vs GPU-fp32 trajectory."""
+    from rltime_amd.acting.acting_interface import ActingInterface
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.spaces import Box, Discrete
+    from rltime_amd.training.iqn import IQN
+    d = np.load(os.path.join(scenario.GOLDEN, "e2e_iqn_lstm_per.npz"))
+    cfg = json.loads(str(d["config"]))
+    spec = StreamSpec(**cfg["spec"])
+
+    class ScriptedActor(ActingInterface):
+        def __init__(self):
+            super().__init__(Box(0, 255, spec.frame_shape, np.uint8), Discrete(spec.n_actions))
+            self.t = 0
+
+        def get_env_count(self):
+            return spec.num_envs
+
+        def set_actor_policy(self, p):
+            pass
+
+        def update_state(self, progress, policy_state=None):
+            pass
+
+        def close(self):
+            pass
+
+        def get_samples(self, min_samples):
+            iters = (max(1, min_samples) + spec.num_envs - 1) // spec.num_envs
+            out = []
+            for step in vector_steps(spec, iters, start_step=self.t):
+                out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
+            self.t += iters
+            return out
+
+    sizes, flat = d["tau_sizes"], torch.from_numpy(d["taus"])
+    cursor = {"call": 0, "at": 0}
+
+    def replay(count):
+        i = cursor["call"]
+        assert i < len(sizes) and int(sizes[i]) == count, (i, count, int(sizes[i]) if i < len(sizes) else None)
+        out = flat[cursor["at"]:cursor["at"] + count]
+        cursor["call"], cursor["at"] = i + 1, cursor["at"] + count
+        return out
+
+    random.seed(cfg["seed"]); np.random.seed(cfg["seed"]); torch.manual_seed(cfg["seed"])   # noqa: E702
+    pargs = dict(cfg["policy_args"])
+    pargs["cuda"] = True
+    tr = IQN(logger=NullLogger(), actors=ScriptedActor(), model_config=cfg["model"], policy_args=pargs)
+    series = {"qloss": [], "grad_norm": []}
+    orig = tr.value_log.log
+
+    def tap(key, value, *a, **k):
+        if key in series and k.get("group") == "train":
+            series[key].append(float(value.item() if hasattr(value, "item") else value))
+        return orig(key, value, *a, **k)
+    tr.value_log.log = tap
+    real_init = tr.init_policies
+
+    def init_from_reference():
+        real_init()
+        tr.policy.load_state_dict(torch.load(io.BytesIO(d["init_online"].tobytes()), map_location="cuda"))
+        tr.target_policy.load_state_dict(torch.load(io.BytesIO(d["init_target"].tobytes()), map_location="cuda"))
+        tr.policy.tau_source = tr.target_policy.tau_source = replay
+    tr.init_policies = init_from_reference
+    args = copy.deepcopy(cfg["train"])
+    args["burn_in_full_forward"] = True
+    tr.train(**args)
+    assert cursor["call"] == len(sizes)                      # same number and order of tau draws
+    assert len(series["qloss"]) == len(d["qloss"])
+    n = 40
+    np.testing.assert_allclose(series["qloss"][:n], d["qloss"][:n], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
+    print("IQN-LSTM e2e: max rel dev over all %d steps: qloss %.2e" % (
+        len(d["qloss"]), np.max(np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"]))))

@@ -275,6 +275,69 @@ def test_frame_dedup_rejects_frames_that_break_the_stack_contract():
         b2.update(as_reference_samples(s2, next(vector_steps(s2, 1))))
 
 
+def _philox_u53(seed, call, lane):
+    """Philox4x32-10 (Salmon et al., SC'11) keyed (seed lo, seed hi), counter
+    (lane, call lo, call hi, tag) -> 53-bit uniform: an independent restatement of
+    what k_per_sample draws in device-RNG mode (csrc/replay.hip)."""
+    M0, M1, MASK = 0xD2511F53, 0xCD9E8D57, 0xFFFFFFFF
+    c = [lane & MASK, call & MASK, (call >> 32) & MASK, 0x52544D45]
+    k0, k1 = seed & MASK, (seed >> 32) & MASK
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & MASK, p1 & MASK, ((p0 >> 32) ^ c[3] ^ k1) & MASK, p0 & MASK]
+        k0, k1 = (k0 + 0x9E3779B9) & MASK, (k1 + 0xBB67AE85) & MASK
+    return ((c[0] >> 5) * 67108864.0 + (c[1] >> 6)) / 9007199254740992.0
+
+
+def test_device_rng_path_is_the_reference_sampler_on_philox_uniforms(monkeypatch):
+    """bench.py samples with device_rng=True (Philox drawn inside k_per_sample), every
+    other parity test with the reference's host streams.  Pin the device-RNG path too:
+    recompute the Philox uniforms on the host, hand them to the ORACLE's stratified
+    sampler in place of random.random(), and demand the same tree indices, windows,
+    importance weights and gathered batch."""
+    from oracle import replay as orc
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    E, B, gamma = 6, 16, 0.997
+    spec = StreamSpec(seed=61, num_envs=E, frame_shape=(1, 8, 8), lstm_units=4, n_actions=4, done_prob=0.04)
+    hist = dict(size=900, train_frequency=4, nstep_target=2, nstep_train=16, prefix_steps=8,
+                alpha=0.9, beta=0.6, max_weight_factor=0.9)
+    ora = orc.OraclePrioritizedReplay(**hist, discount_function=orc.make_discount(gamma))
+    dev = PrioritizedReplayHistoryBuffer(**hist, gamma=gamma, device_rng=True)
+    step_no, calls, draws = 0, 0, 0
+    for feed, progress in ((70, 0.0), (25, 0.3), (0, 0.4), (90, 0.7), (40, 1.0)):
+        for st in vector_steps(spec, feed, start_step=step_no):
+            ora.update(as_reference_samples(spec, st))
+            dev.update(as_reference_samples(spec, st))
+        step_no += feed
+        b = dev.get_train_data(B, train_progress=progress)
+        calls += 1
+        uniforms = iter([_philox_u53(dev._seed, calls, i) for i in range(B)])
+        monkeypatch.setattr(random, "random", lambda: next(uniforms))
+        a = ora.get_train_data(B, train_progress=progress)
+        monkeypatch.undo()
+        assert (a is None) == (b is None)
+        if a is None:
+            continue
+        draws += 1
+        assert np.array_equal(dev.last_sample["slot"].cpu().numpy(), np.array(ora.last_slots))
+        fa = scenario.flatten("", a, {})
+        fb = {k: scenario.to_numpy(v) for k, v in scenario.flatten("", b, {}).items()}
+        for key, w in fa.items():
+            if key.endswith("importance_weights"):
+                np.testing.assert_allclose(fb[key], w.astype(np.float32), rtol=scenario.WEIGHT_RTOL, err_msg=key)
+            elif key.endswith("actions") or key.endswith("loss_indices"):
+                assert np.array_equal(fb[key], w), key
+            else:
+                assert np.array_equal(fb[key], scenario.make_tensor_dtype(w)), key
+        P = hist["prefix_steps"]
+        idx = a["extra_data"]["loss_indices"][P:].reshape(-1, 2)
+        losses = (np.random.RandomState(draws).randn(idx.shape[0]) * 0.7).astype(np.float32)
+        ora.update_losses(idx, losses)
+        dev.update_losses(idx, losses)
+    assert draws >= 4
+    dev.close()
+
+
 def test_per_t1_vs_oracle_rainbow_shape():
     """Rainbow-shaped: T=1, n=3, f32 tree regime, beta anneal, many updates."""
     script = [("feed", 50)]

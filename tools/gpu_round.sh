@@ -13,6 +13,8 @@ for w in $WHAT; do
     probe)   timeout 300 python tools/convert_probe.py > "$OUT/convert_probe.jsonl" 2> "$OUT/convert_probe.err"; echo "probe rc=$?"; cat "$OUT/convert_probe.jsonl"; tail -3 "$OUT/convert_probe.err";;
     prof)    R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -60 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     gprobe)  for nt in 1 2; do PROBE_SIZE=1000000 PROBE_NT=$nt PROBE_ITERS=10 timeout 300 python tools/gather_probe.py >> "$OUT/gather_probe.jsonl" 2>> "$OUT/gather_probe.err"; done; echo "gprobe rc=$?"; cat "$OUT/gather_probe.jsonl";;
+    overlap) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-arg overlap_acting=true > "$OUT/bench_overlap.json" 2> "$OUT/bench_overlap.err"; echo "overlap rc=$?"; tail -c 600 "$OUT/bench_overlap.err"; head -c 1500 "$OUT/bench_overlap.json"; echo;;
+    dedup)   timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --frame-dedup > "$OUT/bench_dedup.json" 2> "$OUT/bench_dedup.err"; echo "dedup rc=$?"; tail -c 600 "$OUT/bench_dedup.err"; head -c 2500 "$OUT/bench_dedup.json"; echo;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
