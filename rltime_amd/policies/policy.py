@@ -6,6 +6,9 @@ class Policy:
     def actor_predict(self, state, timesteps=1):
         raise NotImplementedError
 
+    def get_creator(self, cuda=False):
+        raise NotImplementedError
+
     def get_state(self):
         raise NotImplementedError
 

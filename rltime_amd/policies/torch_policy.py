@@ -56,6 +56,14 @@ class TorchPolicy(nn.Module, Policy):
     def make_tensor(self, x, non_blocking=False):
         return make_tensor(x, self.device(), non_blocking)
 
+    def get_creator(self, cuda=False):
+        """torch_policy.py:93-97: a callable that builds a CPU copy of this policy
+        (what the reference ships to actor processes; `cuda` is unsupported there too)."""
+        f = io.BytesIO()
+        torch.save(self, f)
+        data = f.getvalue()
+        return lambda: torch.load(io.BytesIO(data), map_location="cpu", weights_only=False)
+
     def get_state(self):
         f = io.BytesIO()
         torch.save(self.state_dict(), f)

@@ -35,6 +35,15 @@ class DQN(TorchTrainer):
             return qops.q_target_dqn(q_t, q_s, mk(returns), mk(nsteps), mk(target_masks),
                                      self.gamma, self.vf_scale_epsilon)
 
+    def _get_bootstrap_target_value(self, target_states, timesteps):
+        """dqn.py:52-71 alone (the hook of the reference's TorchTrainer contract; the
+        fused calc_target_values above does not go through it): the same kernel with a
+        zero return, unit mask and gamma**0."""
+        q_t = self.target_policy.predict(target_states, timesteps=timesteps)
+        q_s = q_t if not self.double_q else self.policy.predict(target_states, timesteps=timesteps)
+        z = torch.zeros(q_t.shape[0], device=q_t.device)
+        return qops.q_target_dqn(q_t, q_s, z, z, torch.ones_like(z), self.gamma, None)
+
     def _report_losses_if_needed(self, losses, extra_train_data):
         """dqn.py:73-81 — the per-transition errors go to the replay as a device
         tensor (the reference copies them to the host first)."""

@@ -23,6 +23,14 @@ class IQN(DQN):
             return qops.q_target_iqn(z_t, z_s, mk(returns), mk(nsteps), mk(target_masks),
                                      self.gamma, self.vf_scale_epsilon)
 
+    def _get_bootstrap_target_value(self, target_states, timesteps):
+        """iqn.py:15-52 alone (see DQN._get_bootstrap_target_value)."""
+        z_t = self.target_policy.predict(target_states, timesteps=timesteps)[0]
+        sel = self.policy if self.double_q else self.target_policy
+        z_s = sel.predict(target_states, timesteps=timesteps)[0]
+        z = torch.zeros(z_t.shape[0], device=z_t.device)
+        return qops.q_target_iqn(z_t, z_s, z, z, torch.ones_like(z), self.gamma, None)
+
     def _compute_grads(self, states, targets, policy_outputs, extra_data, timesteps):
         """iqn.py:54-129."""
         assert self.loss_mode == "huber", "IQN supports only huber loss"

@@ -36,6 +36,45 @@ class TorchTrainer(MultiStepTrainer):
     def _compute_grads(self, states, targets, policy_outputs, extra_data, timesteps):
         raise NotImplementedError
 
+    # -- the reference's target hooks (torch_trainer.py:91-147).  DQN / IQN override
+    # calc_target_values with one fused kernel after their forwards; a subclass that
+    # only supplies `_get_bootstrap_target_value` (the reference's plugin contract)
+    # gets the generic composition below, same arithmetic in plain torch ops.
+    def _get_bootstrap_target_value(self, target_states, timesteps):
+        raise NotImplementedError
+
+    def _discount_bootstrap_target_value(self, target_values, nsteps):
+        return (self.gamma ** nsteps) * target_values
+
+    def _vf_scale(self, x):
+        """torch_trainer.py:46-52."""
+        eps = self.vf_scale_epsilon
+        if eps is None:
+            return x
+        return torch.sign(x) * (torch.sqrt(torch.abs(x) + 1) - 1) + eps * x
+
+    def _vf_unscale(self, y):
+        """torch_trainer.py:54-78 (float64 inside, float32 out)."""
+        eps = self.vf_scale_epsilon
+        if eps is None:
+            return y
+        y64 = y.double()
+        a = torch.abs(y64)
+        x = a / eps - (1 / (2. * eps ** 2)) * torch.sqrt(4 * eps * a + (2. * eps + 1) ** 2) + (2. * eps + 1) / (2. * eps ** 2)
+        return (x * torch.sign(y64)).float()
+
+    def calc_target_values(self, returns, target_states, target_masks, nsteps, timesteps):
+        """torch_trainer.py:101-147."""
+        with torch.no_grad():
+            target_states, returns, target_masks, nsteps = self.target_policy.make_tensor(
+                (target_states, returns, target_masks, nsteps), non_blocking=True)
+            v = self._vf_unscale(self._get_bootstrap_target_value(target_states, timesteps))
+            assert returns.shape == target_masks.shape == nsteps.shape == (v.shape[0],)
+            assert v.dim() in (1, 2)
+            if v.dim() == 2:
+                returns, target_masks, nsteps = (t.unsqueeze(-1) for t in (returns, target_masks, nsteps))
+            return self._vf_scale(returns + self._discount_bootstrap_target_value(v, nsteps) * target_masks)
+
     def _clip_value(self, norm):
         """torch_trainer.py:153-175: fixed clip or clip_grad x EMA(norm); the EMA
         lives on the device."""

@@ -858,6 +858,60 @@ def run_config_cases():
     print("config cases: %s" % ", ".join(out))
 
 
+# --------------------------------------------------------------------------
+# Plugin-surface conformance: the parameter names of the reference's plugin
+# classes / methods, taken from the imported reference with
+# inspect.signature.  tests/test_abi.py holds rltime_amd's mirror classes to them
+# (same names in the same order; the mirror may only APPEND optional parameters).
+# --------------------------------------------------------------------------
+SIGNATURE_TARGETS = {
+    "history.History": ("rltime.history.history", "History",
+                        ["__init__", "update", "needed_feed_count", "get_train_data", "update_losses"]),
+    "history.ReplayHistoryBuffer": ("rltime.history.replay_history", "ReplayHistoryBuffer", ["__init__"]),
+    "history.PrioritizedReplayHistoryBuffer": ("rltime.history.prioritized_replay_history",
+                                               "PrioritizedReplayHistoryBuffer", ["__init__", "update_losses"]),
+    "policies.Policy": ("rltime.policies.policy", "Policy",
+                        ["actor_predict", "get_creator", "get_state", "is_recurrent", "make_input_state",
+                         "get_state_store"]),
+    "policies.TorchPolicy": ("rltime.policies.torch.torch_policy", "TorchPolicy",
+                             ["create", "copy_from", "get_grad_norm", "make_tensor", "get_creator", "load_state"]),
+    "policies.DQNPolicy": ("rltime.policies.torch.dqn", "DQNPolicy", ["__init__", "predict", "actor_predict"]),
+    "policies.IQNPolicy": ("rltime.policies.torch.iqn", "IQNPolicy", ["__init__"]),
+    "training.PolicyTrainer": ("rltime.training.policy_trainer", "PolicyTrainer",
+                               ["__init__", "create_policy", "sample_actors", "train"]),
+    "training.MultiStepTrainer": ("rltime.training.multi_step_trainer", "MultiStepTrainer",
+                                  ["calc_target_values", "train_init", "set_lr", "train_batch", "_burn_in", "_train"]),
+    "training.TorchTrainer": ("rltime.training.torch.torch_trainer", "TorchTrainer",
+                              ["_train", "_compute_grads", "_get_bootstrap_target_value"]),
+    "training.DQN": ("rltime.training.torch.dqn", "DQN", ["_train"]),
+    "acting.ActingInterface": ("rltime.acting.acting_interface", "ActingInterface",
+                               ["get_spaces", "get_samples", "get_env_count", "set_actor_policy", "update_state",
+                                "close", "_create_sample"]),
+    "acting.Actor": ("rltime.acting.actor", "Actor", ["get_samples", "update_state", "set_actor_policy"]),
+    "models.SequentialModel": ("rltime.models.torch.sequential", "SequentialModel",
+                               ["make_input_state", "forward", "set_layer_preprocessor"]),
+}
+
+
+def run_signature_cases():
+    import importlib
+    import inspect
+    out = {}
+    for key, (module, cls_name, methods) in SIGNATURE_TARGETS.items():
+        cls = getattr(importlib.import_module(module), cls_name)
+        table = {}
+        for m in methods:
+            params = []
+            for name, p in inspect.signature(getattr(cls, m)).parameters.items():
+                kind = {p.VAR_POSITIONAL: "*", p.VAR_KEYWORD: "**"}.get(p.kind, "")
+                params.append([kind + name, p.default is not p.empty])
+            table[m] = params
+        out[key] = table
+    with open(os.path.join(HERE, "signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("signature cases: %d classes" % len(out))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_tree_cases()
@@ -869,4 +923,5 @@ if __name__ == "__main__":
     run_e2e_iqn_case()
     run_schedule_cases()
     run_config_cases()
+    run_signature_cases()
     print("golden fixtures written to", HERE)

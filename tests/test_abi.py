@@ -49,8 +49,8 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(d, f)
     for f in ("bench.py",):
         src = open(os.path.join(ROOT, f)).read()
-        # bench.py may use the oracle only inside cpu_baseline()
-        head, _, tail = src.partition("def cpu_baseline")
+        # bench.py may use the oracle only inside its cpu_baseline leg (class CpuPath + cpu_baseline())
+        head, _, tail = src.partition("class CpuPath")
         body, _, rest = tail.partition("\ndef main")
         assert "from oracle" not in head and "from oracle" not in rest
 
@@ -62,3 +62,73 @@ def test_history_requires_gpu():
     from rltime_amd.history import ReplayHistoryBuffer
     with pytest.raises(_lib.MirlError, match="no CPU fallback"):
         ReplayHistoryBuffer(size=8, train_frequency=1, nstep_target=1, nstep_train=1)
+
+
+# --------------------------------------------------------------------------
+# plugin surface: the mirror classes against the reference's signatures
+# (tests/golden/signatures.json, written by tests/golden/generate.py from the
+# imported reference with inspect.signature)
+# --------------------------------------------------------------------------
+_MIRROR = {
+    "history.History": ("rltime_amd.history.replay_history", "History"),
+    "history.ReplayHistoryBuffer": ("rltime_amd.history.replay_history", "ReplayHistoryBuffer"),
+    "history.PrioritizedReplayHistoryBuffer": ("rltime_amd.history.replay_history", "PrioritizedReplayHistoryBuffer"),
+    "policies.Policy": ("rltime_amd.policies.policy", "Policy"),
+    "policies.TorchPolicy": ("rltime_amd.policies.torch_policy", "TorchPolicy"),
+    "policies.DQNPolicy": ("rltime_amd.policies.dqn", "DQNPolicy"),
+    "policies.IQNPolicy": ("rltime_amd.policies.iqn", "IQNPolicy"),
+    "training.PolicyTrainer": ("rltime_amd.training.policy_trainer", "PolicyTrainer"),
+    "training.MultiStepTrainer": ("rltime_amd.training.multi_step_trainer", "MultiStepTrainer"),
+    "training.TorchTrainer": ("rltime_amd.training.torch_trainer", "TorchTrainer"),
+    "training.DQN": ("rltime_amd.training.dqn", "DQN"),
+    "acting.ActingInterface": ("rltime_amd.acting.acting_interface", "ActingInterface"),
+    "acting.Actor": ("rltime_amd.acting.actor", "Actor"),
+    "models.SequentialModel": ("rltime_amd.models.torch.sequential", "SequentialModel"),
+}
+# where the mirror deliberately differs from the reference's parameter list
+_KNOWN = {
+    # the device replay evaluates the n-step return on the GPU and takes the discount as a number too
+    ("history.History", "__init__"): "appends gamma",
+    # History methods live on the concrete device buffers (History itself only normalises arguments)
+    ("history.History", "update"): "on ReplayHistoryBuffer",
+    ("history.History", "needed_feed_count"): "on ReplayHistoryBuffer",
+    ("history.History", "get_train_data"): "on ReplayHistoryBuffer",
+    ("history.History", "update_losses"): "on ReplayHistoryBuffer",
+}
+
+
+def _params(fn):
+    import inspect
+    out = []
+    for name, p in inspect.signature(fn).parameters.items():
+        kind = {p.VAR_POSITIONAL: "*", p.VAR_KEYWORD: "**"}.get(p.kind, "")
+        out.append([kind + name, p.default is not p.empty])
+    return out
+
+
+def test_mirror_classes_keep_the_reference_signatures():
+    import importlib
+    import json
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "signatures.json")))
+    problems = []
+    for key, methods in want.items():
+        module, cls_name = _MIRROR[key]
+        cls = getattr(importlib.import_module(module), cls_name)
+        for m, ref in methods.items():
+            owner = cls
+            if (key, m) in _KNOWN and _KNOWN[(key, m)].startswith("on "):
+                owner = getattr(importlib.import_module(module), _KNOWN[(key, m)][3:])
+            if not hasattr(owner, m):
+                problems.append("%s.%s is missing" % (key, m))
+                continue
+            got = _params(getattr(owner, m))
+            ref_named = [p for p in ref if not p[0].startswith("*")]
+            got_named = [p for p in got if not p[0].startswith("*")]
+            # same names, same order, same optionality; the mirror may append OPTIONAL parameters
+            if got_named[:len(ref_named)] != ref_named:
+                problems.append("%s.%s: reference %s, mirror %s" % (key, m, ref_named, got_named))
+            elif any(not opt for _, opt in got_named[len(ref_named):]):
+                problems.append("%s.%s: mirror adds required parameters %s" % (key, m, got_named[len(ref_named):]))
+            if any(p[0].startswith("**") for p in ref) and not any(p[0].startswith("**") for p in got):
+                problems.append("%s.%s: reference forwards **kwargs, mirror does not" % (key, m))
+    assert not problems, "\n".join(problems)

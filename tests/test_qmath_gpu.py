@@ -116,3 +116,41 @@ def test_dqn_random_shapes_vs_oracle(M, A):
     np.testing.assert_allclose(l2.item(), l1.item(), **TOL)
     np.testing.assert_allclose(r2.cpu().numpy(), r1.numpy(), **TOL)
     np.testing.assert_allclose(q2.grad.cpu().numpy(), q1.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("algo", ["dqn", "iqn"])
+@pytest.mark.parametrize("vf_eps", [None, 1e-3])
+def test_reference_target_hooks_compose_to_the_fused_targets(algo, vf_eps):
+    """The reference's TorchTrainer contract (torch_trainer.py:91-147): a subclass
+    supplies `_get_bootstrap_target_value`, the base class composes
+    h(ret + gamma^n h^-1(v) mask).  rltime_amd's DQN / IQN override calc_target_values
+    with one fused kernel; the hook path must give the same targets (1e-4)."""
+    from rltime_amd.models.torch.utils import make_tensor
+    from rltime_amd.training.dqn import DQN
+    from rltime_amd.training.iqn import IQN
+    from rltime_amd.training.torch_trainer import TorchTrainer
+    g = torch.Generator().manual_seed(7)
+    M, N, A = 300, 8, 5
+
+    class Stub:
+        def __init__(self, out):
+            self.out = out
+
+        def predict(self, x, timesteps):
+            return (self.out, None) if algo == "iqn" else self.out
+
+        def make_tensor(self, x, non_blocking=False):
+            return make_tensor(x, "cuda", non_blocking)
+
+    shape = (M, N, A) if algo == "iqn" else (M, A)
+    tr = (IQN if algo == "iqn" else DQN).__new__(IQN if algo == "iqn" else DQN)
+    tr.policy, tr.target_policy = Stub(torch.randn(shape, generator=g).cuda()), Stub(torch.randn(shape, generator=g).cuda())
+    tr.gamma, tr.vf_scale_epsilon, tr.double_q = 0.97, vf_eps, True
+    returns = torch.randn(M, generator=g).numpy().astype(np.float64)
+    nsteps = torch.randint(1, 4, (M,), generator=g).numpy()
+    masks = (torch.rand(M, generator=g) > 0.2).numpy().astype(np.int64)
+    states = {"x": torch.zeros(M, 1).cuda()}
+    fused = tr.calc_target_values(returns, states, masks, nsteps, 1)
+    hooks = TorchTrainer.calc_target_values(tr, returns, states, masks, nsteps, 1)
+    assert fused.shape == hooks.shape
+    np.testing.assert_allclose(fused.cpu().numpy(), hooks.cpu().numpy(), rtol=1e-4, atol=1e-4)
