@@ -79,6 +79,19 @@ class DataParallel:
     def active(self):
         return self.world > 1 or self.force
 
+    # -- transport ------------------------------------------------------------------
+    def _all_reduce(self, t, op):
+        """RCCL reduces device tensors in place.  gloo (CPU tests, two ranks on one
+        GPU) goes through a host copy: its device-tensor path stages through pinned
+        memory on its own streams, which is not robust with two processes time-slicing
+        one GPU."""
+        if self._backend != "nccl" and t.is_cuda:
+            host = t.cpu()
+            dist.all_reduce(host, op=op, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+
     # -- parameters / gradients ---------------------------------------------------
     def broadcast_parameters(self, module, src=0):
         """Identical initial weights (and buffers) on every rank."""
@@ -86,7 +99,12 @@ class DataParallel:
             return
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src, group=self.group)
+                if self._backend != "nccl" and t.is_cuda:
+                    host = t.data.cpu()
+                    dist.broadcast(host, src, group=self.group)
+                    t.data.copy_(host)
+                else:
+                    dist.broadcast(t.data, src, group=self.group)
 
     def attach(self, module):
         """Make every parameter's .grad a view of one flat bucket.  Autograd then
@@ -117,7 +135,7 @@ class DataParallel:
         if self._backend == "nccl":
             dist.all_reduce(self._flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(self._flat, dist.ReduceOp.SUM)
             self._flat.div_(self.world)
 
     # -- importance weights ---------------------------------------------------------
@@ -128,7 +146,7 @@ class DataParallel:
         buf = torch.zeros((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
         buf[self.rank] = mine
         if self.world > 1 or self.force:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(buf, dist.ReduceOp.SUM)
         return buf
 
     def globalize_weights(self, weights, p_sum, n_active, max_raw, beta):

@@ -1,10 +1,10 @@
 """GPU: the N>1 path of THE LOOP, executed for real — two ranks, each a full
 trainer process (device actor, its own replay shard, sampling, gather, burn-in,
 IQN targets, forward/backward, gradient all-reduce, clip + Adam, priority
-update), both on cuda:0 over gloo (RCCL refuses two ranks on one device; the
-code path is the one RCCL serves on a multi-GPU node: rltime_amd/parallel.py
-only uses all_reduce / broadcast, which both backends support for device
-tensors).
+update), both on cuda:0 over gloo (RCCL refuses two ranks on one device).  The
+trainer-side code path is the one RCCL serves on a multi-GPU node:
+rltime_amd/parallel.py only uses all_reduce / broadcast; under gloo the device
+tensors are staged through the host inside DataParallel._all_reduce.
 
 Checked:
   (i)  the parameters are bit-identical across the ranks after every learner step
@@ -63,11 +63,14 @@ def _rank_main(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
+    import datetime
+    import faulthandler
     import random
+    faulthandler.dump_traceback_later(240, exit=True)        # a stuck rank reports where, instead of hanging the suite
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from rltime_amd.general.loggers import NullLogger
     from rltime_amd.general.type_registry import get_registered_type
     from rltime_amd.parallel import DataParallel, shard_config
@@ -121,6 +124,7 @@ def _rank_main(rank, world, port, out_dir):
              steps=trainer.steps)
     hist.close()
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def _kinded(v, k):

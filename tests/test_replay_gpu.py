@@ -266,6 +266,7 @@ def test_frame_dedup_rejects_frames_that_break_the_stack_contract():
     for st in vector_steps(spec, 6):                    # unrelated frames every step: not a shifted stack
         buf.update(as_reference_samples(spec, st))
     np.random.seed(0)
+    torch.cuda.synchronize()                              # the flag is written by the (asynchronous) ingest kernels
     with pytest.raises(_lib.MirlError, match="shift contract"):
         buf.get_train_data(2)
     buf.close()

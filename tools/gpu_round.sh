@@ -7,7 +7,7 @@ WHAT="${*:-tests bench bench23}"
 OUT="gpurun_out/$TAG"; mkdir -p "$OUT"
 for w in $WHAT; do
   case $w in
-    tests)   timeout 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"; tail -15 "$OUT/pytest.log";;
+    tests)   timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 -o faulthandler_timeout=240 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"; tail -15 "$OUT/pytest.log";;
     bench)   timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_iqn_lstm.json" 2> "$OUT/bench_iqn_lstm.err"; echo "bench rc=$?"; tail -c 1500 "$OUT/bench_iqn_lstm.err"; head -c 6000 "$OUT/bench_iqn_lstm.json";;
     bench23) for c in rainbow_iqn dqn_uniform; do timeout 600 python bench.py --config $c --steps 50 --warmup 10 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"; tail -c 800 "$OUT/bench_$c.err"; head -c 5000 "$OUT/bench_$c.json"; done;;
     probe)   timeout 300 python tools/convert_probe.py > "$OUT/convert_probe.jsonl" 2> "$OUT/convert_probe.err"; echo "probe rc=$?"; cat "$OUT/convert_probe.jsonl"; tail -3 "$OUT/convert_probe.err";;
@@ -15,6 +15,7 @@ for w in $WHAT; do
     gprobe)  for nt in 1 2; do PROBE_SIZE=1000000 PROBE_NT=$nt PROBE_ITERS=10 timeout 300 python tools/gather_probe.py >> "$OUT/gather_probe.jsonl" 2>> "$OUT/gather_probe.err"; done; echo "gprobe rc=$?"; cat "$OUT/gather_probe.jsonl";;
     overlap) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-arg overlap_acting=true > "$OUT/bench_overlap.json" 2> "$OUT/bench_overlap.err"; echo "overlap rc=$?"; tail -c 600 "$OUT/bench_overlap.err"; head -c 1500 "$OUT/bench_overlap.json"; echo;;
     dedup)   timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --frame-dedup > "$OUT/bench_dedup.json" 2> "$OUT/bench_dedup.err"; echo "dedup rc=$?"; tail -c 600 "$OUT/bench_dedup.err"; head -c 2500 "$OUT/bench_dedup.json"; echo;;
+    tests1)  timeout 600 python -m pytest tests/test_multirank_gpu.py -x -q --timeout 300 -o faulthandler_timeout=240 > "$OUT/pytest_multirank.log" 2>&1; echo "pytest multirank rc=$?"; tail -40 "$OUT/pytest_multirank.log";;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
