@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen benchmarks its solvers "
+                    "per conv shape instead of taking the immediate-mode pick (experiment)")
     ap.add_argument("--frame-dedup", action="store_true", help="SURVEY 8(f)2: stack-consistent synthetic frames and de-duplicated "
                     "storage (one 84x84 plane per transition in the ring, stacks rebuilt by the gather)")
     ap.add_argument("--train-arg", action="append", default=[], help="KEY=JSON extra training.args override (experiments)")
@@ -369,6 +371,8 @@ def main():
 
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
     spec = CONFIGS[args.config]
     config = build_config(args, rank, world)
     targs = config["training"]["args"]

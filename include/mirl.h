@@ -331,6 +331,17 @@ int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const floa
 int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g, const float* emb, const float* x,
                      float* d_pre, float* dx, float* db, float* partial, int32_t blocks, void* stream);
 
+/* ---- device-resident actor bookkeeping (csrc/acting.hip) -----------------------
+ * Episode statistics on the RAW rewards and the action histogram
+ * (rltime/training/policy_trainer.py:75-131), one launch per vector step:
+ * ep_reward / ep_len [E] are the running accumulators; out_reward / out_len [E] get
+ * (reward, length) of the episodes that ended at this step (length 0 = none);
+ * action_counts [A] accumulates (may be NULL).  The host reads the out rows back
+ * asynchronously.                                                                  */
+int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,
+                       const int32_t* actions, float* ep_reward, int32_t* ep_len,
+                       float* out_reward, int32_t* out_len, int32_t* action_counts, void* stream);
+
 /* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
 int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
 

@@ -41,6 +41,7 @@ class DeviceSamples:
         self.num_envs = num_envs
         self.env_base = env_base
         self.vector_steps = []
+        self.episode_tracker = None      # acting/episode_tracker.py when the env reports no host-side stats
 
     def append(self, **fields):
         self.vector_steps.append(fields)
@@ -55,6 +56,10 @@ class DeviceSamples:
         """policy_trainer.py:248-254 on the device: episode stats from the raw
         rewards, then sign clipping if configured."""
         import torch
+        if self.episode_tracker is not None:
+            for reward, length in self.episode_tracker.drain():
+                trainer._log_episode(reward, length)
+            trainer.episodes.device_tracker = self.episode_tracker
         for step in self.vector_steps:
             stats = step.pop("episode_stats", None)
             if stats is not None:

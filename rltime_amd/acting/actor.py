@@ -112,6 +112,7 @@ class Actor(ActingInterface):
         self._device_mode = device
         self._use_graph = use_graph and device
         self._graphed = None
+        self._tracker = None
         super().__init__(vec_env.observation_space, vec_env.action_space)
 
     def get_env_count(self):
@@ -205,6 +206,13 @@ class Actor(ActingInterface):
             # (3) actor.py:124: the environments
             obs, rewards, dones, stats = self._vec_env.step_device(actions)
             rewards, dones8 = rewards.to(torch.float32), dones.to(torch.uint8)
+            if stats is None:
+                # episode reward / length and the action histogram on the device
+                # (policy_trainer.py:75-131), one launch per vector step
+                if self._tracker is None:
+                    from .episode_tracker import EpisodeTracker
+                    self._tracker = EpisodeTracker(self._num_envs, self._action_space.n, rewards.device)
+                self._tracker.step(rewards, dones8, actions)
             # (4) actor.py:128: next input state (+ the next action when replayed from the graph)
             fields, pending = None, None
             if self._use_graph:
@@ -236,6 +244,9 @@ class Actor(ActingInterface):
                 out = DeviceSamples(example, self._num_envs, self._base_env_id)
             fields.update(actions=actions, policy=qvalues, rewards=rewards, dones=dones8, episode_stats=stats)
             out.append(**fields)
+        if self._tracker is not None:
+            self._tracker.flush()
+            out.episode_tracker = self._tracker
         return out
 
     def _eps(self):

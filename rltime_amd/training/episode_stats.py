@@ -14,6 +14,7 @@ class EpisodeStats:
         self.length = {}
         self.action_counts = {}
         self.action_total = 0
+        self.device_tracker = None       # the device actor's EpisodeTracker: action counts live on the GPU
 
     def episode_finished(self, reward, length):
         log = self.value_log.log
@@ -51,6 +52,11 @@ class EpisodeStats:
             self.action_total += 1
 
     def action_histogram(self):
+        if self.device_tracker is not None:
+            for a, c in enumerate(self.device_tracker.take_action_counts()):
+                if c:
+                    self.action_counts[a] = self.action_counts.get(a, 0) + c
+                    self.action_total += c
         if not self.action_counts:
             return []
         hist = [0] * (max(self.action_counts) + 1)

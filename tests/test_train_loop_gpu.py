@@ -38,6 +38,12 @@ def _run(config, device_acting=True):
         assert last["timings_gpu_mean_ms"][phase] >= 0.0
     for p in trainer.policy.parameters():
         assert torch.isfinite(p).all()
+    # episode statistics and the action histogram (policy_trainer.py:75-131) — on the
+    # device-resident actor they are accumulated on the GPU (acting/episode_tracker.py)
+    assert last["total"]["episodes"] > 0
+    assert last["last10"]["episode_length"] >= 1 and math.isfinite(last["last10"]["reward"])
+    hist = last["acting"]["actions"]
+    assert len(hist) > 1 and abs(sum(hist) - 1.0) < 0.02
     return trainer, last
 
 

@@ -16,6 +16,7 @@ for w in $WHAT; do
     overlap) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-arg overlap_acting=true > "$OUT/bench_overlap.json" 2> "$OUT/bench_overlap.err"; echo "overlap rc=$?"; tail -c 600 "$OUT/bench_overlap.err"; head -c 1500 "$OUT/bench_overlap.json"; echo;;
     dedup)   timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --frame-dedup > "$OUT/bench_dedup.json" 2> "$OUT/bench_dedup.err"; echo "dedup rc=$?"; tail -c 600 "$OUT/bench_dedup.err"; head -c 2500 "$OUT/bench_dedup.json"; echo;;
     tests1)  timeout 600 python -m pytest tests/test_multirank_gpu.py -x -q --timeout 300 -o faulthandler_timeout=240 > "$OUT/pytest_multirank.log" 2>&1; echo "pytest multirank rc=$?"; tail -40 "$OUT/pytest_multirank.log";;
+    find)    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 --miopen-find > "$OUT/bench_miopen_find.json" 2> "$OUT/bench_miopen_find.err"; echo "find rc=$?"; tail -c 400 "$OUT/bench_miopen_find.err"; head -c 700 "$OUT/bench_miopen_find.json"; echo;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
