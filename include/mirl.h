@@ -331,6 +331,16 @@ int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const floa
 int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g, const float* emb, const float* x,
                      float* d_pre, float* dx, float* db, float* partial, int32_t blocks, void* stream);
 
+/* backward of the dueling head's two output layers fused with the ReLU mask and bias
+ * gradient of the joint hidden activation `both` (M, H1+Hv):
+ *   g = (both > 0) * [ga @ wo | gv @ wq],  db = column sums of g
+ * ga (M, A), gv (M, Q), wo (A, H1), wq (Q, Hv) row-major; A, Q <= 16.
+ * (rltime/policies/torch/dqn.py:50-66,74-112 — the autograd of out_layer /
+ * value_layer over the last FC layer and the value-hidden layer.)                 */
+int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga,
+                          const float* gv, const float* wo, const float* wq, const float* both,
+                          float* g, float* db, float* partial, int32_t blocks, void* stream);
+
 /* ---- device-resident actor bookkeeping (csrc/acting.hip) -----------------------
  * Episode statistics on the RAW rewards and the action histogram
  * (rltime/training/policy_trainer.py:75-131), one launch per vector step:

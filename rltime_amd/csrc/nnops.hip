@@ -210,6 +210,71 @@ k_iqn_mul_bwd(const nn_f4* __restrict__ g, const nn_f4* __restrict__ emb, const 
   }
 }
 
+// Backward of the dueling tail's two small output layers fused with the ReLU mask
+// of the joint hidden activation and its bias gradient:
+//   d_both[r][c] = sum_a ga[r][a] * wo[a][c]            (c <  H1: advantage branch, a < A)
+//                = sum_q gv[r][q] * wq[q][c - H1]       (c >= H1: value branch,     q < Q)
+//   g[r][c]      = both[r][c] > 0 ? d_both[r][c] : 0 ;  db[c] = sum_r g[r][c]
+// PyTorch runs two K<=A GEMMs that WRITE the (M, H1+Hv) gradient (5.4 GB at the
+// benchmark shape) and a mask pass that re-reads it; here the K<=16 dot products sit
+// in registers, `both` is read once and g written once.  Lane = one column quad for
+// the whole sweep (its 4 x A weights stay in registers), block = a row range.
+#define MIRL_TAIL_MAXK 16
+__global__ void __launch_bounds__(256)
+k_tail_bwd(const float* __restrict__ ga, const float* __restrict__ gv, const float* __restrict__ wo,
+           const float* __restrict__ wq, const nn_f4* __restrict__ both, nn_f4* __restrict__ g,
+           nn_f4* __restrict__ partial, int64_t rows, int H1, int Hv, int A, int Q, int64_t rpb) {
+  __shared__ nn_f4 s_acc[256];
+  const int C = H1 + Hv, CQ = C / 4, tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
+  const int c0 = cq * 4;
+  const bool adv = c0 < H1;
+  const int K = adv ? A : Q;
+  const float* w = adv ? wo + c0 : wq + (c0 - H1);
+  const int ldw = adv ? H1 : Hv;
+  const float* gsrc = adv ? ga : gv;
+  nn_f4 wk[MIRL_TAIL_MAXK];
+#pragma unroll
+  for (int k = 0; k < MIRL_TAIL_MAXK; ++k)
+    wk[k] = k < K ? nn_f4{w[(int64_t)k * ldw], w[(int64_t)k * ldw + 1], w[(int64_t)k * ldw + 2], w[(int64_t)k * ldw + 3]}
+                  : nn_f4{0.f, 0.f, 0.f, 0.f};
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  nn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  int64_t r = r0 + rl;
+  for (; r + 3 * RL < r1; r += 4 * RL) {              // four rows in flight per lane
+    nn_f4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = both[(r + (int64_t)u * RL) * CQ + cq];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* gr = gsrc + (r + (int64_t)u * RL) * K;
+      nn_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
+      MIRL_MASK(d, b[u])
+      g[(r + (int64_t)u * RL) * CQ + cq] = d;
+      acc = acc + d;
+    }
+  }
+  for (; r < r1; r += RL) {
+    const nn_f4 b = both[r * CQ + cq];
+    const float* gr = gsrc + r * K;
+    nn_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
+    MIRL_MASK(d, b)
+    g[r * CQ + cq] = d;
+    acc = acc + d;
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    nn_f4 t = s_acc[cq];
+    for (int k = 1; k < RL; ++k) t = t + s_acc[k * CQ + cq];
+    partial[(int64_t)blockIdx.x * CQ + cq] = t;
+  }
+}
+
 static inline bool pow2_quads(int C) { int cq = C / 4; return (C % 4) == 0 && cq >= 1 && cq <= 256 && (256 % cq) == 0; }
 static inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
@@ -304,6 +369,30 @@ extern "C" int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g,
     ProfScope ps("k_iqn_mul_bwd", (3.0 * M * N + 2.0 * M) * C * 4, st);
     hipLaunchKernelGGL(k_iqn_mul_bwd, dim3((unsigned)blocks), dim3(256), 0, st, (const nn_f4*)g, (const nn_f4*)emb, (const nn_f4*)x,
                        (nn_f4*)d_pre, (nn_f4*)dx, (nn_f4*)partial, M, (int)N, C / 4, gpb);
+  }
+  MIRL_LAUNCH_CHECK();
+  {
+    ProfScope ps("k_colsum_partials", (double)blocks * C * 4, st);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, st, partial, db, (int)blocks, (int)C);
+  }
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga, const float* gv,
+                                     const float* wo, const float* wq, const float* both, float* g, float* db, float* partial,
+                                     int32_t blocks, void* stream) {
+  if (M <= 0 || H1 <= 0 || Hv <= 0 || A <= 0 || Q <= 0 || !ga || !gv || !wo || !wq || !both || !g || !db || !partial || blocks <= 0)
+    return fail(MIRL_ERR_ARG, "bad dueling_tail_bwd arguments");
+  if (A > MIRL_TAIL_MAXK || Q > MIRL_TAIL_MAXK || (H1 % 4) || !pow2_quads(H1 + Hv) || !aligned16(both) || !aligned16(g) || !aligned16(partial))
+    return fail(MIRL_ERR_ARG, "dueling_tail_bwd: outputs per branch <= 16, H1 % 4 == 0, H1 + Hv = 4 * 2^k <= 1024, 16-byte aligned pointers");
+  hipStream_t st = (hipStream_t)stream;
+  const int C = H1 + Hv;
+  const int64_t rpb = (M + blocks - 1) / blocks;
+  {
+    ProfScope ps("k_tail_bwd", 2.0 * M * C * 4 + (double)M * (A + Q) * 4, st);
+    hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)blocks), dim3(256), 0, st, ga, gv, wo, wq, (const nn_f4*)both, (nn_f4*)g, (nn_f4*)partial,
+                       M, (int)H1, (int)Hv, (int)A, (int)Q, rpb);
   }
   MIRL_LAUNCH_CHECK();
   {

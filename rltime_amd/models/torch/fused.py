@@ -207,15 +207,29 @@ class _DuelingTail(torch.autograd.Function):
         x, w1, wo, wv, wq, both = ctx.saved_tensors
         h1 = ctx.h1
         ga, gv = ga.contiguous(), gv.contiguous()
-        d_both = torch.empty_like(both)
-        torch.mm(ga, wo, out=d_both[:, :h1])
-        torch.mm(gv, wq, out=d_both[:, h1:])
         width = both.shape[1]
-        if _pow2_quads(width):
-            g, db = relu_bwd_bias_rows(d_both, both, width)
+        if (_pow2_quads(width) and h1 % 4 == 0 and ga.shape[1] <= 16 and gv.shape[1] <= 16
+                and wo.is_contiguous() and wq.is_contiguous()):
+            # [ga @ wo | gv @ wq], ReLU mask and bias gradient in ONE pass over `both`
+            L = _lib()
+            M = both.shape[0]
+            blocks = C.c_int32()
+            L.check(L.lib.mirl_colsum_blocks(M, width, C.byref(blocks)))
+            g = torch.empty_like(both)
+            db = torch.empty(width, dtype=torch.float32, device=both.device)
+            partial = torch.empty((blocks.value, width), dtype=torch.float32, device=both.device)
+            L.check(L.lib.mirl_dueling_tail_bwd(M, h1, width - h1, ga.shape[1], gv.shape[1], _p(ga), _p(gv), _p(wo), _p(wq),
+                                                _p(both), _p(g), _p(db), _p(partial), blocks.value, _stream()),
+                    "mirl_dueling_tail_bwd")
         else:
-            g = torch.ops.aten.threshold_backward(d_both, both, 0.0)
-            db = g.sum(0)
+            d_both = torch.empty_like(both)
+            torch.mm(ga, wo, out=d_both[:, :h1])
+            torch.mm(gv, wq, out=d_both[:, h1:])
+            if _pow2_quads(width):
+                g, db = relu_bwd_bias_rows(d_both, both, width)
+            else:
+                g = torch.ops.aten.threshold_backward(d_both, both, 0.0)
+                db = g.sum(0)
         # data / weight gradients per branch on the two column blocks (strided views):
         # hipBLASLt's 512-wide kernels measured faster than one 1024-wide GEMM here
         # (10.3 + 11.5 ms merged vs 4 x 3.55 ms, profiles/r02b)

@@ -17,6 +17,17 @@ for w in $WHAT; do
     dedup)   timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --frame-dedup > "$OUT/bench_dedup.json" 2> "$OUT/bench_dedup.err"; echo "dedup rc=$?"; tail -c 600 "$OUT/bench_dedup.err"; head -c 2500 "$OUT/bench_dedup.json"; echo;;
     tests1)  timeout 600 python -m pytest tests/test_multirank_gpu.py -x -q --timeout 300 -o faulthandler_timeout=240 > "$OUT/pytest_multirank.log" 2>&1; echo "pytest multirank rc=$?"; tail -40 "$OUT/pytest_multirank.log";;
     find)    timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 --miopen-find > "$OUT/bench_miopen_find.json" 2> "$OUT/bench_miopen_find.err"; echo "find rc=$?"; tail -c 400 "$OUT/bench_miopen_find.err"; head -c 700 "$OUT/bench_miopen_find.json"; echo;;
+    actprobe) R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/act_stats" -o act -- python "$R/tools/acting_probe.py" 200 > "$R/$OUT/acting_probe.json" 2> "$R/$OUT/acting_probe.err"); echo "actprobe rc=$?"; cat "$OUT/acting_probe.json"; python - "$OUT" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/act_stats/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0]))) if f else []
+steps = 230.0
+print("%8s %9s %9s  %s" % ("calls/st", "us/step", "avg_us", "kernel"))
+for r in rows[:45]:
+    print("%8.2f %9.2f %9.2f  %s" % (int(r["Calls"]) / steps, float(r["TotalDurationNs"]) / 1e3 / steps, float(r["AverageNs"]) / 1e3, r["Name"][:110]))
+print("total us/step", sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / steps)
+PY
+      find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
