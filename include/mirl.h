@@ -348,6 +348,16 @@ int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t 
  * (reward, length) of the episodes that ended at this step (length 0 = none);
  * action_counts [A] accumulates (may be NULL).  The host reads the out rows back
  * asynchronously.                                                                  */
+/* The acting head after the network, one launch per vector step: adv (E*N, A) and the
+ * optional dueling value val (E*N, Q; only column 0 is used) -> q[e][a] = mean over
+ * the N quantile rows of (val + adv - mean_a adv) (policies/torch/dqn.py:74-87,
+ * iqn.py actor post-processing), greedy action (first maximum), epsilon-greedy remap
+ * (exploration/epsilon_greedy.py:74-100): per-env epsilon = max(eps ** expo[e], eps_min),
+ * action := rnd[e] when u[e] < epsilon.  eps NULL = no exploration; val NULL = plain
+ * (non-dueling) outputs.  eps / expo are device doubles (eps one value).           */
+int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
+                    const double* eps, const double* expo, double eps_min, const float* u, const int64_t* rnd,
+                    int32_t* actions, float* qvalues, float* eps_used, void* stream);
 int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,
                        const int32_t* actions, float* ep_reward, int32_t* ep_len,
                        float* out_reward, int32_t* out_len, int32_t* action_counts, void* stream);

@@ -147,6 +147,7 @@ _SIGNATURES = {
     "mirl_iqn_mul_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_iqn_mul_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_dueling_tail_bwd": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_copy_bytes": [_vp, _vp, _i64, _vp],
     "mirl_book_create": [_P(ReplayConfig), _P(_vp)],

@@ -46,15 +46,11 @@ class GraphedStep:
             return states, _pack_state(states)
 
         def tail(states):
-            pred = pol.actor_predict(states, timesteps=1, as_numpy=False)
-            actions = pred["actions"]
-            if actor._exploration is not None:
-                actions, _ = actor._exploration.remap_with_eps_tensor(
-                    actions, self.eps, actor._env_ids, actor._action_space)
+            actions, qvalues = actor._select(states, self.eps)
             for layer, (h, c) in zip(self.rec, self.carry):
                 h.copy_(layer.last_state[0])
                 c.copy_(layer.last_state[1])
-            return actions.to(torch.int32), pred["qvalues"].contiguous()
+            return actions, qvalues
 
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -186,12 +182,52 @@ class Actor(ActingInterface):
         return samples
 
     def _act_eager(self, state):
-        pred = self._policy.actor_predict(state, timesteps=1, as_numpy=False)
-        actions = pred["actions"]
+        eps = None
         if self._exploration is not None:
-            actions, _ = self._exploration.remap_actions_device(
-                actions, self._env_ids, self._action_space, self._progress)
-        return actions.to(torch.int32), pred["qvalues"].contiguous()
+            eps = torch.as_tensor(self._exploration._get_eps(self._progress), dtype=torch.float64,
+                                  device=self._policy.device())
+        return self._select(state, eps)
+
+    def _select(self, state, eps):
+        """Policy forward -> greedy action -> epsilon-greedy remap for one vector step
+        (actor.py:108-122), everything after the network in ONE launch
+        (csrc/acting.hip k_actor_head) when the policy exposes its raw head outputs.
+        `eps`: 0-dim float64 device tensor holding the base epsilon (None = greedy)."""
+        import ctypes as C
+        pol = self._policy
+        expl = self._exploration
+        fused = getattr(self, "fused_head", True) and hasattr(pol, "actor_head_raw") and pol.is_cuda() \
+            and (expl is None or hasattr(expl, "_device_exponents"))
+        if not fused:
+            pred = pol.actor_predict(state, timesteps=1, as_numpy=False)
+            actions = pred["actions"]
+            if expl is not None:
+                actions, _ = expl.remap_with_eps_tensor(actions, eps, self._env_ids, self._action_space)
+            return actions.to(torch.int32), pred["qvalues"].contiguous()
+        from rltime_amd._lib import lib, check
+        adv, val, n = pol.actor_head_raw(state, 1)
+        adv = adv.contiguous()
+        A = adv.shape[1]
+        E = adv.shape[0] // n
+        dev = adv.device
+        actions = torch.empty(E, dtype=torch.int32, device=dev)
+        qvalues = torch.empty((E, A), dtype=torch.float32, device=dev)
+        u = rnd = expo = None
+        eps_min = 0.0
+        if expl is not None:
+            # same draws, same order as EpsilonGreedyExplorationManager.remap_with_eps_tensor
+            u = torch.rand(E, device=dev)
+            rnd = torch.randint(0, self._action_space.n, (E,), device=dev)
+            expo = expl._device_exponents(self._env_ids, dev)
+            eps_min = float(expl.eps_min)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)   # noqa: E731
+        if val is not None:
+            val = val.contiguous()
+        check(lib.mirl_actor_head(E, n, A, p(adv), p(val), val.shape[1] if val is not None else 0,
+                                  p(eps) if expl is not None else C.c_void_p(None), p(expo), eps_min, p(u), p(rnd),
+                                  p(actions), p(qvalues), C.c_void_p(None),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_actor_head")
+        return actions, qvalues
 
     def _device_steps(self, iters):
         out, pending = None, None

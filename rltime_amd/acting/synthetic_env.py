@@ -10,6 +10,7 @@ from rltime_amd.spaces import Box, Discrete
 
 
 class SyntheticAtariVecEnv:
+    POOL = 512
     def __init__(self, num_envs, frame_shape=(4, 84, 84), n_actions=6, done_prob=0.002,
                  reward_probs=(0.1, 0.8, 0.1), device="cuda", seed=0, pool=8, frame_stack=False):
         self.num_envs = num_envs
@@ -32,6 +33,10 @@ class SyntheticAtariVecEnv:
             if self.frame_stack else None
         self._cum = torch.tensor(np.cumsum(reward_probs), device=self.device, dtype=torch.float32)
         self._t = 0
+        # rewards / dones are pre-drawn for POOL steps at a time (like the frames, their
+        # synthesis is not what is being measured): one burst of kernels per 512 steps
+        # instead of six tiny launches per step
+        self._sched, self._sched_at = None, 0
         self._ep_reward = torch.zeros(num_envs, device=self.device)
         self._ep_len = torch.zeros(num_envs, device=self.device)
 
@@ -45,9 +50,12 @@ class SyntheticAtariVecEnv:
     def step_device(self, actions):
         self._t += 1
         obs = self._pool[self._t % len(self._pool)]
-        u = torch.rand(2, self.num_envs, device=self.device, generator=self._g)
-        rewards = torch.bucketize(u[0], self._cum).clamp(max=2).float() - 1.0
-        dones = u[1] < self.done_prob
+        if self._sched is None or self._sched_at == self.POOL:
+            u = torch.rand(2, self.POOL, self.num_envs, device=self.device, generator=self._g)
+            self._sched = (torch.bucketize(u[0], self._cum).clamp(max=2).float() - 1.0, u[1] < self.done_prob)
+            self._sched_at = 0
+        rewards, dones = self._sched[0][self._sched_at], self._sched[1][self._sched_at]
+        self._sched_at += 1
         if self.frame_stack:
             keep = (~dones).to(torch.uint8).view(-1, 1, 1, 1)
             nxt = torch.empty_like(self._stack)
@@ -63,11 +71,15 @@ class SyntheticAtariVecEnv:
 
     def get_state(self):
         return {"t": self._t, "generator": self._g.get_state().cpu(),
+                "sched": None if self._sched is None else (self._sched[0].cpu(), self._sched[1].cpu(), self._sched_at),
                 "stack": None if self._stack is None else self._stack.cpu()}
 
     def set_state(self, state):
         self._t = state["t"]
         self._g.set_state(state["generator"].cpu())
+        if state.get("sched") is not None:
+            self._sched = (state["sched"][0].to(self.device), state["sched"][1].to(self.device))
+            self._sched_at = state["sched"][2]
         if state.get("stack") is not None and self._stack is not None:
             self._stack = state["stack"].to(self.device)
 

@@ -220,18 +220,21 @@ k_iqn_mul_bwd(const nn_f4* __restrict__ g, const nn_f4* __restrict__ emb, const 
 // in registers, `both` is read once and g written once.  Lane = one column quad for
 // the whole sweep (its 4 x A weights stay in registers), block = a row range.
 #define MIRL_TAIL_MAXK 16
+#define MIRL_TAIL_ROWS 16
 __global__ void __launch_bounds__(256)
 k_tail_bwd(const float* __restrict__ ga, const float* __restrict__ gv, const float* __restrict__ wo,
            const float* __restrict__ wq, const nn_f4* __restrict__ both, nn_f4* __restrict__ g,
            nn_f4* __restrict__ partial, int64_t rows, int H1, int Hv, int A, int Q, int64_t rpb) {
   __shared__ nn_f4 s_acc[256];
+  __shared__ float s_ga[MIRL_TAIL_ROWS * MIRL_TAIL_MAXK];
+  __shared__ float s_gv[MIRL_TAIL_ROWS * MIRL_TAIL_MAXK];
   const int C = H1 + Hv, CQ = C / 4, tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
   const int c0 = cq * 4;
   const bool adv = c0 < H1;
   const int K = adv ? A : Q;
   const float* w = adv ? wo + c0 : wq + (c0 - H1);
   const int ldw = adv ? H1 : Hv;
-  const float* gsrc = adv ? ga : gv;
+  const float* sg = adv ? s_ga : s_gv;
   nn_f4 wk[MIRL_TAIL_MAXK];
 #pragma unroll
   for (int k = 0; k < MIRL_TAIL_MAXK; ++k)
@@ -240,32 +243,42 @@ k_tail_bwd(const float* __restrict__ ga, const float* __restrict__ gv, const flo
   const int64_t r0 = (int64_t)blockIdx.x * rpb;
   int64_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
   nn_f4 acc = {0.f, 0.f, 0.f, 0.f};
-  int64_t r = r0 + rl;
-  for (; r + 3 * RL < r1; r += 4 * RL) {              // four rows in flight per lane
-    nn_f4 b[4];
+  // chunks of 16 rows: their (16 x A) and (16 x Q) output-gradient rows are staged in
+  // LDS with one coalesced load, every lane then reads them as LDS broadcasts
+  for (int64_t base = r0; base < r1; base += MIRL_TAIL_ROWS) {
+    const int nr = r1 - base < MIRL_TAIL_ROWS ? (int)(r1 - base) : MIRL_TAIL_ROWS;
+    __syncthreads();
+    for (int i = tid; i < nr * A; i += 256) s_ga[i] = ga[base * A + i];
+    for (int i = tid; i < nr * Q; i += 256) s_gv[i] = gv[base * Q + i];
+    __syncthreads();
+    int u = rl;
+    for (; u + 3 * RL < nr; u += 4 * RL) {               // four rows in flight per lane
+      nn_f4 b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = both[(r + (int64_t)u * RL) * CQ + cq];
+      for (int v = 0; v < 4; ++v) b[v] = both[(base + u + v * RL) * CQ + cq];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* gr = gsrc + (r + (int64_t)u * RL) * K;
+      for (int v = 0; v < 4; ++v) {
+        const float* gr = sg + (u + v * RL) * K;
+        nn_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
+        MIRL_MASK(d, b[v])
+        g[(base + u + v * RL) * CQ + cq] = d;
+        acc = acc + d;
+      }
+    }
+    for (; u < nr; u += RL) {
+      const nn_f4 b = both[(base + u) * CQ + cq];
+      const float* gr = sg + u * K;
       nn_f4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
-      MIRL_MASK(d, b[u])
-      g[(r + (int64_t)u * RL) * CQ + cq] = d;
+      MIRL_MASK(d, b)
+      g[(base + u) * CQ + cq] = d;
       acc = acc + d;
     }
   }
-  for (; r < r1; r += RL) {
-    const nn_f4 b = both[r * CQ + cq];
-    const float* gr = gsrc + r * K;
-    nn_f4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
-    MIRL_MASK(d, b)
-    g[r * CQ + cq] = d;
-    acc = acc + d;
-  }
+  __syncthreads();
   s_acc[tid] = acc;
   __syncthreads();
   if (rl == 0) {

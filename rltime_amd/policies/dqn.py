@@ -77,6 +77,30 @@ class DQNPolicy(TorchPolicy):
     def _tail_postprocess(self, output, model_output):
         return output
 
+    def _samples_per_state(self):
+        return 1
+
+    def actor_head_raw(self, inp, timesteps):
+        """The network outputs the acting head starts from, WITHOUT the dueling
+        combine / quantile mean / argmax (those run fused in csrc/acting.hip for the
+        device-resident actor): (adv (rows, A), val (rows, q) or None, samples per state)."""
+        with torch.no_grad():
+            fc = self._fused_tail_layer()
+            if fc is not None:
+                res = self.model(inp, timesteps, skip_last=True)
+                inner = res["output"].reshape(-1, fc.in_features)
+                adv, val = dueling_tail(inner, fc, self.out_layer, self.value_hidden_layer, self.value_layer)
+                return adv, val, self._samples_per_state()
+            res = self.model(inp, timesteps)
+            adv = self.out_layer(res["output"])
+            val = None
+            if self.value_layer is not None:
+                state_layer = res["layer_inputs"][-1]
+                state_layer = state_layer.reshape(state_layer.shape[0], -1)
+                val = self.value_layer(linear_relu(state_layer, self.value_hidden_layer.weight,
+                                                   self.value_hidden_layer.bias))
+            return adv, val, self._samples_per_state()
+
     def _actor_predict_postprocess(self, pred):
         return pred
 

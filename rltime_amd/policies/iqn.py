@@ -55,6 +55,9 @@ class IQNPolicy(DQNPolicy):
     def _tail_postprocess(self, output, model_output):
         return output, model_output["quantiles"]
 
+    def _samples_per_state(self):
+        return self.num_sampling_quantiles
+
     def _actor_predict_postprocess(self, pred):
         assert pred[0].shape[1] == self.num_sampling_quantiles
         return pred[0].mean(1)
