@@ -87,6 +87,65 @@ class _LSTMSequence(torch.autograd.Function):
         return d_x, d_wih, d_whh, d_b, None, None, None
 
 
+class _LSTMSequenceFromProjection(torch.autograd.Function):
+    """The same recurrence on an input projection computed elsewhere (gx (T, B, 4H) =
+    x W_ih^T + b_ih + b_hh, possibly a slice of a larger shared block): gx is left
+    untouched (it may have other consumers), so the gates buffer is a copy of it."""
+
+    @staticmethod
+    def forward(ctx, gx, w_hh, h0, c0, keep):
+        T, B, G = gx.shape
+        H = G // 4
+        w = w_hh.float().contiguous()
+        keep = keep.float().contiguous()
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dev = gx.device
+        gates = gx.float().clone(memory_format=torch.contiguous_format)
+        hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+        out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev) if need_grad else None
+        torch.mul(h0.float(), keep[0].unsqueeze(-1), out=hm[0])
+        torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
+        wt = w.t()
+        st = _stream()
+        for t in range(T):
+            gates[t].addmm_(hm[t], wt)
+            check(lib.mirl_lstm_cell_fwd(
+                B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+                "mirl_lstm_cell_fwd")
+        if need_grad:
+            ctx.save_for_backward(gates, c_all, cm, hm, keep, w)
+        h_last, c_last = hm[T], cm[T]
+        ctx.mark_non_differentiable(h_last, c_last)
+        return out, h_last, c_last
+
+    @staticmethod
+    def backward(ctx, d_out, _dh, _dc):
+        gates, c_all, cm, hm, keep, w = ctx.saved_tensors
+        T, B, G = gates.shape
+        H = G // 4
+        d_out = d_out.float().contiguous()
+        dh_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+        dc_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+        st = _stream()
+        for t in range(T - 1, -1, -1):
+            check(lib.mirl_lstm_cell_bwd(
+                B, H, _p(gates[t]), _p(c_all[t]), _p(cm[t]), _p(d_out[t]), _p(dh_rec), _p(dc_rec),
+                _p(keep[t + 1]) if t + 1 < T else None, 1 if t == T - 1 else 0, st),
+                "mirl_lstm_cell_bwd")
+            if t > 0:
+                torch.mm(gates[t], w, out=dh_rec)
+        d_whh = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[1] else None
+        return gates, d_whh, None, None, None
+
+
+def lstm_sequence_from_projection(gx, w_hh, h0, c0, keep):
+    """gx (T, B, 4H) -> (out (T,B,H), h_T, c_T)."""
+    return _LSTMSequenceFromProjection.apply(gx, w_hh, h0, c0, keep)
+
+
 def lstm_sequence(x, w_ih, w_hh, bias, h0, c0, keep):
     """x (T*B, I) -> (out (T,B,H), h_T (B,H), c_T (B,H)); keep (T, B) = 1 - initials."""
     return _LSTMSequence.apply(x, w_ih, w_hh, bias, h0, c0, keep)

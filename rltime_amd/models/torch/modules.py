@@ -152,7 +152,26 @@ class LSTM(BaseModule):
         init_weight(self.lstm_cell.weight_hh)
         init_weight(self.lstm_cell.weight_ih)
 
-    def forward(self, x, hx, cx, initials, timesteps):
+    def project_input(self, x):
+        """x W_ih^T + b_ih + b_hh for every row of x: the part of the sequence forward
+        that does not depend on the recurrent state.  A caller that runs this layer
+        over overlapping row ranges of one block (the online net's training pass and
+        its double-Q selection pass, MultiStepTrainer._share_online_features) computes
+        it once and hands each pass its rows through forward(projected=...)."""
+        cell = self.lstm_cell
+        return F.linear(x.reshape(-1, self.inp_size), cell.weight_ih, cell.bias_ih + cell.bias_hh)
+
+    def forward(self, x, hx, cx, initials, timesteps, projected=None):
+        if projected is not None and projected.is_cuda and self.fused and projected.shape[0] == hx.shape[0]:
+            from .lstm_seq import lstm_sequence_from_projection
+            batch = projected.shape[0] // timesteps
+            h0 = hx.reshape(timesteps, batch, self.num_units)[0]
+            c0 = cx.reshape(timesteps, batch, self.num_units)[0]
+            out, h_last, c_last = lstm_sequence_from_projection(
+                projected.reshape(timesteps, batch, -1), self.lstm_cell.weight_hh, h0, c0,
+                (1 - initials).reshape(timesteps, batch))
+            self.last_state = (h_last.detach(), c_last.detach())
+            return out.reshape(timesteps * batch, self.num_units)
         x = x.reshape(-1, self.inp_size)
         assert hx.shape[1] == self.num_units and cx.shape[1] == self.num_units
         assert x.shape[0] % hx.shape[0] == 0

@@ -113,6 +113,10 @@ class SequentialModel(nn.Module):
         # scale, NHWC) by CNN.prepare_input — one conversion of the gathered block
         # serves every pass of a learner step
         prepared = inp.get("x_prepared")
+        # optional: the input projection of recurrent layer 1 computed earlier for
+        # exactly these rows by THIS model (same sharing, one layer further)
+        shared_proj = inp.get("x_projected")
+        projected = shared_proj.get(id(self)) if isinstance(shared_proj, dict) else None
         extra = None
         if isinstance(x, (tuple, list)):
             x, extra = x[0], torch.cat([v.reshape(v.shape[0], -1) for v in x[1:]], dim=-1)
@@ -132,6 +136,9 @@ class SequentialModel(nn.Module):
                 break
             if i == 0 and first_out is not None:
                 x = first_out
+            elif i == 1 and projected is not None and first_out is not None and i != self.extra_input_layer \
+                    and i not in self.layer_pre_processors and hasattr(layer, "project_input"):
+                x = layer(x, timesteps=timesteps, projected=projected, **inp.get("layer%d_state" % i, {}))
             elif i == 0 and prepared is not None and self.extra_input_layer != 0 and 0 not in self.layer_pre_processors:
                 x = layer(prepared, timesteps=timesteps, prepared=True, **inp.get("layer0_state", {}))
             else:

@@ -6,7 +6,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rltime_amd._lib import lib, check  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 62464
