@@ -472,8 +472,9 @@ def main():
         if args.config == "iqn_lstm" and os.path.isfile(args.pmc_traffic):
             try:
                 traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/gather_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) over tools/gather_probe.py " \
-                              "at this B/T/P/n, collected by tools/profile_round.sh — NOT measured in this run"
+                traffic_src = "profiles/gather_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) over " \
+                              "tools/gather_probe.py with the same 1M-transition replay and B/T/P/n, collected by " \
+                              "`tools/gpu_round.sh <tag> pmc` — NOT measured in this run"
             except Exception:
                 traffic = None
         kernels = []
