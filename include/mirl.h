@@ -285,6 +285,14 @@ int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const float* z,
  * i.e. the masked inputs of the following step.  h_out / c_out may be NULL.     */
 int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, const float* keep_next,
                        float* h_out, float* c_out, float* h_next, float* c_next, void* stream);
+/* One whole LSTM step in one launch: gates [B][4H] holds the input projection (+ biases)
+ * on entry; the recurrent contribution h_in [B][H] x w_hh [4H][H]^T is accumulated on
+ * f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32) and the cell applied in the epilogue —
+ * same outputs as mirl_lstm_cell_fwd after `gates += h_in @ w_hh^T`.  B, H multiples
+ * of 32.                                                                            */
+int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates,
+                       const float* c_in, const float* keep_next, float* h_out, float* c_out,
+                       float* h_next, float* c_next, void* stream);
 /* Backward of one step: gates holds the activated gates on entry and
  * d loss / d pre-activation on exit; d_out [B][H] = grad of this step's output h
  * (NULL = 0); dh_rec / dc_rec = grads w.r.t. the next step's masked inputs

@@ -137,6 +137,7 @@ _SIGNATURES = {
     "mirl_loss_dqn": [_i64, _i32, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _vp, _vp, _vp, _vp],
     "mirl_loss_iqn": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp],
     "mirl_lstm_cell_fwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_lstm_step_fwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_lstm_cell_bwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_frames_to_f32_nhwc": [_i64, _i32, _i32, _vp, C.c_float, _vp, _vp],
     "mirl_frames_to_f32_nhwc_ex": [_i64, _i32, _i32, _vp, C.c_float, _vp, _i32, _i32, _vp],

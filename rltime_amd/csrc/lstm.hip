@@ -61,9 +61,124 @@ k_lstm_cell_bwd(int B, int H, float* __restrict__ gates, const float* __restrict
   dc_rec[idx] = dc * f;
 }
 
+// ---------------------------------------------------------------------------
+// One LSTM timestep in ONE launch: the recurrent GEMM on f32 MFMA with the cell in
+// its epilogue.  gates[b][g*H + j] += sum_k h_in[b][k] * W_hh[g*H + j][k]
+// is a real dense contraction (512 x 512 x 2048 per step at config D), so it runs on
+// v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered fmaf chain); what rocBLAS + the
+// pointwise kernel did in two launches with the 4 MB gate tensor written and
+// re-read in between now keeps the four gate blocks of a (32 batch x 32 hidden)
+// tile in one workgroup:
+//   * grid (H/32, B/32): 256 workgroups at B = H = 512 — one per CU;
+//   * wave g of the 4 computes gate g's 32x32 block, K streamed in chunks of 32
+//     through double-buffered LDS (global -> registers for chunk c+1 while chunk c
+//     feeds the MFMAs; rows padded to 33 floats: bank-conflict-free operand reads);
+//   * epilogue: the four accumulator blocks meet in LDS, every lane activates 4
+//     elements (sigmoid / tanh), updates c, h, applies the next step's reset mask
+//     and writes the activated gates for the backward pass.
+// Operand maps (cdna_hip_programming.md section 3): lane l supplies A[i=l&31][k=l>>5],
+// B[k=l>>5][j=l&31]; D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
+typedef float ls_f16 __attribute__((ext_vector_type(16)));
+typedef float ls_f4 __attribute__((ext_vector_type(4)));
+#define LS_KC 32
+#define LS_LD 33
+
+__global__ void __launch_bounds__(256)
+k_lstm_step_fwd(int B, int H, const float* __restrict__ h_in, const float* __restrict__ w, float* __restrict__ gates,
+                const float* __restrict__ c_in, const float* __restrict__ keep_next, float* __restrict__ h_out,
+                float* __restrict__ c_out, float* __restrict__ h_next, float* __restrict__ c_next) {
+  __shared__ float sA[2][32 * LS_LD];
+  __shared__ float sB[2][4][32 * LS_LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;                 // loader: 32 rows x 8 quads
+  const float* gA = h_in + (int64_t)(b0 + lrow) * H + lk;
+  const float* gB = w + (int64_t)(j0 + lrow) * H + lk;           // + gate * H * H
+  const int64_t gate_stride = (int64_t)H * H;
+  ls_f4 ra, rb0, rb1, rb2, rb3;
+  auto fetch = [&](int k0) {
+    ra = *(const ls_f4*)(gA + k0);
+    rb0 = *(const ls_f4*)(gB + k0);
+    rb1 = *(const ls_f4*)(gB + gate_stride + k0);
+    rb2 = *(const ls_f4*)(gB + 2 * gate_stride + k0);
+    rb3 = *(const ls_f4*)(gB + 3 * gate_stride + k0);
+  };
+  auto stash = [&](int buf) {
+    float* a = &sA[buf][lrow * LS_LD + lk];
+    a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
+    float* q0 = &sB[buf][0][lrow * LS_LD + lk];
+    q0[0] = rb0.x; q0[1] = rb0.y; q0[2] = rb0.z; q0[3] = rb0.w;
+    float* q1 = &sB[buf][1][lrow * LS_LD + lk];
+    q1[0] = rb1.x; q1[1] = rb1.y; q1[2] = rb1.z; q1[3] = rb1.w;
+    float* q2 = &sB[buf][2][lrow * LS_LD + lk];
+    q2[0] = rb2.x; q2[1] = rb2.y; q2[2] = rb2.z; q2[3] = rb2.w;
+    float* q3 = &sB[buf][3][lrow * LS_LD + lk];
+    q3[0] = rb3.x; q3[1] = rb3.y; q3[2] = rb3.z; q3[3] = rb3.w;
+  };
+  ls_f16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int chunks = H / LS_KC;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int orow = (lane & 31) * LS_LD + (lane >> 5);            // operand address of this lane for k-pair 0
+  for (int c = 0; c < chunks; ++c) {
+    if (c + 1 < chunks) fetch((c + 1) * LS_KC);
+    const float* a = &sA[c & 1][orow];
+    const float* b = &sB[c & 1][wave][orow];
+#pragma unroll
+    for (int kk = 0; kk < LS_KC / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk], acc, 0, 0, 0);
+    if (c + 1 < chunks) stash((c + 1) & 1);
+    __syncthreads();
+  }
+  // the four gate blocks meet in LDS (sB[0] is free after the last barrier)
+  float* G = &sB[0][0][0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    G[(wave * 32 + row) * LS_LD + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, col = e & 31;
+    const int b = b0 + row, j = j0 + col;
+    float* g = gates + (int64_t)b * 4 * H + j;
+    const float pi = G[(0 * 32 + row) * LS_LD + col] + g[0];
+    const float pf = G[(1 * 32 + row) * LS_LD + col] + g[H];
+    const float pg = G[(2 * 32 + row) * LS_LD + col] + g[2 * H];
+    const float po = G[(3 * 32 + row) * LS_LD + col] + g[3 * H];
+    const float i = sigmoidf_(pi), f = sigmoidf_(pf), gg = tanhf(pg), o = sigmoidf_(po);
+    const int64_t idx = (int64_t)b * H + j;
+    const float cc = f * c_in[idx] + i * gg;
+    const float hh = o * tanhf(cc);
+    g[0] = i; g[H] = f; g[2 * H] = gg; g[3 * H] = o;
+    if (h_out) h_out[idx] = hh;
+    if (c_out) c_out[idx] = cc;
+    const float k = keep_next ? keep_next[b] : 1.0f;
+    h_next[idx] = hh * k;
+    c_next[idx] = cc * k;
+  }
+}
+
 }  // namespace mirl
 
 using namespace mirl;
+
+extern "C" int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates, const float* c_in,
+                                  const float* keep_next, float* h_out, float* c_out, float* h_next, float* c_next, void* stream) {
+  if (B <= 0 || H <= 0 || !h_in || !w_hh || !gates || !c_in || !h_next || !c_next) return fail(MIRL_ERR_ARG, "bad lstm_step_fwd arguments");
+  if ((B % 32) || (H % 32)) return fail(MIRL_ERR_ARG, "lstm_step_fwd needs batch and hidden sizes that are multiples of 32");
+  if (((uintptr_t)h_in % 16) || ((uintptr_t)w_hh % 16)) return fail(MIRL_ERR_ARG, "lstm_step_fwd needs 16-byte aligned h_in / w_hh");
+  // algorithmic bytes: h_in + W_hh + c_in read, gates read + written, h, c, h_next, c_next written
+  ProfScope ps("k_lstm_step_fwd", 4.0 * ((double)B * H * 2 + 4.0 * H * H + 8.0 * B * H + 4.0 * B * H), (hipStream_t)stream);
+  hipLaunchKernelGGL(k_lstm_step_fwd, dim3(H / 32, B / 32), dim3(256), 0, (hipStream_t)stream, (int)B, (int)H, h_in, w_hh, gates, c_in,
+                     keep_next, h_out, c_out, h_next, c_next);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
 
 extern "C" int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, const float* keep_next,
                                   float* h_out, float* c_out, float* h_next, float* c_next, void* stream) {

@@ -15,7 +15,7 @@
 //   K32 op K32 -> K32 (f32 arithmetic)        K64 op any -> K64 (f64 arithmetic)
 //
 // Everything here is a pure function usable from device code and — for the
-// CPU-only unit tests of this header (tests/test_emul_host.py, which compare
+// CPU-only unit tests of this header (tests/test_host_logic.py, which compare
 // it with the golden tree fixtures) — from host code.  Compile with
 // -ffp-contract=off: a fused multiply-add would change the roundings.
 #pragma once
@@ -122,7 +122,7 @@ MIRL_HD int64_t tagged_descend(const double* tv, const uint8_t* tk,
 // sequential; <=128 eight interleaved accumulators combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail; larger inputs split at
 // n/2 rounded down to a multiple of 8.  Verified against np.mean for
-// n in [2, 1000] in tests/test_emul_host.py.
+// n in [2, 1000] in tests/test_host_logic.py.
 template <class T, class Get>
 MIRL_HD T np_pairwise_block(Get get, int lo, int n) {
   if (n < 8) {

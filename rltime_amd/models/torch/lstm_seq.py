@@ -7,9 +7,11 @@ Same recurrence as the reference's LSTMCell time loop with per-step reset
     gates = W_ih x(t) + b_ih + W_hh h_in + b_hh       (i, f, g, o)
     c(t) = sig(f) c_in + sig(i) tanh(g) ; h(t) = sig(o) tanh(c(t))
 
-but the input projection of all T steps is ONE GEMM, one step costs one rocBLAS
-GEMM (h_in @ W_hh^T accumulated IN PLACE onto its slice of that projection) plus
-one fused HIP kernel (csrc/lstm.hip: mirl_lstm_cell_fwd / _bwd), and the weight
+but the input projection of all T steps is ONE GEMM, a forward step is ONE launch
+(csrc/lstm.hip mirl_lstm_step_fwd: the recurrent GEMM h_in @ W_hh^T on f32 MFMA,
+accumulated onto its slice of that projection, with the cell in the epilogue; for
+sizes that are not multiples of 32: one rocBLAS GEMM in place + mirl_lstm_cell_fwd),
+a backward step one cell kernel (mirl_lstm_cell_bwd) + one rocBLAS GEMM, and the weight
 gradients of W_ih and W_hh are one GEMM each over all timesteps after the
 backward sweep.
 """
@@ -18,6 +20,11 @@ import ctypes as C
 import torch
 
 from rltime_amd._lib import lib, check
+
+
+import os
+
+_FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "1") != "0"
 
 
 def _p(t):
@@ -51,7 +58,15 @@ class _LSTMSequence(torch.autograd.Function):
         torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
         wt = w.t()
         st = _stream()
+        fused_step = _FUSED_STEP and B % 32 == 0 and H % 32 == 0
         for t in range(T):
+            if fused_step:
+                # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
+                check(lib.mirl_lstm_step_fwd(
+                    B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+                    _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+                    "mirl_lstm_step_fwd")
+                continue
             gates[t].addmm_(hm[t], wt)
             check(lib.mirl_lstm_cell_fwd(
                 B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
@@ -109,7 +124,15 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
         torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
         wt = w.t()
         st = _stream()
+        fused_step = _FUSED_STEP and B % 32 == 0 and H % 32 == 0
         for t in range(T):
+            if fused_step:
+                # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
+                check(lib.mirl_lstm_step_fwd(
+                    B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+                    _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+                    "mirl_lstm_step_fwd")
+                continue
             gates[t].addmm_(hm[t], wt)
             check(lib.mirl_lstm_cell_fwd(
                 B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
