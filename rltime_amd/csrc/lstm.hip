@@ -70,9 +70,10 @@ k_lstm_cell_bwd(int B, int H, float* __restrict__ gates, const float* __restrict
 // re-read in between now keeps the four gate blocks of a (32 batch x 32 hidden)
 // tile in one workgroup:
 //   * grid (H/32, B/32): 256 workgroups at B = H = 512 — one per CU;
-//   * wave g of the 4 computes gate g's 32x32 block, K streamed in chunks of 32
-//     through double-buffered LDS (global -> registers for chunk c+1 while chunk c
-//     feeds the MFMAs; rows padded to 33 floats: bank-conflict-free operand reads);
+//   * wave g of the 4 computes gate g's 32x32 block, K streamed
+//     through double-buffered LDS in chunks of 64 (global -> registers for chunk c+1
+//     while chunk c feeds the MFMAs; rows padded to 65 floats: conflict-free operand
+//     reads, all 32 operand pairs of a chunk requested before the first MFMA);
 //   * epilogue: the four accumulator blocks meet in LDS, every lane activates 4
 //     elements (sigmoid / tanh), updates c, h, applies the next step's reset mask
 //     and writes the activated gates for the backward pass.
@@ -80,8 +81,8 @@ k_lstm_cell_bwd(int B, int H, float* __restrict__ gates, const float* __restrict
 // B[k=l>>5][j=l&31]; D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5), r in [0,16).
 typedef float ls_f16 __attribute__((ext_vector_type(16)));
 typedef float ls_f4 __attribute__((ext_vector_type(4)));
-#define LS_KC 32
-#define LS_LD 33
+#define LS_KC 64
+#define LS_LD 65
 
 __global__ void __launch_bounds__(256)
 k_lstm_step_fwd(int B, int H, const float* __restrict__ h_in, const float* __restrict__ w, float* __restrict__ gates,
@@ -91,29 +92,30 @@ k_lstm_step_fwd(int B, int H, const float* __restrict__ h_in, const float* __res
   __shared__ float sB[2][4][32 * LS_LD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int j0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-  const int lrow = tid >> 3, lk = (tid & 7) * 4;                 // loader: 32 rows x 8 quads
+  const int lrow = tid >> 3, lk = (tid & 7) * 8;                 // loader: 32 rows x 8 lanes x 2 quads
   const float* gA = h_in + (int64_t)(b0 + lrow) * H + lk;
   const float* gB = w + (int64_t)(j0 + lrow) * H + lk;           // + gate * H * H
   const int64_t gate_stride = (int64_t)H * H;
-  ls_f4 ra, rb0, rb1, rb2, rb3;
+  ls_f4 ra[2], rb[4][2];
   auto fetch = [&](int k0) {
-    ra = *(const ls_f4*)(gA + k0);
-    rb0 = *(const ls_f4*)(gB + k0);
-    rb1 = *(const ls_f4*)(gB + gate_stride + k0);
-    rb2 = *(const ls_f4*)(gB + 2 * gate_stride + k0);
-    rb3 = *(const ls_f4*)(gB + 3 * gate_stride + k0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ra[h] = *(const ls_f4*)(gA + k0 + 4 * h);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rb[g][h] = *(const ls_f4*)(gB + g * gate_stride + k0 + 4 * h);
+    }
   };
   auto stash = [&](int buf) {
-    float* a = &sA[buf][lrow * LS_LD + lk];
-    a[0] = ra.x; a[1] = ra.y; a[2] = ra.z; a[3] = ra.w;
-    float* q0 = &sB[buf][0][lrow * LS_LD + lk];
-    q0[0] = rb0.x; q0[1] = rb0.y; q0[2] = rb0.z; q0[3] = rb0.w;
-    float* q1 = &sB[buf][1][lrow * LS_LD + lk];
-    q1[0] = rb1.x; q1[1] = rb1.y; q1[2] = rb1.z; q1[3] = rb1.w;
-    float* q2 = &sB[buf][2][lrow * LS_LD + lk];
-    q2[0] = rb2.x; q2[1] = rb2.y; q2[2] = rb2.z; q2[3] = rb2.w;
-    float* q3 = &sB[buf][3][lrow * LS_LD + lk];
-    q3[0] = rb3.x; q3[1] = rb3.y; q3[2] = rb3.z; q3[3] = rb3.w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* a = &sA[buf][lrow * LS_LD + lk + 4 * h];
+      a[0] = ra[h].x; a[1] = ra[h].y; a[2] = ra[h].z; a[3] = ra[h].w;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float* q = &sB[buf][g][lrow * LS_LD + lk + 4 * h];
+        q[0] = rb[g][h].x; q[1] = rb[g][h].y; q[2] = rb[g][h].z; q[3] = rb[g][h].w;
+      }
+    }
   };
   ls_f16 acc;
 #pragma unroll
@@ -127,9 +129,15 @@ k_lstm_step_fwd(int B, int H, const float* __restrict__ h_in, const float* __res
     if (c + 1 < chunks) fetch((c + 1) * LS_KC);
     const float* a = &sA[c & 1][orow];
     const float* b = &sB[c & 1][wave][orow];
+    // all 32 operand pairs of the chunk are requested from LDS up front, so the MFMAs
+    // issue back to back (the LDS latency is paid once per chunk, not once per pair)
+    float av[LS_KC / 2], bv[LS_KC / 2];
+#pragma unroll
+    for (int kk = 0; kk < LS_KC / 2; ++kk) { av[kk] = a[2 * kk]; bv[kk] = b[2 * kk]; }
+    __builtin_amdgcn_sched_barrier(0);        // keep the LDS reads ahead of the MFMA chain
 #pragma unroll
     for (int kk = 0; kk < LS_KC / 2; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * kk], b[2 * kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
     if (c + 1 < chunks) stash((c + 1) & 1);
     __syncthreads();
   }
@@ -170,7 +178,7 @@ using namespace mirl;
 extern "C" int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates, const float* c_in,
                                   const float* keep_next, float* h_out, float* c_out, float* h_next, float* c_next, void* stream) {
   if (B <= 0 || H <= 0 || !h_in || !w_hh || !gates || !c_in || !h_next || !c_next) return fail(MIRL_ERR_ARG, "bad lstm_step_fwd arguments");
-  if ((B % 32) || (H % 32)) return fail(MIRL_ERR_ARG, "lstm_step_fwd needs batch and hidden sizes that are multiples of 32");
+  if ((B % 32) || (H % 64)) return fail(MIRL_ERR_ARG, "lstm_step_fwd needs a batch that is a multiple of 32 and a hidden size that is a multiple of 64");
   if (((uintptr_t)h_in % 16) || ((uintptr_t)w_hh % 16)) return fail(MIRL_ERR_ARG, "lstm_step_fwd needs 16-byte aligned h_in / w_hh");
   // algorithmic bytes: h_in + W_hh + c_in read, gates read + written, h, c, h_next, c_next written
   ProfScope ps("k_lstm_step_fwd", 4.0 * ((double)B * H * 2 + 4.0 * H * H + 8.0 * B * H + 4.0 * B * H), (hipStream_t)stream);

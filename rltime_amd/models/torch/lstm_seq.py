@@ -58,7 +58,7 @@ class _LSTMSequence(torch.autograd.Function):
         torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
         wt = w.t()
         st = _stream()
-        fused_step = _FUSED_STEP and B % 32 == 0 and H % 32 == 0
+        fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
         for t in range(T):
             if fused_step:
                 # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
@@ -124,7 +124,7 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
         torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
         wt = w.t()
         st = _stream()
-        fused_step = _FUSED_STEP and B % 32 == 0 and H % 32 == 0
+        fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
         for t in range(T):
             if fused_step:
                 # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
