@@ -7,11 +7,11 @@ Same recurrence as the reference's LSTMCell time loop with per-step reset
     gates = W_ih x(t) + b_ih + W_hh h_in + b_hh       (i, f, g, o)
     c(t) = sig(f) c_in + sig(i) tanh(g) ; h(t) = sig(o) tanh(c(t))
 
-but the input projection of all T steps is ONE GEMM, a forward step is ONE launch
-(csrc/lstm.hip mirl_lstm_step_fwd: the recurrent GEMM h_in @ W_hh^T on f32 MFMA,
-accumulated onto its slice of that projection, with the cell in the epilogue; for
-sizes that are not multiples of 32: one rocBLAS GEMM in place + mirl_lstm_cell_fwd),
-a backward step one cell kernel (mirl_lstm_cell_bwd) + one rocBLAS GEMM, and the weight
+but the input projection of all T steps is ONE GEMM, a forward step is one rocBLAS
+GEMM accumulated IN PLACE onto its slice of that projection + one fused cell kernel
+(csrc/lstm.hip mirl_lstm_cell_fwd) — or, opt-in, ONE launch (mirl_lstm_step_fwd: the
+recurrent GEMM on f32 MFMA with the cell in its epilogue) —, a backward step one cell
+kernel (mirl_lstm_cell_bwd) + one rocBLAS GEMM, and the weight
 gradients of W_ih and W_hh are one GEMM each over all timesteps after the
 backward sweep.
 """
@@ -24,7 +24,12 @@ from rltime_amd._lib import lib, check
 
 import os
 
-_FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "1") != "0"
+# The one-launch step kernel (recurrent GEMM on f32 MFMA + cell epilogue) is correct
+# (tests/test_lstm_gpu.py) but measured 21.3 us per step against 12.6 us (rocBLAS GEMM)
+# + 5.7 us (cell kernel) + ~1.5 us launch gap for the two-launch path at B = H = 512
+# (profiles/README.md round 2) — one wave per SIMD cannot hide its prologue / epilogue /
+# barrier latencies.  Off by default; MIRL_LSTM_FUSED_STEP=1 selects it.
+_FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "0") == "1"
 
 
 def _p(t):

@@ -9,9 +9,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("T,B,I,H", [(1, 3, 5, 4), (7, 5, 12, 8), (20, 33, 40, 64), (80, 16, 64, 512),
-                                     (5, 32, 24, 32), (12, 64, 40, 96), (9, 256, 48, 512)])   # last three: fused MFMA step kernel
-def test_fused_lstm_matches_loop(T, B, I, H):
+                                     (5, 32, 24, 64), (12, 64, 40, 128), (9, 256, 48, 512)])
+@pytest.mark.parametrize("step_kernel", [False, True])
+def test_fused_lstm_matches_loop(T, B, I, H, step_kernel, monkeypatch):
+    from rltime_amd.models.torch import lstm_seq
     from rltime_amd.models.torch.modules import LSTM
+    if step_kernel and (B % 32 or H % 64):
+        pytest.skip("the one-launch step kernel needs B % 32 == 0 and H % 64 == 0")
+    monkeypatch.setattr(lstm_seq, "_FUSED_STEP", step_kernel)
     torch.manual_seed(T * 100 + B)
     a = LSTM((I,), H).cuda()
     b = LSTM((I,), H).cuda()
@@ -125,7 +130,7 @@ def test_prepared_input_feeds_the_same_values():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("B,H", [(32, 32), (64, 96), (512, 512), (256, 512)])
+@pytest.mark.parametrize("B,H", [(32, 64), (64, 192), (512, 512), (256, 512)])
 def test_fused_lstm_step_kernel_matches_gemm_plus_cell(B, H):
     """mirl_lstm_step_fwd (recurrent GEMM on f32 MFMA + cell epilogue, one launch)
     against the two-launch path it replaces (rocBLAS addmm_ + mirl_lstm_cell_fwd) on
