@@ -183,6 +183,26 @@ int mirl_replay_sample(mirl_replay* h, int32_t mbatch, double train_progress,
  * divided by.  With the active-sequence count (mirl_replay_stats) this is what
  * ranks exchange to turn shard-local importance weights into global ones
  * (rltime_amd/parallel.py).                                                   */
+/* Exact global sampling over env-sharded replays (no reference counterpart; SURVEY.md
+ * section 8(e)2).  mirl_replay_tree_root writes {sum of priorities, active sequences}
+ * of this shard to 2 device doubles; the ranks exchange them (rltime_amd/parallel.py)
+ * and every rank calls mirl_replay_sample_global with the same table shard_totals
+ * [world][2], the same seed and — because every rank makes the same sequence of calls —
+ * the same step counter: the mbatch_global strata of the global mass are drawn with
+ * one shared Philox stream and each goes to the shard whose cumulative range contains
+ * it, exactly as ONE tree over the concatenated shards would sample.  A rank gets a
+ * data-dependent number of strata, written in stratum order to the first rows of its
+ * `rows`-row outputs; the rest is padding (slot -1, env -1: mirl_replay_gather gives
+ * such rows no loss index, the caller gives them weight 0).  weight_raw (double) is
+ * (p / P_g * N_g)^-beta, un-normalised; stats (4 device doubles): P_g, the local max
+ * raw weight, strata kept, strata dropped because they exceeded `rows`.
+ * Quota / NEED_MORE behave like mirl_replay_sample with mbatch_local.             */
+int mirl_replay_tree_root(mirl_replay* h, double* root_dev, void* stream);
+int mirl_replay_sample_global(mirl_replay* h, int32_t mbatch_local, int32_t mbatch_global, int32_t rows,
+                              int32_t rank, int32_t world, const double* shard_totals,
+                              double train_progress, uint64_t seed, int32_t* slot, int32_t* env,
+                              int64_t* start, int64_t* loss_start, double* weight_raw,
+                              int32_t* stratum, double* stats, void* stream);
 /* uniform mode helper for the host RNG path: np.random.choice's `a` argument. */
 int mirl_replay_uniform_total(mirl_replay* h, int64_t* total);
 

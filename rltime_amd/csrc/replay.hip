@@ -126,12 +126,13 @@ k_dedup_depth(Dev d, const uint8_t* __restrict__ frames, const int32_t* __restri
     // reset observation's) become VIRTUAL predecessors in the ring slots -1, -2, ...
     // (mod C), which no live transition can occupy before they are out of reach
     u32x4* theirs = (u32x4*)(d.frames + ((int64_t)e * d.C + ((off - j) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
+    if (!have && !chain) same = 0;               // nothing stored to match and the chain is already cut: must be zero fill
     for (int q = threadIdx.x; q < nq; q += 256) {
       u32x4 a = mine[q];
       if (a.x | a.y | a.z | a.w) zero = 0;
       if (have) { u32x4 b = theirs[q]; if ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) same = 0; }
-      else theirs[q] = a;
-    }
+      else if (chain) theirs[q] = a;             // virtual predecessor (only while it continues this stack's chain:
+    }                                            //  a cut chain must not overwrite an older stack's virtual planes)
     same = __syncthreads_and(same);
     zero = __syncthreads_and(zero);
     if (chain && same) ++depth;
@@ -308,6 +309,87 @@ k_per_sample(Dev d, int B, const double* __restrict__ uniforms, uint64_t seed, u
   for (int i = threadIdx.x; i < B; i += 1024) w_out[i] = (float)(w_tmp[i] / top);
   if (stats && threadIdx.x == 0) { stats[0] = total.v; stats[1] = top; }
 }
+
+// ---------------------------------------------------------------------------
+// Exact global stratified sampling over env-sharded replays.
+// Every rank runs this kernel with the same Philox key / step counter and the same
+// table of shard totals; the B_g strata of the GLOBAL mass [0, sum_q P_q) are assigned
+// to the shard whose cumulative range [C_r, C_r + P_r) contains them — what one tree
+// over the concatenation of the shards' leaves would sample — so a rank draws a
+// data-dependent number of sequences (about B_g P_r / P_g).  Its batch has a fixed
+// B_pad rows; unused rows are padding (slot -1, env -1 -> weight 0, no loss index).
+// Cross-shard arithmetic is float64; the local descent uses the shard tree's own
+// tagged arithmetic with a float64 mass.  out: w_raw = (p/P_g N_g)^-beta (double),
+// stats = {P_g, local max raw weight, strata owned, strata dropped (B_pad overflow)}.
+__global__ void __launch_bounds__(1024)
+k_per_sample_global(Dev d, int Bg, int Bpad, int rank, int R, const double* __restrict__ shard, uint64_t seed, uint64_t call,
+                    double beta, int32_t* __restrict__ slot_out, int32_t* __restrict__ env_out, int64_t* __restrict__ start_out,
+                    int64_t* __restrict__ base_out, double* __restrict__ w_raw, int32_t* __restrict__ stratum_out,
+                    double* __restrict__ stats) {
+  __shared__ double s_tv[MIRL_LDS_NODES];
+  __shared__ uint8_t s_tk[MIRL_LDS_NODES];
+  __shared__ double s_red[16];
+  __shared__ int s_cnt[2][16];
+  const int64_t staged = 2 * d.cap < MIRL_LDS_NODES ? 2 * d.cap : MIRL_LDS_NODES;
+  for (int i = threadIdx.x; i < staged; i += 1024) { s_tv[i] = d.tv[i]; s_tk[i] = d.tk[i]; }
+  double Pg = 0.0, Ng = 0.0, Cr = 0.0;
+  for (int q = 0; q < R; ++q) { if (q < rank) Cr += shard[2 * q]; Pg += shard[2 * q]; Ng += shard[2 * q + 1]; }
+  const double Pr = shard[2 * rank], seg = Pg / (double)Bg;
+  const double hi_edge = rank == R - 1 ? INFINITY : Cr + Pr;
+  // pass 1: how many strata lie below this shard's range / inside it
+  int below = 0, mine = 0;
+  for (int i = threadIdx.x; i < Bg; i += 1024) {
+    const double mass = (philox_u53(seed, call, (uint32_t)i) + (double)i) * seg;
+    below += mass < Cr;
+    mine += mass >= Cr && mass < hi_edge;
+  }
+  for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); mine += __shfl_xor(mine, o); }
+  if ((threadIdx.x & 63) == 0) { s_cnt[0][threadIdx.x >> 6] = below; s_cnt[1][threadIdx.x >> 6] = mine; }
+  __syncthreads();
+  below = 0; mine = 0;
+  for (int k = 0; k < 16; ++k) { below += s_cnt[0][k]; mine += s_cnt[1][k]; }
+  // pass 2: owned strata, in stratum order, to rows [0, mine)
+  double local_max = 0.0;
+  for (int i = threadIdx.x; i < Bg; i += 1024) {
+    const double mass = (philox_u53(seed, call, (uint32_t)i) + (double)i) * seg;
+    if (!(mass >= Cr && mass < hi_edge)) continue;
+    const int p = i - below;
+    if (p >= Bpad) continue;                                    // counted as dropped below
+    TV m{mass - Cr, K64};
+    int64_t pos = 1;
+    while (pos < d.cap) {
+      int64_t c = 2 * pos;
+      TV left;
+      if (c < staged) { left.v = s_tv[c]; left.k = s_tk[c]; } else { left.v = d.tv[c]; left.k = d.tk[c]; }
+      if (tgreater(left, m)) pos = c; else { m = tsub(m, left); pos = c + 1; }
+    }
+    const int32_t idx = (int32_t)(pos - d.cap);
+    const int32_t e = d.slot_env[idx];
+    const int64_t base = d.slot_base[idx];
+    int64_t start = base - d.P;
+    if (e >= 0) start = refine_start(d, e, start);
+    slot_out[p] = idx; env_out[p] = e; start_out[p] = start; stratum_out[p] = i;
+    if (base_out) base_out[p] = base;
+    const double w = e >= 0 ? pow((d.tv[pos] / Pg) * Ng, -beta) : 0.0;
+    w_raw[p] = w;
+    local_max = w > local_max ? w : local_max;
+  }
+  const int kept = mine < Bpad ? mine : Bpad;
+  for (int p = kept + threadIdx.x; p < Bpad; p += 1024) {       // padding rows
+    slot_out[p] = -1; env_out[p] = -1; start_out[p] = 0; stratum_out[p] = -1; w_raw[p] = 0.0;
+    if (base_out) base_out[p] = 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { double x = __shfl_xor(local_max, o); local_max = x > local_max ? x : local_max; }
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = local_max;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double top = s_red[0];
+    for (int k = 1; k < 16; ++k) top = s_red[k] > top ? s_red[k] : top;
+    stats[0] = Pg; stats[1] = top; stats[2] = (double)kept; stats[3] = (double)(mine - kept);
+  }
+}
+
+__global__ void k_tree_root(Dev d, double active, double* __restrict__ out) { out[0] = d.tv[1]; out[1] = active; }
 
 // test hook: descent only
 __global__ void k_tree_find(Dev d, int B, const double* __restrict__ uniforms, int64_t* __restrict__ idx) {
@@ -1063,6 +1145,39 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
   }
   MIRL_LAUNCH_CHECK();
   return h->staging.mark(st);
+}
+
+extern "C" int mirl_replay_tree_root(mirl_replay* h, double* root_dev, void* stream) {
+  if (!h || !h->d.per || !root_dev) return fail(MIRL_ERR_ARG, "bad tree_root arguments");
+  hipLaunchKernelGGL(k_tree_root, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d, (double)h->book.active, root_dev);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_sample_global(mirl_replay* h, int32_t mbatch_local, int32_t mbatch_global, int32_t rows, int32_t rank,
+                                         int32_t world, const double* shard_totals, double train_progress, uint64_t seed,
+                                         int32_t* slot, int32_t* env, int64_t* start, int64_t* loss_start, double* weight_raw,
+                                         int32_t* stratum, double* stats, void* stream) {
+  if (!h || !h->d.per || mbatch_local <= 0 || mbatch_global <= 0 || rows <= 0 || rank < 0 || rank >= world || !shard_totals ||
+      !slot || !env || !start || !weight_raw || !stratum || !stats)
+    return fail(MIRL_ERR_ARG, "bad sample_global arguments");
+  if (train_progress < 0) return fail(MIRL_ERR_ARG, "train_progress must be >= 0 (general/utils.py:97)");
+  hipStream_t st = (hipStream_t)stream;
+  Book& bk = h->book;
+  if (h->bad_host && *h->bad_host) { *h->bad_host = 0; return fail(MIRL_ERR_STATE, "an earlier call flagged an invalid sample or frame (see mirl_replay_sample)"); }
+  int rc = bk.charge_quota(mbatch_local);
+  if (rc) { last_error_ref() = bk.err; return rc; }
+  ++h->sample_calls;
+  if (bk.active < mbatch_local) {
+    if (bk.total_items() >= bk.cfg.size) return fail(MIRL_ERR_STATE, "buffer full but fewer sequences than mbatch (prioritized_replay_history.py:298)");
+    return MIRL_NEED_MORE;
+  }
+  const double beta = anneal_beta(bk.cfg, train_progress);
+  ProfScope ps("k_per_sample_global", (double)mbatch_global * h->d.log2cap * 9.0 / world, st);
+  hipLaunchKernelGGL(k_per_sample_global, dim3(1), dim3(1024), 0, st, h->d, (int)mbatch_global, (int)rows, (int)rank, (int)world,
+                     shard_totals, seed, h->sample_calls, beta, slot, env, start, loss_start, weight_raw, stratum, stats);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
 }
 
 static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_t* env, const int64_t* start,

@@ -337,6 +337,8 @@ class ReplayHistoryBuffer(History):
         if self._h is None:
             return None
         B = mbatch_size
+        if getattr(self, "_global", None) is not None:
+            return self._get_train_data_global(B, train_progress)
         rng = None if self._device_rng else self._draw_host_rng(B)
         dev = self.device
         slot = torch.empty(B, dtype=torch.int32, device=dev)
@@ -501,6 +503,49 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
         self._global_importance_scaling = global_importance_scaling
         if overlap is not None and overlap >= 0:
             assert overlap < self.nstep_train, "Overlap must be < nstep_train"
+
+    # -- exact global sampling over env-sharded replays ------------------
+    def enable_global_sampling(self, data_parallel, slack=0.25, min_slack=4):
+        """Sample like ONE tree over the concatenation of all ranks' shards instead of
+        per-shard proportionally: every rank draws the same Philox uniforms for the
+        B_global = mbatch * world strata of the global priority mass and takes the
+        strata that fall into its own cumulative range (include/mirl.h,
+        mirl_replay_sample_global).  The per-rank count is data-dependent, so batches
+        are padded to mbatch * (1 + slack) rows; padding rows carry weight 0 and no loss
+        index, and the real rows' importance weights are scaled so that the all-reduced
+        mean over the padded batches equals the mean over the B_global global rows."""
+        if not self._device_rng:
+            raise ValueError("global sampling draws its uniforms on the device: construct the buffer with device_rng=True")
+        self._global = (data_parallel, float(slack), int(min_slack))
+
+    def _get_train_data_global(self, B, train_progress):
+        dp, slack, min_slack = self._global
+        R, rank = dp.world, dp.rank
+        rows = B + max(min_slack, int(np.ceil(B * slack)))
+        dev = self.device
+        root = torch.empty(2, dtype=torch.float64, device=dev)
+        check(lib.mirl_replay_tree_root(self._h, _ptr(root), _stream()), "mirl_replay_tree_root")
+        shard = dp.exchange_rows(root).contiguous()                 # (R, 2): sum of priorities, active sequences
+        slot = torch.empty(rows, dtype=torch.int32, device=dev)
+        env = torch.empty(rows, dtype=torch.int32, device=dev)
+        start = torch.empty(rows, dtype=torch.int64, device=dev)
+        loss_start = torch.empty(rows, dtype=torch.int64, device=dev)
+        raw = torch.empty(rows, dtype=torch.float64, device=dev)
+        stratum = torch.empty(rows, dtype=torch.int32, device=dev)
+        stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._seed += 1
+        rc = check(lib.mirl_replay_sample_global(
+            self._h, B, B * R, rows, rank, R, _ptr(shard), float(train_progress or 0.0), self._seed,
+            _ptr(slot), _ptr(env), _ptr(start), _ptr(loss_start), _ptr(raw), _ptr(stratum), _ptr(stats), _stream()),
+            "mirl_replay_sample_global")
+        if rc == _lib.MIRL_NEED_MORE:
+            return None
+        self.last_beta = self._current_beta(train_progress)
+        top = dp.exchange_rows(stats[1:2]).max()                    # batch max over ALL ranks (prioritized_replay_history.py:353-354)
+        weight = (raw / top * (float(R * rows) / float(B * R))).to(torch.float32)
+        self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight, "stats": stats,
+                            "loss_start": loss_start, "stratum": stratum, "raw": raw, "shard": shard, "global": True}
+        return self._gather(rows, env, start, weight, loss_start)
 
     def _per_config(self, cfg):
         cfg.alpha, cfg.beta, cfg.eps = self._alpha, self._beta, self._eps

@@ -60,7 +60,7 @@ class DQN(TorchTrainer):
         w = self.policy.make_tensor(extra_data["importance_weights"])
         dp = getattr(self, "data_parallel", None)
         last = getattr(self.history_buffer, "last_sample", None)
-        if dp is not None and last is not None and "stats" in last:
+        if dp is not None and last is not None and "stats" in last and not last.get("global"):
             # shard-local -> global importance weights (rltime_amd/parallel.py)
             w = dp.globalize_weights(w, last["stats"][0], self.history_buffer.stats()["active_sequences"],
                                      last["stats"][1], self.history_buffer.last_beta)

@@ -100,15 +100,22 @@ class MultiStepTrainer(PolicyTrainer):
             **mode.get("args", {}), nstep_target=nstep_target, nstep_train=nstep_train,
             prefix_steps=prefix_steps, discount_function=self._get_discount_function(self.gamma),
             state_store=self.policy.get_state_store(async_history))
+        dp = self.data_parallel
+        if getattr(self, "global_sampling", False) and dp is not None and dp.active \
+                and hasattr(self.history_buffer, "enable_global_sampling"):
+            self.history_buffer.enable_global_sampling(dp)
 
     def _train(self, gamma, nstep_train, lr, history_mode, mbatch_size=None, nstep_target=None,
                lr_anneal=False, epochs=1, minibatches=1, warmup_steps=0,
                actor_update_frequency_steps=1000, burn_in_timesteps=0, rnn_steps_train=None,
-               rnn_bootstrap=False, async_history=False, overlap_acting=False):
+               rnn_bootstrap=False, async_history=False, overlap_acting=False, global_sampling=False):
         """multi_step_trainer.py:152-379.  overlap_acting (not in the reference): run the
         acting + ingest of iteration k+1 on a second HIP stream while iteration k trains
         (see _loop_iteration_overlapped)."""
         self.overlap_acting = overlap_acting     # True | "serial" (same schedule on ONE stream: race check)
+        # multi-GPU + prioritized replay: sample exactly like one tree over all shards
+        # (history needs device_rng=True); default: per-shard proportional + global IS weights
+        self.global_sampling = bool(global_sampling)
         self._ov = None
         self.train_init(lr)
         self.gamma = gamma

@@ -198,3 +198,135 @@ def test_train_entry_under_torchrun_world1_forced_collectives(tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     rows = [json.loads(line) for line in open(tmp_path / "run" / "train.json")]
     assert rows and rows[-1]["this_interval"]["steps_trained"] > 0
+
+
+# --------------------------------------------------------------------------
+# exact global sampling over two shards == ONE tree over their union
+# --------------------------------------------------------------------------
+GS = dict(size=600, train_frequency=0, nstep_target=2, nstep_train=8, prefix_steps=4,
+          alpha=0.9, beta=0.6, beta_anneal=True, max_weight_factor=0.9)
+GS_B, GS_DRAWS = 8, 6
+
+
+def _global_rank(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    from rltime_amd.parallel import DataParallel
+    from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
+    dp = DataParallel()
+    E = 5
+    spec = StreamSpec(seed=80 + rank, num_envs=E, frame_shape=(1, 8, 8), lstm_units=4, n_actions=4,
+                      done_prob=0.05, env_base=rank * E)
+    buf = PrioritizedReplayHistoryBuffer(**GS, gamma=0.99, device_rng=True, num_envs=E, env_base=rank * E)
+    buf.enable_global_sampling(dp)
+    rec = {k: [] for k in ("stratum", "slot", "weight", "leaf", "seed", "call", "beta", "active", "kept", "dropped")}
+    step_no, calls = 0, 0
+    feeds = [70, 12, 0, 25, 9, 40]
+    for draw in range(GS_DRAWS):
+        for st in vector_steps(spec, feeds[draw], start_step=step_no):
+            buf.update(as_reference_samples(spec, st))
+        step_no += feeds[draw]
+        progress = draw / float(GS_DRAWS)
+        v, k, _ = buf.tree_nodes()                        # the tree the draw will see
+        batch = buf.get_train_data(GS_B, train_progress=progress)
+        calls += 1
+        assert batch is not None
+        last = buf.last_sample
+        rows = last["slot"].shape[0]
+        assert batch["states"]["x"].shape[1] == rows and rows >= GS_B + 4
+        cap = len(v) // 2
+        rec["stratum"].append(last["stratum"].cpu().numpy())
+        rec["slot"].append(last["slot"].cpu().numpy())
+        rec["weight"].append(last["weight"].double().cpu().numpy())
+        rec["leaf"].append(v[cap:].copy())
+        rec["seed"].append(buf._seed)
+        rec["call"].append(calls)
+        rec["beta"].append(buf.last_beta)
+        rec["active"].append(buf.stats()["active_sequences"])
+        rec["kept"].append(float(last["stats"][2].item()))
+        rec["dropped"].append(float(last["stats"][3].item()))
+        # padding rows: weight 0, no loss index
+        pad = last["slot"].cpu().numpy() < 0
+        w = batch["extra_data"]["importance_weights"][0].cpu().numpy()
+        li = batch["extra_data"]["loss_indices"][GS["prefix_steps"]:].cpu().numpy()
+        assert np.all(w[pad] == 0) and np.all(li[:, pad] == -1) and np.all(li[:, ~pad, 0] >= rank * E)
+        P = GS["prefix_steps"]
+        idx = batch["extra_data"]["loss_indices"][P:].reshape(-1, 2)
+        g = torch.Generator(device="cuda").manual_seed(draw * 10 + rank)
+        buf.update_losses(idx, torch.randn(idx.shape[0], device="cuda", generator=g) * 0.7)
+    np.savez(os.path.join(out_dir, "gs_rank%d.npz" % rank), **{k: np.array(v) for k, v in rec.items()}, rows=rows)
+    buf.close()
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+def test_global_sampling_is_one_tree_over_the_union_of_shards(tmp_path):
+    """`enable_global_sampling` (mirl_replay_sample_global): with the same Philox
+    stream on both ranks, the strata of the GLOBAL priority mass go to the shard whose
+    cumulative range contains them.  Checked against ONE reference tree
+    (oracle.sumtree.SumTree, float64 leaves) over the concatenation of both shards'
+    leaves with host-recomputed Philox uniforms: every stratum is drawn exactly once,
+    by the right rank, at the leaf the union tree's descent reaches (a stratum whose
+    mass sits within 1e-6 relative of a leaf boundary may land on the neighbour: the
+    shards sum their float32 leaves in float32 like the reference does, the union tree
+    in float64), and the importance weights are the union tree's."""
+    import torch.multiprocessing as mp
+    from oracle.sumtree import SumTree
+    from tests.test_replay_gpu import _philox_u53
+    world = 2
+    mp.spawn(_global_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("gs_rank%d.npz" % i)) for i in range(world)]
+    Bg = GS_B * world
+    rows = int(r[0]["rows"])
+    exact = near = 0
+    for s in range(GS_DRAWS):
+        assert r[0]["seed"][s] == r[1]["seed"][s] and r[0]["call"][s] == r[1]["call"][s]
+        n0 = r[0]["leaf"][s].shape[0]
+        leaves = np.concatenate([r[0]["leaf"][s], r[1]["leaf"][s]]).astype(np.float64)
+        tree = SumTree(2 * n0)
+        for j, x in enumerate(leaves):
+            if x != 0:
+                tree.set_leaf(j, np.float64(x))
+        Pg = float(tree.total())
+        Ng = int(r[0]["active"][s] + r[1]["active"][s])
+        beta = float(r[0]["beta"][s])
+        seg = Pg / Bg
+        got = {}
+        for i in range(world):
+            assert r[i]["dropped"][s] == 0
+            for st, sl, w in zip(r[i]["stratum"][s], r[i]["slot"][s], r[i]["weight"][s]):
+                if st >= 0:
+                    assert st not in got
+                    got[int(st)] = (i, int(sl), float(w))
+            assert int(r[i]["kept"][s]) == int((r[i]["stratum"][s] >= 0).sum())
+        assert sorted(got) == list(range(Bg))                       # every stratum exactly once
+        raws = {}
+        for st in range(Bg):
+            mass = (_philox_u53(int(r[0]["seed"][s]), int(r[0]["call"][s]), st) + st) * seg
+            want = tree.descend(mass)
+            rank_got, slot_got, _ = got[st]
+            leaf_got = rank_got * n0 + slot_got
+            if leaf_got == want:
+                exact += 1
+            else:
+                # a boundary case: the mass must sit within 1e-6 (relative) of the edge between the two leaves
+                prefix = float(np.sum(leaves[:max(leaf_got, want)]))
+                assert abs(leaf_got - want) == 1 or leaves[min(leaf_got, want) + 1:max(leaf_got, want)].sum() == 0
+                assert abs(mass - prefix) <= 1e-6 * Pg, (s, st, mass, prefix)
+                near += 1
+            raws[st] = ((leaves[leaf_got] / Pg) * Ng) ** (-beta)
+        top = max(raws.values())
+        for st in range(Bg):
+            want_w = raws[st] / top * (float(world * rows) / float(Bg))
+            assert abs(got[st][2] - want_w) <= 5e-6 * want_w, (s, st)
+    assert exact >= GS_DRAWS * Bg - 2
+    print("global sampling: %d strata identical to the union tree, %d at a leaf boundary" % (exact, near))

@@ -242,6 +242,16 @@ def test_frame_dedup_uniform_atari_frames_vs_oracle():
               dev_kw=dict(frame_stack_dedup=True))
 
 
+def test_frame_dedup_resets_within_an_envs_first_steps():
+    """Episode ends inside an env's first three transitions: their stacks reach back
+    to planes no transition stored (virtual predecessors in ring slots -1, -2, -3);
+    a reset's zero fill must not overwrite them."""
+    _run_pair(53, 12, [("feed", 6), ("draw", 1, None), ("feed", 9), ("draw", 2, None), ("feed", 40), ("draw", 3, None)],
+              dict(size=600, train_frequency=0, nstep_target=2, nstep_train=2, prefix_steps=0),
+              0.99, False, dict(frame_shape=(4, 8, 8), n_actions=4, done_prob=0.35, stacked=True), 24,
+              dev_kw=dict(frame_stack_dedup=True))
+
+
 @pytest.mark.parametrize("noxing", [False, True])
 def test_frame_dedup_per_sequences_vs_oracle(noxing):
     """De-duplicated storage under prioritized sequence replay: overlapped
