@@ -59,7 +59,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, global_sampling=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -78,6 +78,10 @@ def _rank_main(rank, world, port, out_dir):
     dp = DataParallel()
     cfg = shard_config(copy.deepcopy(CONFIG), rank, world, "strong")
     assert cfg["acting"]["actor_envs"] == 4 and cfg["training"]["args"]["mbatch_size"] == 4
+    if global_sampling:
+        # one tree over the union of the shards (mirl_replay_sample_global): padded batches
+        cfg["training"]["args"]["global_sampling"] = True
+        cfg["training"]["args"]["history_mode"]["args"]["device_rng"] = True
     random.seed(10 + rank); np.random.seed(20 + rank); torch.manual_seed(30 + rank)   # noqa: E702
     actors = create_actors(cfg, "cuda", device_acting=True)
     trainer = get_registered_type("trainers", "iqn")(
@@ -91,6 +95,12 @@ def _rank_main(rank, world, port, out_dir):
 
     def tap(extra):
         w = inner(extra)
+        if global_sampling:
+            assert hist.last_sample.get("global") and w.reshape(T, -1).shape[1] > 4      # padded rows
+            rec["w"].append(np.zeros(1)); rec["slots"].append(np.zeros(1, np.int64))     # noqa: E702
+            rec["leaf_v"].append(np.zeros(1)); rec["leaf_k"].append(np.zeros(1, np.uint8))   # noqa: E702
+            rec["active"].append(0); rec["beta"].append(hist.last_beta)                  # noqa: E702
+            return w
         v, k, _ = hist.tree_nodes()
         cap = len(v) // 2
         rec["w"].append(w.reshape(T, -1)[0].double().cpu().numpy())
@@ -137,11 +147,12 @@ def _kinded(v, k):
     return float(v)
 
 
-def test_two_ranks_full_loop_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("sampling", ["per_shard", "global"])
+def test_two_ranks_full_loop_on_one_gpu(tmp_path, sampling):
     import torch.multiprocessing as mp
     from oracle.sumtree import SumTree
     world = 2
-    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, _free_port(), str(tmp_path), sampling == "global"), nprocs=world, join=True)
     r = [np.load(tmp_path / ("rank%d.npz" % i)) for i in range(world)]
     # (i) replicas stay bit-identical (initial broadcast included), and they moved
     assert list(r[0]["hash"]) == list(r[1]["hash"])
@@ -149,6 +160,8 @@ def test_two_ranks_full_loop_on_one_gpu(tmp_path):
     assert len(set(r[0]["hash"])) == STEPS + 1
     assert len(set(r[0]["target_hash"])) > 1                      # the target sync fired on both
     assert int(r[0]["steps"]) == int(r[1]["steps"])
+    if sampling == "global":
+        return          # the sampler itself is checked in test_global_sampling_is_one_tree_over_the_union_of_shards
     # (ii) importance weights == one reference tree over the union of the shards
     assert r[0]["w"].shape[0] == STEPS
     worst = 0.0
