@@ -556,6 +556,54 @@ k_gather_rows_dedup(Dev d, uint8_t* __restrict__ out, const int32_t* __restrict_
   }
 }
 
+// The same rebuild with the planes of a run of consecutive rows staged ONCE in LDS:
+// rows r .. r+RC-1 of one sequence come from consecutive transitions, whose stacks
+// share all but one plane, so a workgroup loads RC + P - 1 planes (instead of RC * P)
+// and writes RC stacks: (RC + P - 1) / RC read amplification instead of P.  Chunks
+// whose source transitions are not one short run (layout seams, truncated n-step
+// targets at the ring end) take the direct path of k_gather_rows_dedup.
+#define MIRL_DD_MAX_PLANES 16
+__global__ void __launch_bounds__(512)
+k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restrict__ env,
+                        const int64_t* __restrict__ start, int B, int R, int overlapped, int RC, int lds_planes) {
+  extern __shared__ u32x4 s_planes[];
+  const int chunks = (R + RC - 1) / RC;
+  const int ch = blockIdx.x / B, b = blockIdx.x - ch * B;
+  (void)chunks;
+  const int r0 = ch * RC, r1 = r0 + RC < R ? r0 + RC : R;
+  int32_t e = env[b];
+  if (e < 0 || e >= d.E) e = 0;
+  const int64_t st = start[b];
+  int64_t lo = INT64_MAX, hi = INT64_MIN;
+  for (int r = r0; r < r1; ++r) { int64_t o = row_src_off(d, overlapped, r, e, st); lo = o < lo ? o : lo; hi = o > hi ? o : hi; }
+  const int nq = d.plane_bytes >> 4, n = nq * d.planes;
+  const uint8_t* ring0 = d.frames + (int64_t)e * d.C * d.plane_bytes;
+  const int64_t first = lo - (d.planes - 1);
+  const int span = (int)(hi - first + 1);
+  const bool staged = span <= lds_planes;
+  if (staged) {
+    for (int c = threadIdx.x; c < span * nq; c += 512) {
+      const int p = c / nq, q = c - p * nq;
+      s_planes[c] = __builtin_nontemporal_load((const u32x4*)(ring0 + (((first + p) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+    }
+    __syncthreads();
+  }
+  for (int r = r0; r < r1; ++r) {
+    const int64_t o = row_src_off(d, overlapped, r, e, st);
+    const int dep = d.depth[slot_of(d, e, o)];
+    u32x4* t4 = (u32x4*)(out + ((int64_t)r * B + b) * (int64_t)d.F);
+    for (int c = threadIdx.x; c < n; c += 512) {
+      const int p = c / nq, q = c - p * nq, back = d.planes - 1 - p;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (back < dep) {
+        if (staged) v = s_planes[(int)(o - back - first) * nq + q];
+        else v = __builtin_nontemporal_load((const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+      }
+      __builtin_nontemporal_store(v, t4 + c);
+    }
+  }
+}
+
 // Per-step scalars of the batch.  One lane per (t, b):
 //   _update_nstep (history.py:71-108): forward scan over <= n rewards / dones,
 //   return accumulated in float64 with gamma**k from the host libm (the Python
@@ -817,6 +865,7 @@ struct mirl_replay {
   int gather_nt = 0;
   int gather_variant = 1, gather_order = 0;
   int recalc_wave = 1;
+  int dedup_lds = 1;
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
 };
@@ -933,6 +982,7 @@ extern "C" int mirl_replay_create(const mirl_replay_config* cfg, mirl_replay** o
   if (const char* v = getenv("MIRL_GATHER_VARIANT")) h->gather_variant = atoi(v);
   if (const char* v = getenv("MIRL_GATHER_ORDER")) h->gather_order = atoi(v);
   if (const char* v = getenv("MIRL_RECALC_WAVE")) h->recalc_wave = atoi(v);
+  if (const char* v = getenv("MIRL_DEDUP_LDS")) h->dedup_lds = atoi(v);
   MIRL_HIP(hipDeviceSynchronize());
   *out = h;
   return MIRL_OK;
@@ -1373,6 +1423,14 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
       // algorithmic bytes: every output stack written once + every distinct plane of a
       // window read once (rows + P - 1 planes per sequence and state block)
       ProfScope ps("k_gather_rows_dedup(frames)", (double)blocks * d.F + (double)B * (h->rows + d.planes - 1) * d.plane_bytes, st);
+      // LDS-staged variant: as many planes as fit in 64 KB; RC rows per workgroup
+      int lds_planes = (int)(65536 / d.plane_bytes); if (lds_planes > MIRL_DD_MAX_PLANES) lds_planes = MIRL_DD_MAX_PLANES;
+      const int RC = lds_planes - (d.planes - 1);
+      if (h->dedup_lds && RC >= 2) {
+        const int chunks = (h->rows + RC - 1) / RC;
+        hipLaunchKernelGGL(k_gather_rows_dedup_lds, dim3((unsigned)(chunks * B)), dim3(512), (size_t)lds_planes * d.plane_bytes, st, d,
+                           out->frames, env, start, B, h->rows, h->overlapped, RC, lds_planes);
+      } else
       hipLaunchKernelGGL(k_gather_rows_dedup, dim3((unsigned)blocks), dim3(512), 0, st, d, out->frames, env, start, B, h->overlapped);
     }
     MIRL_LAUNCH_CHECK();
