@@ -25,10 +25,12 @@ from rltime_amd._lib import lib, check
 import os
 
 # The one-launch step kernel (recurrent GEMM on f32 MFMA + cell epilogue) is correct
-# (tests/test_lstm_gpu.py) but measured 21.3 us per step against 12.6 us (rocBLAS GEMM)
-# + 5.7 us (cell kernel) + ~1.5 us launch gap for the two-launch path at B = H = 512
-# (profiles/README.md round 2) — one wave per SIMD cannot hide its prologue / epilogue /
-# barrier latencies.  Off by default; MIRL_LSTM_FUSED_STEP=1 selects it.
+# (tests/test_lstm_gpu.py) but no faster than the two launches at B = H = 512: 18.8 us
+# per step (16x16x4 tiles, 4 waves per SIMD; a 32x32x2 / one-wave-per-SIMD version:
+# 21.3 us) against 12.6 us (rocBLAS GEMM) + 5.7 us (cell kernel) + ~1.5 us launch gap.
+# Like the library GEMM it is bound by moving W_hh (re-read by every batch tile, every
+# step: ~100 MB L2->LDS per step) — the gain is in keeping W_hh resident across steps
+# (persistent kernel), not in fusing one step.  Off by default; MIRL_LSTM_FUSED_STEP=1.
 _FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "0") == "1"
 
 
