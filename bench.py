@@ -322,7 +322,7 @@ def cpu_baseline(args, seconds):
         return per_b[Bmax][0] * (B_full / Bmax), per_b, spent
 
     learner_step(2)                                           # untimed warm-up (allocator, MKL)
-    one_s, one_b, one_spent = leg(1, [(4, 1), (16, 1)], seconds * 0.6)
+    one_s, one_b, one_spent = leg(1, [(4, 1), (16, 1)], seconds * 0.5)
     # "all cores": torch intra-op threads capped at 32 — the LSTMCell time loop is a chain of
     # small GEMMs; with one thread per logical core of a 256-core host the same step measured
     # 33x SLOWER than 1 thread (profiles/README.md, round 2).  B=4 first; B=16 only if the
@@ -334,7 +334,7 @@ def cpu_baseline(args, seconds):
     many = max(2, min(usable, 32))
     all_s, all_b, all_spent = leg(many, [(4, 1)], seconds * 0.2)
     if all_b[4][0] < one_b[4][0]:
-        s2, b2, sp2 = leg(many, [(16, 1)], seconds * 0.2)
+        s2, b2, sp2 = leg(many, [(32, 1)], seconds * 0.3)
         all_s, all_spent = s2, all_spent + sp2
         all_b.update(b2)
     torch.set_num_threads(1)

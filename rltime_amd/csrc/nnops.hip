@@ -68,7 +68,8 @@ k_relu_bwd_bias_rows(const nn_f4* __restrict__ dy, const nn_f4* __restrict__ y, 
     nn_f4 b0 = y[i], b1 = y[i + 256], b2 = y[i + 512], b3 = y[i + 768];
 #define MIRL_MASK(a, b) a.x = b.x > 0.f ? a.x : 0.f; a.y = b.y > 0.f ? a.y : 0.f; a.z = b.z > 0.f ? a.z : 0.f; a.w = b.w > 0.f ? a.w : 0.f;
     MIRL_MASK(a0, b0) MIRL_MASK(a1, b1) MIRL_MASK(a2, b2) MIRL_MASK(a3, b3)
-    g[i] = a0; g[i + 256] = a1; g[i + 512] = a2; g[i + 768] = a3;
+    __builtin_nontemporal_store(a0, g + i); __builtin_nontemporal_store(a1, g + i + 256);
+    __builtin_nontemporal_store(a2, g + i + 512); __builtin_nontemporal_store(a3, g + i + 768);
     acc = acc + a0; acc = acc + a1; acc = acc + a2; acc = acc + a3;
   }
   for (; i < hi; i += 256) {
@@ -140,7 +141,8 @@ k_iqn_mul_fwd(const nn_f4* __restrict__ x, const nn_f4* __restrict__ emb, nn_f4*
     for (; n + 3 * RL < N; n += 4 * RL) {
       const int64_t i0 = base + (int64_t)n * CQ;
       nn_f4 e0 = emb[i0], e1 = emb[i0 + st], e2 = emb[i0 + 2 * st], e3 = emb[i0 + 3 * st];
-      out[i0] = e0 * xv; out[i0 + st] = e1 * xv; out[i0 + 2 * st] = e2 * xv; out[i0 + 3 * st] = e3 * xv;
+      __builtin_nontemporal_store(e0 * xv, out + i0); __builtin_nontemporal_store(e1 * xv, out + i0 + st);
+      __builtin_nontemporal_store(e2 * xv, out + i0 + 2 * st); __builtin_nontemporal_store(e3 * xv, out + i0 + 3 * st);
     }
     for (; n < N; n += RL) { const int64_t i0 = base + (int64_t)n * CQ; out[i0] = emb[i0] * xv; }
   }
@@ -175,7 +177,8 @@ k_iqn_mul_bwd(const nn_f4* __restrict__ g, const nn_f4* __restrict__ emb, const 
       acc = acc + g0 * e0; acc = acc + g1 * e1; acc = acc + g2 * e2; acc = acc + g3 * e3;
       nn_f4 p0 = g0 * xv, p1 = g1 * xv, p2 = g2 * xv, p3 = g3 * xv;
       MIRL_MASK(p0, e0) MIRL_MASK(p1, e1) MIRL_MASK(p2, e2) MIRL_MASK(p3, e3)
-      d_pre[i0] = p0; d_pre[i0 + st] = p1; d_pre[i0 + 2 * st] = p2; d_pre[i0 + 3 * st] = p3;
+      __builtin_nontemporal_store(p0, d_pre + i0); __builtin_nontemporal_store(p1, d_pre + i0 + st);
+      __builtin_nontemporal_store(p2, d_pre + i0 + 2 * st); __builtin_nontemporal_store(p3, d_pre + i0 + 3 * st);
       db = db + p0; db = db + p1; db = db + p2; db = db + p3;
     }
     for (; n < N; n += RL) {
@@ -263,7 +266,7 @@ k_tail_bwd(const float* __restrict__ ga, const float* __restrict__ gv, const flo
 #pragma unroll
         for (int k = 0; k < MIRL_TAIL_MAXK; ++k) if (k < K) d = d + wk[k] * gr[k];
         MIRL_MASK(d, b[v])
-        g[(base + u + v * RL) * CQ + cq] = d;
+        __builtin_nontemporal_store(d, g + (base + u + v * RL) * CQ + cq);
         acc = acc + d;
       }
     }
