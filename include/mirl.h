@@ -333,6 +333,34 @@ int mirl_frames_to_f32_nhwc(int64_t N, int32_t C, int32_t HW, const uint8_t* src
 int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* src, float scale,
                                float* dst, int32_t per_wg, int32_t flags, void* stream);
 
+/* ---- the network's input layer straight from uint8 frames (csrc/conv_in.hip).
+ * Replaces, for the first conv layer of the reference's Atari models
+ * (rltime/models/torch/modules/cnn.py:44-49 with configs/models/cnn_*.json:
+ * Conv2d(4 -> 32, kernel 8, stride 4)), the chain `x.float() * scale` ->
+ * conv -> + bias -> ReLU by ONE kernel on the f32 MFMA pipe:
+ *   x       uint8 [N][4][H][W] (the replay's gathered rows, as stored)
+ *   weight  float, logical [32][4][8][8] with element strides ws_o, ws_c, ws_h, ws_w
+ *   y       float [N][OH][OW][32] = relu(conv(x * scale, weight) + bias), the NHWC
+ *           memory of the logical (N, 32, OH, OW) tensor; OH = (H-8)/4+1, OW likewise
+ *   wpk     scratch, 8192 floats (the weights re-ordered into MFMA operand order,
+ *           rewritten by every call)
+ * Products are float(x)*scale times weight as in the reference; only the order of
+ * the 256-term sum differs (fp32 tolerance 1e-4, tests/test_conv_in_gpu.py).
+ * mirl_conv1_u8_supported() says whether a layer shape is covered (C = 4, F = 32,
+ * K = 8, S = 4, W % 4 == 0, H*W % 16 == 0, 4 padded planes <= 64 KiB of LDS);
+ * anything else returns MIRL_ERR_ARG and the caller keeps the generic path
+ * (mirl_frames_to_f32_nhwc + library convolution).                              */
+int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t F, int32_t K, int32_t S);
+int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
+                      int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
+                      float scale, float* wpk, float* y, void* stream);
+/* the same with explicit launch shape (tuning probe): flags bit 0 = cached output
+ * stores (default non-temporal), bits 8-15 = frames per LDS fill (1 | 2, 0 = heuristic),
+ * bits 16-23 = workgroups sharing one frame's tiles (0 = heuristic).               */
+int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
+                         int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
+                         float scale, float* wpk, float* y, int32_t flags, void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

@@ -1,0 +1,199 @@
+// conv_in.hip — the network's input layer straight from the replay's uint8 frames.
+//
+// Reference: rltime/models/torch/modules/cnn.py:44-49 — `x.float() * scale`, then
+// `F.relu(conv(x))` for every conv layer; the first layer of every Atari config
+// is Conv2d(4 stacked frames -> 32 filters, kernel 8, stride 4) on 84x84 frames
+// (rltime/configs/models/cnn_*.json).  Round 1/2 ran it as three passes: u8 NCHW
+// -> f32 NHWC conversion (csrc/convert.hip, 5 B per pixel of HBM traffic), a
+// MIOpen implicit-GEMM convolution that re-reads those 4 B pixels (measured
+// 3.2 ms per 20 480-frame call, ~25 % of the f32 MFMA rate — the K = 256, N = 32
+// shape is far from what its tiles are tuned for) and an in-place bias + ReLU
+// pass.  This kernel does the layer in ONE pass from the uint8 planes:
+//
+//   HBM traffic   1 B per input pixel + 4 B per output element (28 KB in, 51 KB
+//                 out per frame) — 3.3 GB for a 41 472-frame block, 0.6 ms at the
+//                 achievable HBM rate, so the kernel is bound by the f32 MFMA pipe:
+//                 2 * 256 * 32 flop per output position = 6.55 MFLOP per frame,
+//                 1.7 ms per 41 472 frames at the 157 TFLOP/s f32 MFMA peak.
+//   work split    persistent workgroups (4 waves, 2 per CU), each staging FPI whole
+//                 frames (4 planes, raw uint8) in LDS with 16 B per lane and then
+//                 walking their 16-position output tiles, one tile per wave at a time.
+//   contraction   v_mfma_f32_16x16x4_f32 with the FILTERS as rows and the output
+//                 POSITIONS as columns: one instruction sums the 4 input planes
+//                 (k = plane) for one (kh, kw) tap; 64 taps x 2 filter halves = 128
+//                 MFMAs per tile on two independent accumulator chains (dependent
+//                 issue distance 64 cycles > the 40-cycle MFMA latency).
+//   operands      the 2 x 64 weight operands of a lane are loop-invariant and live
+//                 in registers for the whole kernel (packed once per launch by
+//                 k_conv1_pack_w into the lane order); the position operand is
+//                 float(u8) * scale — the very products the reference forms — read
+//                 as 8 consecutive bytes per (plane, kh) row from LDS.
+//   LDS layout    plane pitch padded to 16 (mod 64) dwords, so the four planes a
+//                 ds_read touches land on disjoint bank groups.
+//   epilogue      accumulator rows are 4 consecutive filters: + bias, ReLU, two
+//                 16 B stores per lane; a wave writes 2 KiB of contiguous NHWC rows.
+//
+// Only the forward needs this shape; the weight gradient keeps MIOpen (the input
+// needs no gradient), see rltime_amd/models/torch/fused.py:_ConvU8BiasReLU.
+#include "common.hpp"
+
+namespace mirl {
+
+typedef float cv_f4 __attribute__((ext_vector_type(4)));
+
+constexpr int C1_PLANES = 4, C1_K = 8, C1_S = 4, C1_F = 32, C1_TAPS = C1_K * C1_K;
+constexpr int C1_WPK = 2 * C1_TAPS * 64;      // packed weight image: [half][tap][lane]
+constexpr int C1_LD = 7;                      // staging loads in flight per lane (one 84x84 frame = 6.9 x 256 vectors)
+
+// wpk[(m*64 + tap)*64 + lane] = w[f][c][kh][kw] with the MFMA A-operand lane map
+// (row i = lane & 15, k = lane >> 4 = input plane) and the row -> filter
+// permutation f = (i>>2)*8 + m*4 + (i&3), which makes the 4 accumulator rows a
+// lane owns 4 CONSECUTIVE filters (and the two halves 8 consecutive ones).
+__global__ void __launch_bounds__(256)
+k_conv1_pack_w(const float* __restrict__ w, int64_t so, int64_t sc, int64_t sh, int64_t sw, float* __restrict__ wpk) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C1_WPK) return;
+  const int lane = t & 63, tap = (t >> 6) & 63, m = t >> 12;
+  const int i = lane & 15, c = lane >> 4, kh = tap >> 3, kw = tap & 7;
+  const int f = (i >> 2) * 8 + m * 4 + (i & 3);
+  wpk[t] = w[f * so + c * sc + kh * sh + kw * sw];
+}
+
+__device__ __forceinline__ float c1_byte(uint32_t v, int b) { return (float)((v >> (8 * b)) & 0xffu); }
+
+// x: uint8 [N][4][H][W]; y: float [N][OH][OW][32] (NHWC memory of the logical
+// (N, 32, OH, OW) tensor).  Work unit u = (frame group, part): a group is FPI
+// consecutive frames, `split` parts share a group's tiles (split > 1 only for
+// small N, to spread few frames over the chip).  NTS: non-temporal output stores.
+template <int FPI, int NTS>
+__global__ void __launch_bounds__(256, 2)
+k_conv1_u8_fwd(int64_t N, int H, int W, int OH, int OW, int pitch, int split, const uint8_t* __restrict__ x,
+               const float* __restrict__ wpk, const float* __restrict__ bias, float scale, float* __restrict__ y) {
+  extern __shared__ __align__(16) uint8_t c1_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  float wr0[C1_TAPS], wr1[C1_TAPS];
+#pragma unroll
+  for (int s = 0; s < C1_TAPS; ++s) { wr0[s] = wpk[s * 64 + lane]; wr1[s] = wpk[(C1_TAPS + s) * 64 + lane]; }
+  const cv_f4 b0 = *reinterpret_cast<const cv_f4*>(bias + kq * 8), b1 = *reinterpret_cast<const cv_f4*>(bias + kq * 8 + 4);
+  const int HW = H * W, OHW = OH * OW, tiles = (OHW + 15) >> 4, hw16 = HW >> 4;
+  const int64_t groups = (N + FPI - 1) / FPI, units = groups * split;
+  bool first = true;
+  for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
+    const int64_t group = u / split, n0 = group * FPI;
+    const int part = (int)(u - group * split);
+    if (!first) __syncthreads();                    // every wave is done reading the previous frames
+    first = false;
+    {
+      // FPI frames x 4 planes are one contiguous run of 16 B vectors in HBM; only the LDS
+      // side has the padded plane pitch.  C1_LD loads in flight per lane before the writes.
+      const int64_t left = N - n0;
+      const int vecs = (int)(left < FPI ? left : FPI) * C1_PLANES * hw16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(x + n0 * (int64_t)(C1_PLANES * HW));
+      for (int o0 = tid; o0 < vecs; o0 += 256 * C1_LD) {
+        uint4 v[C1_LD];
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; if (o < vecs) v[k] = s4[o]; }
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) {
+          const int o = o0 + k * 256;
+          if (o < vecs) { const int pl = o / hw16; *reinterpret_cast<uint4*>(c1_lds + pl * pitch + (o - pl * hw16) * 16) = v[k]; }
+        }
+      }
+    }
+    __syncthreads();
+    for (int tt = part * 4 + wave; tt < FPI * tiles; tt += 4 * split) {
+      const int f = tt / tiles, tile = tt - f * tiles;
+      if (n0 + f >= N) break;                       // wave-uniform
+      const int p = tile * 16 + j, pc = p < OHW ? p : OHW - 1;
+      const int oh = pc / OW, ow = pc - oh * OW;
+      const uint8_t* base = c1_lds + (f * C1_PLANES + kq) * pitch + (oh * C1_S) * W + ow * C1_S;
+      uint32_t px[2 * C1_K];
+#pragma unroll
+      for (int kh = 0; kh < C1_K; ++kh) {
+        px[2 * kh] = *reinterpret_cast<const uint32_t*>(base + kh * W);
+        px[2 * kh + 1] = *reinterpret_cast<const uint32_t*>(base + kh * W + 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);            // all 16 LDS words in flight before the MFMA chain starts
+      cv_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < C1_TAPS; ++s) {
+        const float v = c1_byte(px[s >> 2], s & 3) * scale;     // tap s = kh*8 + kw: word kh*2 + (kw>>2), byte kw&3
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr0[s], v, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[s], v, a1, 0, 0, 0);
+      }
+      if (p < OHW) {
+        cv_f4 o0 = a0 + b0, o1 = a1 + b1;
+        o0.x = o0.x > 0.f ? o0.x : 0.f; o0.y = o0.y > 0.f ? o0.y : 0.f; o0.z = o0.z > 0.f ? o0.z : 0.f; o0.w = o0.w > 0.f ? o0.w : 0.f;
+        o1.x = o1.x > 0.f ? o1.x : 0.f; o1.y = o1.y > 0.f ? o1.y : 0.f; o1.z = o1.z > 0.f ? o1.z : 0.f; o1.w = o1.w > 0.f ? o1.w : 0.f;
+        cv_f4* dst = reinterpret_cast<cv_f4*>(y + ((n0 + f) * (int64_t)OHW + p) * C1_F + kq * 8);
+        if (NTS) { __builtin_nontemporal_store(o0, dst); __builtin_nontemporal_store(o1, dst + 1); }
+        else { dst[0] = o0; dst[1] = o1; }
+      }
+    }
+  }
+}
+
+// LDS plane pitch in bytes: >= HW, a multiple of 16 B, and 16 (mod 64) in dwords
+static int c1_pitch(int HW) {
+  int dw = (HW + 3) / 4;
+  dw += ((16 - dw % 64) + 64) % 64;
+  return dw * 4;
+}
+
+}  // namespace mirl
+
+extern "C" int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t F, int32_t K, int32_t S) {
+  using namespace mirl;
+  if (C != C1_PLANES || F != C1_F || K != C1_K || S != C1_S) return 0;
+  if (H < C1_K || W < C1_K || (W % 4) != 0 || ((H * W) % 16) != 0) return 0;
+  return C1_PLANES * c1_pitch(H * W) <= 64 * 1024 ? 1 : 0;
+}
+
+// flags: bit 0 = plain (cached) output stores instead of non-temporal ones;
+// bits 8.. = frames per LDS fill override (1 or 2), bits 16.. = split override.
+extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight, int64_t ws_o,
+                                    int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias, float scale, float* wpk,
+                                    float* y, int32_t flags, void* stream) {
+  using namespace mirl;
+  if (N <= 0 || !x || !weight || !bias || !wpk || !y) return fail(MIRL_ERR_ARG, "bad conv1_u8_fwd arguments");
+  if (!mirl_conv1_u8_supported(C1_PLANES, H, W, C1_F, C1_K, C1_S)) return fail(MIRL_ERR_ARG, "conv1_u8_fwd: unsupported frame shape");
+  if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || ((uintptr_t)wpk % 16))
+    return fail(MIRL_ERR_ARG, "conv1_u8_fwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
+  const int tiles = (OH * OW + 15) / 16;
+  {
+    ProfScope ps("k_conv1_pack_w", 2.0 * C1_WPK * 4, st);
+    hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, wpk);
+    MIRL_LAUNCH_CHECK();
+  }
+  int fpi = (flags >> 8) & 0xff, split = (flags >> 16) & 0xff;
+  if (fpi != 1 && fpi != 2) fpi = (N >= 1024 && 2 * C1_PLANES * pitch <= 64 * 1024) ? 2 : 1;
+  if (fpi == 2 && 2 * C1_PLANES * pitch > 64 * 1024) fpi = 1;
+  const int max_split = (tiles + 3) / 4;
+  if (split <= 0) split = N >= 512 ? 1 : (int)((512 + N - 1) / N);
+  if (split > max_split) split = max_split;
+  if (fpi == 2) split = 1;
+  const int64_t units = (N + fpi - 1) / fpi * split;
+  const unsigned grid = (unsigned)(units < 512 ? units : 512);
+  const size_t lds = (size_t)fpi * C1_PLANES * pitch;
+  ProfScope ps("k_conv1_u8_fwd", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
+  const bool nts = !(flags & 1);
+  if (fpi == 2) {
+    if (nts) hipLaunchKernelGGL((k_conv1_u8_fwd<2, 1>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+    else     hipLaunchKernelGGL((k_conv1_u8_fwd<2, 0>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+  } else {
+    if (nts) hipLaunchKernelGGL((k_conv1_u8_fwd<1, 1>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+    else     hipLaunchKernelGGL((k_conv1_u8_fwd<1, 0>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+  }
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight, int64_t ws_o,
+                                 int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias, float scale, float* wpk,
+                                 float* y, void* stream) {
+  static const int flags = getenv("MIRL_CONV1_FLAGS") ? atoi(getenv("MIRL_CONV1_FLAGS")) : 0;
+  return mirl_conv1_u8_fwd_ex(N, H, W, x, weight, ws_o, ws_c, ws_h, ws_w, bias, scale, wpk, y, flags, stream);
+}

@@ -11,6 +11,11 @@ expressions; parity tests in tests/test_fused_gpu.py compare against those):
   conv_bias_relu     relu(conv2d(x, W) + b) (cnn.py:47-49): bias-less MIOpen conv,
                      one in-place bias+ReLU pass; backward = one mask + bias-gradient
                      pass, MIOpen data / weight gradients
+  conv_u8_bias_relu  the INPUT layer, relu(conv2d(x_u8 * scale, W) + b) (cnn.py:44-49),
+                     straight from the replay's uint8 frames on the f32 MFMA pipe
+                     (csrc/conv_in.hip): no converted copy of the frames, no separate
+                     bias / ReLU pass; backward = mask + bias-gradient pass and MIOpen's
+                     weight gradient on a conversion made there
   cos_embed          IQN cosine features (iqn.py:78-81) in one kernel
   quantile_product   x[m] * relu(phi @ Wq^T + bq)[m, n] (iqn.py:82-102) with a
                      backward that never materialises g*x / g*emb / the mask
@@ -126,6 +131,65 @@ def conv_bias_relu(x, conv):
             and conv.weight.is_contiguous(memory_format=torch.channels_last)):
         return _ConvBiasReLU.apply(x, conv.weight, conv.bias, tuple(conv.stride))
     return F.relu(conv(x))
+
+
+def frames_to_f32_nhwc(x, scale):
+    """uint8 [N, C, H, W] -> float32 * scale with channels_last memory, one pass (csrc/convert.hip)."""
+    L = _lib()
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    L.check(L.lib.mirl_frames_to_f32_nhwc(n, c, h * w, _p(x), float(scale), _p(out), _stream()), "mirl_frames_to_f32_nhwc")
+    return out
+
+
+def conv_u8_supported(x, conv):
+    """Does the one-pass input layer (mirl_conv1_u8_fwd) cover this conv on this uint8 block?"""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.uint8 and x.dim() == 4 and x.is_contiguous()
+            and x.data_ptr() % 16 == 0 and conv.bias is not None and conv.weight.dtype == torch.float32
+            and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+            and conv.in_channels == x.shape[1] and not torch.is_autocast_enabled()):
+        return False
+    return bool(_lib().lib.mirl_conv1_u8_supported(x.shape[1], x.shape[2], x.shape[3], conv.out_channels,
+                                                   conv.kernel_size[0], conv.stride[0]))
+
+
+class _ConvU8BiasReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, stride):
+        L = _lib()
+        n, _, h, w = x.shape
+        f, k = weight.shape[0], weight.shape[2]
+        oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
+        y = torch.empty((n, f, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if n:
+            wpk = torch.empty(8192, dtype=torch.float32, device=x.device)
+            so, sc, sh, sw = weight.stride()
+            b = bias if bias.data_ptr() % 16 == 0 else bias.clone()
+            L.check(L.lib.mirl_conv1_u8_fwd(n, h, w, _p(x), _p(weight), so, sc, sh, sw, _p(b), float(scale), _p(wpk), _p(y),
+                                            _stream()), "mirl_conv1_u8_fwd")
+        ctx.scale, ctx.stride = scale, stride
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight, y = ctx.saved_tensors
+        grad = grad.contiguous(memory_format=torch.channels_last)
+        g, db = relu_bwd_bias_rows(grad, y, y.shape[1])
+        dw = None
+        if ctx.needs_input_grad[1]:
+            # the weight gradient is the only consumer of float pixels: convert here, for
+            # the rows that take part in the backward only
+            xf = frames_to_f32_nhwc(x, ctx.scale)
+            _, dw, _ = torch.ops.aten.convolution_backward(
+                g, xf, weight, None, [ctx.stride, ctx.stride], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
+        return None, dw, (db if ctx.needs_input_grad[2] else None), None, None
+
+
+def conv_u8_bias_relu(x, conv, scale):
+    """relu(conv(x * scale)) for uint8 NCHW x; the caller checked conv_u8_supported(x, conv)."""
+    return _ConvU8BiasReLU.apply(x, conv.weight, conv.bias, float(scale), int(conv.stride[0]))
 
 
 def cos_embed(taus, freq):

@@ -8,24 +8,16 @@ MI355X-first differences:
   * the LSTM sequence forward hoists the input projection of all timesteps into
     one GEMM and keeps only the recurrent GEMM in the time loop.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .fused import conv_bias_relu, linear_relu
+from .fused import conv_bias_relu, conv_u8_bias_relu, conv_u8_supported, linear_relu
+from .fused import frames_to_f32_nhwc as _frames_to_f32_nhwc
 from .utils import conv2d, conv_out_size, init_weight, linear
-
-
-def _frames_to_f32_nhwc(x, scale):
-    import ctypes as C
-    from rltime_amd._lib import lib, check
-    n, c, h, w = x.shape
-    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    check(lib.mirl_frames_to_f32_nhwc(
-        n, c, h * w, C.c_void_p(x.data_ptr()), float(scale), C.c_void_p(out.data_ptr()),
-        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_frames_to_f32_nhwc")
-    return out
 
 
 def _lead_strides(lead, inner):
@@ -51,10 +43,12 @@ class CNN(BaseModule):
     """modules/cnn.py:9-53: conv+ReLU stack on channel-first input; uint8 input
     is converted and scaled (1/255) on the device."""
 
-    def __init__(self, inp_shape, layers, scale=1.0 / 255.0, channels_last=False):
+    def __init__(self, inp_shape, layers, scale=1.0 / 255.0, channels_last=False, direct_u8=None):
         super().__init__()
         self.scale = scale
         self.channels_last = channels_last
+        # input layer straight from uint8 frames (csrc/conv_in.hip) when its shape is covered
+        self.direct_u8 = (os.environ.get("MIRL_CONV1_DIRECT", "1") != "0") if direct_u8 is None else bool(direct_u8)
         self.layers = nn.ModuleList()
         ch = inp_shape[0]
         h, w = inp_shape[1:]
@@ -77,14 +71,24 @@ class CNN(BaseModule):
                 and x.dtype == torch.uint8 and x.dim() >= 4 and x.is_contiguous()
                 and not torch.is_autocast_enabled()):
             return None
+        if self._takes_u8(x.reshape((-1,) + tuple(x.shape[-3:]))):
+            return None                       # forward() reads the uint8 rows themselves: nothing to prepare
         lead = tuple(x.shape[:-3])
         flat = _frames_to_f32_nhwc(x.reshape((-1,) + tuple(x.shape[-3:])), self.scale)
         # logical [..., C, H, W] view of the NHWC buffer (each frame is channels_last)
         c, h, w = x.shape[-3:]
         return flat.as_strided(lead + (c, h, w), _lead_strides(lead, c * h * w) + (1, w * c, c))
 
+    def _takes_u8(self, x):
+        return bool(self.direct_u8 and self.channels_last and self.scale and len(self.layers)
+                    and conv_u8_supported(x, self.layers[0]))
+
     def forward(self, x, prepared=False, **kwargs):
-        if prepared:
+        layers = self.layers
+        if not prepared and self._takes_u8(x):
+            x = conv_u8_bias_relu(x, layers[0], self.scale)          # conversion + conv + bias + ReLU, one kernel
+            layers = layers[1:]
+        elif prepared:
             # already float32 * scale; NHWC memory unless an index op re-laid it out
             if self.channels_last and not x.is_contiguous(memory_format=torch.channels_last):
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -99,7 +103,7 @@ class CNN(BaseModule):
             # uint8 * python float promotes to float32 in ONE pass (same values as
             # x.float() * scale, cnn.py:44-45)
             x = x * self.scale if x.dtype == torch.uint8 else x.float() * self.scale
-        for layer in self.layers:
+        for layer in layers:
             x = conv_bias_relu(x, layer) if self.channels_last else F.relu(layer(x))
         return x
 

@@ -1,0 +1,123 @@
+"""GPU: the one-pass input layer (csrc/conv_in.hip, mirl_conv1_u8_fwd) against the
+reference's expression for it, rltime/models/torch/modules/cnn.py:44-49:
+relu(conv2d(x.float() * scale, W, b, stride 4)).  Integer-valued weights with
+scale 1 make every product and partial sum exact in fp32, so indexing is checked
+BIT-exactly; real weights are held to the north-star 1e-4 (same products, other
+summation order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 84, 84), (2, 84, 84), (3, 84, 84), (33, 84, 84), (1025, 84, 84), (7, 36, 36), (5, 44, 52), (4, 12, 16),
+          (6, 8, 8), (2, 100, 100)]
+
+
+def _call(x, w, b, scale, flags=None):
+    from rltime_amd._lib import lib, check
+    n, _, h, ww = x.shape
+    oh, ow = (h - 8) // 4 + 1, (ww - 8) // 4 + 1
+    y = torch.full((n, 32, oh, ow), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+    wpk = torch.empty(8192, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    so, sc, sh, sw = w.stride()
+    if flags is None:
+        check(lib.mirl_conv1_u8_fwd(n, h, ww, p(x), p(w), so, sc, sh, sw, p(b), scale, p(wpk), p(y), st), "conv1")
+    else:
+        check(lib.mirl_conv1_u8_fwd_ex(n, h, ww, p(x), p(w), so, sc, sh, sw, p(b), scale, p(wpk), p(y), flags, st), "conv1_ex")
+    return y
+
+
+@pytest.mark.parametrize("n,h,w", SHAPES)
+def test_integer_weights_are_bit_exact(n, h, w):
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + h)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g)
+    wt = torch.randint(-2, 3, (32, 4, 8, 8), device="cuda", generator=g).float()
+    b = torch.randint(-50000, 50000, (32,), device="cuda", generator=g).float()
+    want = F.relu(F.conv2d(x.double(), wt.double(), b.double(), 4)).float()
+    got = _call(x, wt, b, 1.0)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    # weights handed over in NHWC memory (how the channels_last model stores them): same result
+    assert torch.equal(_call(x, wt.contiguous(memory_format=torch.channels_last), b, 1.0), want)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 84, 84), (1025, 84, 84), (5, 44, 52)])
+def test_launch_shapes_agree_bitwise(n, h, w):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g)
+    wt = torch.randn(32, 4, 8, 8, device="cuda", generator=g) * 0.05
+    b = torch.randn(32, device="cuda", generator=g) * 0.1
+    base = _call(x, wt, b, 1.0 / 255.0)
+    for fpi in (1, 2):
+        for split in (0, 1, 3, 7):
+            for cached in (0, 1):
+                got = _call(x, wt, b, 1.0 / 255.0, flags=cached | (fpi << 8) | (split << 16))
+                assert torch.equal(got, base), (fpi, split, cached)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 84, 84), (257, 84, 84), (2050, 84, 84), (5, 44, 52)])
+def test_real_weights_within_tolerance(n, h, w):
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g)
+    conv = nn.Conv2d(4, 32, 8, 4).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-0.3, 0.3)
+    want = F.relu(F.conv2d(x.double() * (1.0 / 255.0), conv.weight.double(), conv.bias.double(), 4))
+    got = _call(x, conv.weight.detach(), conv.bias.detach(), 1.0 / 255.0)
+    err = float((got.double() - want).abs().max()) / float(want.abs().max())
+    assert err <= 1e-5, err            # far inside the 1e-4 bar: 256 fp32 terms
+
+
+def test_autograd_function_matches_plain_expression():
+    from rltime_amd.models.torch.fused import conv_u8_bias_relu, conv_u8_supported
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randint(0, 256, (37, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    conv = nn.Conv2d(4, 32, 8, 4).cuda().to(memory_format=torch.channels_last)
+    assert conv_u8_supported(x, conv)
+    res, up = [], None
+    for fused in (True, False):
+        conv.zero_grad(set_to_none=True)
+        y = conv_u8_bias_relu(x, conv, 1.0 / 255.0) if fused else F.relu(conv(x.float() * (1.0 / 255.0)))
+        if up is None:
+            up = torch.randn_like(y)
+        (y * up).sum().backward()
+        res.append((y.detach(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for a, b, what in zip(res[0], res[1], ("y", "dW", "db")):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err <= 1e-4, (what, err)
+
+
+def test_unsupported_shapes_are_refused_and_the_module_falls_back():
+    from rltime_amd._lib import lib
+    from rltime_amd.models.torch.modules import CNN
+    assert lib.mirl_conv1_u8_supported(4, 84, 84, 32, 8, 4) == 1
+    for c, h, w, f, k, s in [(3, 84, 84, 32, 8, 4), (4, 84, 84, 16, 8, 4), (4, 84, 84, 32, 4, 2), (4, 42, 42, 32, 8, 4),
+                             (4, 84, 86, 32, 8, 4), (4, 4, 84, 32, 8, 4), (4, 200, 200, 32, 8, 4)]:
+        assert lib.mirl_conv1_u8_supported(c, h, w, f, k, s) == 0, (c, h, w, f, k, s)
+    x = torch.zeros((2, 4, 42, 42), dtype=torch.uint8, device="cuda")
+    wt, b = torch.zeros(32, 4, 8, 8, device="cuda"), torch.zeros(32, device="cuda")
+    from rltime_amd._lib import MirlError
+    with pytest.raises(MirlError):
+        _call(x, wt, b, 1.0)
+    layers = [{"filters": 32, "kernel": 8, "stride": 4}, {"filters": 64, "kernel": 4, "stride": 2}]
+    torch.manual_seed(0)
+    direct = CNN((4, 84, 84), layers, channels_last=True, direct_u8=True).cuda()
+    plain = CNN((4, 84, 84), layers, channels_last=True, direct_u8=False).cuda()
+    plain.load_state_dict(direct.state_dict())
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randint(0, 256, (9, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g)
+    assert direct.prepare_input(x) is None and plain.prepare_input(x) is not None
+    a, bb = direct(x), plain(x)
+    assert float((a - bb).abs().max()) <= 1e-5 * float(bb.abs().max())
+    # a frame shape the kernel does not cover: both modules take the generic path
+    small = CNN((4, 42, 42), layers, channels_last=True, direct_u8=True).cuda()
+    xs = torch.randint(0, 256, (3, 4, 42, 42), dtype=torch.uint8, device="cuda", generator=g)
+    assert small.prepare_input(xs) is not None
+    assert small(xs).shape == (3, 64, 3, 3)

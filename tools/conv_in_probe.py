@@ -1,0 +1,67 @@
+"""Timing probe for the one-pass input layer (csrc/conv_in.hip) against the path it
+replaces (convert.hip + MIOpen conv + bias/ReLU pass), HIP events on the launch
+stream.  One JSON line per variant.  Usage: python tools/conv_in_probe.py [frames ...]"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import torch.nn as nn
+
+from rltime_amd._lib import lib, check
+from rltime_amd.models.torch.fused import conv_bias_relu, frames_to_f32_nhwc
+
+PEAK_TFLOPS = 157.3
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [32, 20480, 41472]
+    conv = nn.Conv2d(4, 32, 8, 4).cuda().to(memory_format=torch.channels_last)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for n in sizes:
+        x = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, device="cuda")
+        y = torch.empty((n, 32, 20, 20), device="cuda").contiguous(memory_format=torch.channels_last)
+        wpk = torch.empty(8192, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        so, sc, sh, sw = conv.weight.stride()
+        flop = n * 400 * 2.0 * 256 * 32
+        iters = 20 if n > 1000 else 200
+        with torch.no_grad():
+            ms = timed(lambda: conv_bias_relu(frames_to_f32_nhwc(x, 1 / 255.0), conv), iters)
+            xf = frames_to_f32_nhwc(x, 1 / 255.0)
+            ms_conv = timed(lambda: conv_bias_relu(xf, conv), iters)
+            del xf
+        print(json.dumps({"frames": n, "variant": "convert + MIOpen conv + bias/ReLU pass", "ms": round(ms, 4),
+                          "ms_without_convert": round(ms_conv, 4), "tflops": round(flop / ms / 1e9, 1)}), flush=True)
+        variants = [("default", None)] + [("fpi%d split%d %s" % (f, s, "cached" if c else "nt"), c | (f << 8) | (s << 16))
+                                         for f in (1, 2) for s in ((0,) if n > 1000 else (0, 2, 4, 7)) for c in (0, 1)]
+        for name, flags in variants:
+            if flags is None:
+                fn = lambda: check(lib.mirl_conv1_u8_fwd(n, 84, 84, p(x), p(conv.weight), so, sc, sh, sw, p(conv.bias),
+                                                         1 / 255.0, p(wpk), p(y), st))
+            else:
+                fn = lambda flags=flags: check(lib.mirl_conv1_u8_fwd_ex(n, 84, 84, p(x), p(conv.weight), so, sc, sh, sw,
+                                                                         p(conv.bias), 1 / 255.0, p(wpk), p(y), flags, st))
+            ms = timed(fn, iters)
+            print(json.dumps({"frames": n, "variant": "conv1_u8 " + name, "ms": round(ms, 4),
+                              "tflops": round(flop / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(flop / ms / 1e9 / PEAK_TFLOPS, 3),
+                              "hbm_GBps": round(n * (28224 + 51200) / ms / 1e6, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

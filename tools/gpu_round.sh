@@ -10,6 +10,16 @@ for w in $WHAT; do
     tests)   timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 -o faulthandler_timeout=240 > "$OUT/pytest.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest.log"; tail -15 "$OUT/pytest.log";;
     bench)   timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_iqn_lstm.json" 2> "$OUT/bench_iqn_lstm.err"; echo "bench rc=$?"; tail -c 1500 "$OUT/bench_iqn_lstm.err"; head -c 6000 "$OUT/bench_iqn_lstm.json";;
     bench23) for c in rainbow_iqn dqn_uniform; do timeout 600 python bench.py --config $c --steps 50 --warmup 10 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"; tail -c 800 "$OUT/bench_$c.err"; head -c 5000 "$OUT/bench_$c.json"; done;;
+    ctests)  timeout 600 python -m pytest tests/test_conv_in_gpu.py tests/test_fused_gpu.py tests/test_models_gpu.py -x -q --timeout 300 > "$OUT/pytest_conv.log" 2>&1; echo "pytest conv rc=$?"; tail -25 "$OUT/pytest_conv.log";;
+    cprobe)  timeout 300 python tools/conv_in_probe.py > "$OUT/conv_in_probe.jsonl" 2> "$OUT/conv_in_probe.err"; echo "cprobe rc=$?"; cat "$OUT/conv_in_probe.jsonl"; tail -3 "$OUT/conv_in_probe.err";;
+    benchq)  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"; echo "benchq rc=$?"; tail -c 600 "$OUT/bench_quick.err"; python - "$OUT/bench_quick.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("ms/step", d["ms_per_step"], d["step_ms"], "value", d["value"])
+for k in d["roofline_all"]["kernels"][:12]:
+    print(k["kernel"], k["launches_per_step"], k["avg_us"], k["ms_per_step"], k["frac_of_hbm_peak"])
+PY
+    ;;
     probe)   timeout 300 python tools/convert_probe.py > "$OUT/convert_probe.jsonl" 2> "$OUT/convert_probe.err"; echo "probe rc=$?"; cat "$OUT/convert_probe.jsonl"; tail -3 "$OUT/convert_probe.err";;
     prof)    R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -60 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     gprobe)  for nt in 1 2; do PROBE_SIZE=1000000 PROBE_NT=$nt PROBE_ITERS=10 timeout 300 python tools/gather_probe.py >> "$OUT/gather_probe.jsonl" 2>> "$OUT/gather_probe.err"; done; echo "gprobe rc=$?"; cat "$OUT/gather_probe.jsonl";;
