@@ -25,9 +25,10 @@
 //                 issue distance 64 cycles > the 40-cycle MFMA latency).
 //   operands      the 2 x 64 weight operands of a lane are loop-invariant and live
 //                 in registers for the whole kernel (packed once per launch by
-//                 k_conv1_pack_w into the lane order); the position operand is
-//                 float(u8) * scale — the very products the reference forms — read
-//                 as 8 consecutive bytes per (plane, kh) row from LDS.
+//                 k_conv1_pack_w into the lane order, times `scale`); the position
+//                 operand is float(u8), read as 8 consecutive bytes per (plane, kh)
+//                 row from LDS.  x*(scale*w) instead of (x*scale)*w: one rounding of
+//                 the reference's product moved, 1e-7 relative.
 //   LDS layout    plane pitch padded to 16 (mod 64) dwords, so the four planes a
 //                 ds_read touches land on disjoint bank groups.
 //   epilogue      accumulator rows are 4 consecutive filters: + bias, ReLU, two
@@ -50,13 +51,13 @@ constexpr int C1_LD = 7;                      // staging loads in flight per lan
 // permutation f = (i>>2)*8 + m*4 + (i&3), which makes the 4 accumulator rows a
 // lane owns 4 CONSECUTIVE filters (and the two halves 8 consecutive ones).
 __global__ void __launch_bounds__(256)
-k_conv1_pack_w(const float* __restrict__ w, int64_t so, int64_t sc, int64_t sh, int64_t sw, float* __restrict__ wpk) {
+k_conv1_pack_w(const float* __restrict__ w, int64_t so, int64_t sc, int64_t sh, int64_t sw, float scale, float* __restrict__ wpk) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= C1_WPK) return;
   const int lane = t & 63, tap = (t >> 6) & 63, m = t >> 12;
   const int i = lane & 15, c = lane >> 4, kh = tap >> 3, kw = tap & 7;
   const int f = (i >> 2) * 8 + m * 4 + (i & 3);
-  wpk[t] = w[f * so + c * sc + kh * sh + kw * sw];
+  wpk[t] = w[f * so + c * sc + kh * sh + kw * sw] * scale;   // x*scale*w summed as x*(scale*w): one rounding moved
 }
 
 __device__ __forceinline__ float c1_byte(uint32_t v, int b) { return (float)((v >> (8 * b)) & 0xffu); }
@@ -65,74 +66,114 @@ __device__ __forceinline__ float c1_byte(uint32_t v, int b) { return (float)((v 
 // (N, 32, OH, OW) tensor).  Work unit u = (frame group, part): a group is FPI
 // consecutive frames, `split` parts share a group's tiles (split > 1 only for
 // small N, to spread few frames over the chip).  NTS: non-temporal output stores.
-template <int FPI, int NTS>
+// DBG: timing experiments only (tools/conv_in_probe.py): bit 0 no u8->f32
+// conversion, bit 1 no output stores, bit 2 no refill after the first unit.
+//
+// VALU work next to the MFMA chain is NOT free here (both are issued through the
+// SIMD's one VALU port; measured: the 64 conversions + 64 scale multiplies per tile
+// cost 11 % of the kernel), so the per-tile scalar work is kept minimal: the scale
+// is folded into the packed weights, the position -> (row, column) split is one
+// multiply-high, the frame-of-tile split is a compare, and the LDS words of the
+// NEXT tile are requested before the current tile's chain so their latency hides
+// under it.
+#define C1_TILE_ADDR(tt_, f_, p_, base_)                                                        \
+  {                                                                                             \
+    f_ = (FPI > 1 && tt_ >= tiles) ? 1 : 0;                                                     \
+    p_ = (tt_ - f_ * tiles) * 16 + j;                                                           \
+    const int pc_ = p_ < OHW ? p_ : OHW - 1;                                                    \
+    const int oh_ = OW == 1 ? pc_ : (int)__umulhi((unsigned)pc_, ow_magic);                     \
+    base_ = c1_lds + (f_ * C1_PLANES + kq) * pitch + (oh_ * C1_S) * W + (pc_ - oh_ * OW) * C1_S; \
+  }
+#define C1_TILE_READ(base_, px_)                                                                \
+  _Pragma("unroll") for (int kh = 0; kh < C1_K; ++kh) {                                         \
+    px_[2 * kh] = *reinterpret_cast<const uint32_t*>(base_ + kh * W);                           \
+    px_[2 * kh + 1] = *reinterpret_cast<const uint32_t*>(base_ + kh * W + 4);                   \
+  }
+// one tile: 128 MFMAs on two accumulator chains, then + bias, ReLU, two 16 B stores
+#define C1_TILE_COMPUTE(px_, f_, p_)                                                            \
+  {                                                                                             \
+    cv_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};                                 \
+    _Pragma("unroll") for (int s = 0; s < C1_TAPS; ++s) {                                       \
+      /* tap s = kh*8 + kw: word kh*2 + (kw>>2), byte kw&3 */                                   \
+      const float v = (DBG & 1) ? __uint_as_float(px_[s >> 2] & 0x3fffffffu) : c1_byte(px_[s >> 2], s & 3); \
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr0[s], v, a0, 0, 0, 0);                        \
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[s], v, a1, 0, 0, 0);                        \
+    }                                                                                           \
+    if ((DBG & 2) ? (a0.x == 12345.678f) : (p_ < OHW)) {                                        \
+      cv_f4 o0 = a0 + b0, o1 = a1 + b1;                                                         \
+      o0.x = o0.x > 0.f ? o0.x : 0.f; o0.y = o0.y > 0.f ? o0.y : 0.f; o0.z = o0.z > 0.f ? o0.z : 0.f; o0.w = o0.w > 0.f ? o0.w : 0.f; \
+      o1.x = o1.x > 0.f ? o1.x : 0.f; o1.y = o1.y > 0.f ? o1.y : 0.f; o1.z = o1.z > 0.f ? o1.z : 0.f; o1.w = o1.w > 0.f ? o1.w : 0.f; \
+      cv_f4* dst = reinterpret_cast<cv_f4*>(y + ((n0 + f_) * (int64_t)OHW + p_) * C1_F + kq * 8); \
+      if (NTS) { __builtin_nontemporal_store(o0, dst); __builtin_nontemporal_store(o1, dst + 1); } \
+      else { dst[0] = o0; dst[1] = o1; }                                                        \
+    }                                                                                           \
+  }
+
+template <int FPI, int NTS, int DBG>
 __global__ void __launch_bounds__(256, 2)
-k_conv1_u8_fwd(int64_t N, int H, int W, int OH, int OW, int pitch, int split, const uint8_t* __restrict__ x,
-               const float* __restrict__ wpk, const float* __restrict__ bias, float scale, float* __restrict__ y) {
+k_conv1_u8_fwd(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, int split, const uint8_t* __restrict__ x,
+               const float* __restrict__ wpk, const float* __restrict__ bias, float* __restrict__ y) {
   extern __shared__ __align__(16) uint8_t c1_lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kq = lane >> 4;
   float wr0[C1_TAPS], wr1[C1_TAPS];
 #pragma unroll
   for (int s = 0; s < C1_TAPS; ++s) { wr0[s] = wpk[s * 64 + lane]; wr1[s] = wpk[(C1_TAPS + s) * 64 + lane]; }
   const cv_f4 b0 = *reinterpret_cast<const cv_f4*>(bias + kq * 8), b1 = *reinterpret_cast<const cv_f4*>(bias + kq * 8 + 4);
   const int HW = H * W, OHW = OH * OW, tiles = (OHW + 15) >> 4, hw16 = HW >> 4;
-  const int64_t groups = (N + FPI - 1) / FPI, units = groups * split;
+  const int groups = (N + FPI - 1) / FPI, units = groups * split, step = 4 * split;
   bool first = true;
-  for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
-    const int64_t group = u / split, n0 = group * FPI;
-    const int part = (int)(u - group * split);
-    if (!first) __syncthreads();                    // every wave is done reading the previous frames
-    first = false;
-    {
-      // FPI frames x 4 planes are one contiguous run of 16 B vectors in HBM; only the LDS
-      // side has the padded plane pitch.  C1_LD loads in flight per lane before the writes.
-      const int64_t left = N - n0;
-      const int vecs = (int)(left < FPI ? left : FPI) * C1_PLANES * hw16;
-      const uint4* s4 = reinterpret_cast<const uint4*>(x + n0 * (int64_t)(C1_PLANES * HW));
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int group = split == 1 ? u : u / split, part = u - group * split;
+    const int n0 = group * FPI;
+    const int frames = N - n0 < FPI ? N - n0 : FPI;
+    if (!first && !(DBG & 4)) __syncthreads();      // every wave is done reading the previous frames
+    if (first || !(DBG & 4)) {
+      // the unit's frames x 4 planes are one contiguous run of 16 B vectors in HBM; only
+      // the LDS side has the padded plane pitch.  C1_LD loads in flight per lane.
+      const int vecs = frames * C1_PLANES * hw16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(x + (int64_t)n0 * (C1_PLANES * HW));
       for (int o0 = tid; o0 < vecs; o0 += 256 * C1_LD) {
         uint4 v[C1_LD];
 #pragma unroll
-        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; if (o < vecs) v[k] = s4[o]; }
+        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; v[k] = s4[o < vecs ? o : vecs - 1]; }
 #pragma unroll
         for (int k = 0; k < C1_LD; ++k) {
           const int o = o0 + k * 256;
           if (o < vecs) { const int pl = o / hw16; *reinterpret_cast<uint4*>(c1_lds + pl * pitch + (o - pl * hw16) * 16) = v[k]; }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int tt = part * 4 + wave; tt < FPI * tiles; tt += 4 * split) {
-      const int f = tt / tiles, tile = tt - f * tiles;
-      if (n0 + f >= N) break;                       // wave-uniform
-      const int p = tile * 16 + j, pc = p < OHW ? p : OHW - 1;
-      const int oh = pc / OW, ow = pc - oh * OW;
-      const uint8_t* base = c1_lds + (f * C1_PLANES + kq) * pitch + (oh * C1_S) * W + ow * C1_S;
-      uint32_t px[2 * C1_K];
-#pragma unroll
-      for (int kh = 0; kh < C1_K; ++kh) {
-        px[2 * kh] = *reinterpret_cast<const uint32_t*>(base + kh * W);
-        px[2 * kh + 1] = *reinterpret_cast<const uint32_t*>(base + kh * W + 4);
-      }
-      __builtin_amdgcn_sched_barrier(0);            // all 16 LDS words in flight before the MFMA chain starts
-      cv_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < C1_TAPS; ++s) {
-        const float v = c1_byte(px[s >> 2], s & 3) * scale;     // tap s = kh*8 + kw: word kh*2 + (kw>>2), byte kw&3
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr0[s], v, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[s], v, a1, 0, 0, 0);
-      }
-      if (p < OHW) {
-        cv_f4 o0 = a0 + b0, o1 = a1 + b1;
-        o0.x = o0.x > 0.f ? o0.x : 0.f; o0.y = o0.y > 0.f ? o0.y : 0.f; o0.z = o0.z > 0.f ? o0.z : 0.f; o0.w = o0.w > 0.f ? o0.w : 0.f;
-        o1.x = o1.x > 0.f ? o1.x : 0.f; o1.y = o1.y > 0.f ? o1.y : 0.f; o1.z = o1.z > 0.f ? o1.z : 0.f; o1.w = o1.w > 0.f ? o1.w : 0.f;
-        cv_f4* dst = reinterpret_cast<cv_f4*>(y + ((n0 + f) * (int64_t)OHW + p) * C1_F + kq * 8);
-        if (NTS) { __builtin_nontemporal_store(o0, dst); __builtin_nontemporal_store(o1, dst + 1); }
-        else { dst[0] = o0; dst[1] = o1; }
-      }
+    first = false;
+    // this wave's tiles: tt = part*4 + wave, + step, ... < frames * tiles; two tiles per
+    // trip with ping-pong pixel registers, the next tile's LDS reads issued ahead
+    const int tend = frames * tiles;
+    int tt = part * 4 + wave;
+    if (tt >= tend) continue;
+    uint32_t pxa[2 * C1_K], pxb[2 * C1_K];
+    int fa, pa, fb = 0, pb = 0;
+    const uint8_t* base;
+    C1_TILE_ADDR(tt, fa, pa, base);
+    C1_TILE_READ(base, pxa);
+    for (;;) {
+      const bool more_b = tt + step < tend;
+      if (more_b) { C1_TILE_ADDR(tt + step, fb, pb, base); C1_TILE_READ(base, pxb); }
+      __builtin_amdgcn_sched_barrier(0);            // LDS words of the next tile in flight before this chain
+      C1_TILE_COMPUTE(pxa, fa, pa);
+      if (!more_b) break;
+      tt += 2 * step;
+      const bool more_a = tt < tend;
+      if (more_a) { C1_TILE_ADDR(tt, fa, pa, base); C1_TILE_READ(base, pxa); }
+      __builtin_amdgcn_sched_barrier(0);
+      C1_TILE_COMPUTE(pxb, fb, pb);
+      if (!more_a) break;
     }
   }
 }
+#undef C1_TILE_ADDR
+#undef C1_TILE_READ
+#undef C1_TILE_COMPUTE
 
 // LDS plane pitch in bytes: >= HW, a multiple of 16 B, and 16 (mod 64) in dwords
 static int c1_pitch(int HW) {
@@ -150,13 +191,14 @@ extern "C" int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t 
   return C1_PLANES * c1_pitch(H * W) <= 64 * 1024 ? 1 : 0;
 }
 
-// flags: bit 0 = plain (cached) output stores instead of non-temporal ones;
-// bits 8.. = frames per LDS fill override (1 or 2), bits 16.. = split override.
+// flags: bit 0 = plain (cached) output stores instead of non-temporal ones; bits 8.. =
+// frames per LDS fill override (1 or 2), bits 16.. = split override; bits 24-26 =
+// timing-experiment variants (see the kernel).
 extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight, int64_t ws_o,
                                     int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias, float scale, float* wpk,
                                     float* y, int32_t flags, void* stream) {
   using namespace mirl;
-  if (N <= 0 || !x || !weight || !bias || !wpk || !y) return fail(MIRL_ERR_ARG, "bad conv1_u8_fwd arguments");
+  if (N <= 0 || N >= (1LL << 30) || !x || !weight || !bias || !wpk || !y) return fail(MIRL_ERR_ARG, "bad conv1_u8_fwd arguments");
   if (!mirl_conv1_u8_supported(C1_PLANES, H, W, C1_F, C1_K, C1_S)) return fail(MIRL_ERR_ARG, "conv1_u8_fwd: unsupported frame shape");
   if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)bias % 16) || ((uintptr_t)wpk % 16))
     return fail(MIRL_ERR_ARG, "conv1_u8_fwd: pointers must be 16-byte aligned");
@@ -165,7 +207,7 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   const int tiles = (OH * OW + 15) / 16;
   {
     ProfScope ps("k_conv1_pack_w", 2.0 * C1_WPK * 4, st);
-    hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, wpk);
+    hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, wpk);
     MIRL_LAUNCH_CHECK();
   }
   int fpi = (flags >> 8) & 0xff, split = (flags >> 16) & 0xff;
@@ -180,13 +222,23 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   const size_t lds = (size_t)fpi * C1_PLANES * pitch;
   ProfScope ps("k_conv1_u8_fwd", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
   const bool nts = !(flags & 1);
-  if (fpi == 2) {
-    if (nts) hipLaunchKernelGGL((k_conv1_u8_fwd<2, 1>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
-    else     hipLaunchKernelGGL((k_conv1_u8_fwd<2, 0>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+  const int dbg = (flags >> 24) & 7;
+  const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;   // exact n / OW for n < 2^16
+#define C1_LAUNCH(FPI_, NTS_, DBG_) \
+  hipLaunchKernelGGL((k_conv1_u8_fwd<FPI_, NTS_, DBG_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, split, x, wpk, bias, y)
+  if (dbg) {                                             // timing experiments, fpi 2 + nt stores only
+    if (fpi != 2 || !nts) return fail(MIRL_ERR_ARG, "conv1_u8_fwd: debug variants exist for fpi 2 with nt stores only");
+    switch (dbg) {
+      case 1: C1_LAUNCH(2, 1, 1); break;  case 2: C1_LAUNCH(2, 1, 2); break;
+      case 4: C1_LAUNCH(2, 1, 4); break;  case 7: C1_LAUNCH(2, 1, 7); break;
+      default: return fail(MIRL_ERR_ARG, "conv1_u8_fwd: unknown debug variant");
+    }
+  } else if (fpi == 2) {
+    if (nts) C1_LAUNCH(2, 1, 0); else C1_LAUNCH(2, 0, 0);
   } else {
-    if (nts) hipLaunchKernelGGL((k_conv1_u8_fwd<1, 1>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
-    else     hipLaunchKernelGGL((k_conv1_u8_fwd<1, 0>), dim3(grid), dim3(256), lds, st, N, H, W, OH, OW, pitch, split, x, wpk, bias, scale, y);
+    if (nts) C1_LAUNCH(1, 1, 0); else C1_LAUNCH(1, 0, 0);
   }
+#undef C1_LAUNCH
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

@@ -48,8 +48,14 @@ def main():
             del xf
         print(json.dumps({"frames": n, "variant": "convert + MIOpen conv + bias/ReLU pass", "ms": round(ms, 4),
                           "ms_without_convert": round(ms_conv, 4), "tflops": round(flop / ms / 1e9, 1)}), flush=True)
-        variants = [("default", None)] + [("fpi%d split%d %s" % (f, s, "cached" if c else "nt"), c | (f << 8) | (s << 16))
-                                         for f in (1, 2) for s in ((0,) if n > 1000 else (0, 2, 4, 7)) for c in (0, 1)]
+        if n > 1000:
+            variants = [("default", None), ("fpi2 nt", 2 << 8), ("fpi1 nt", 1 << 8), ("fpi2 cached", (2 << 8) | 1)]
+            # timing experiments (results are NOT the convolution): what each part costs
+            for dbg, what in ((1, "no u8->f32 conversion"), (2, "no output stores"), (4, "no LDS refill"), (7, "MFMA chain only")):
+                variants.append(("fpi2 nt EXPERIMENT " + what, (2 << 8) | (dbg << 24)))
+        else:
+            variants = [("default", None)] + [("fpi1 split%d %s" % (s, "cached" if c else "nt"), c | (1 << 8) | (s << 16))
+                                             for s in (0, 2, 4, 7) for c in (0, 1)]
         for name, flags in variants:
             if flags is None:
                 fn = lambda: check(lib.mirl_conv1_u8_fwd(n, 84, 84, p(x), p(conv.weight), so, sc, sh, sw, p(conv.bias),
