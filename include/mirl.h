@@ -361,6 +361,21 @@ int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, cons
                          int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
                          float scale, float* wpk, float* y, int32_t flags, void* stream);
 
+/* Weight gradient of the same layer from the same uint8 frames (what autograd derives
+ * for cnn.py:44-49; the layer's input needs no gradient):
+ *   dw[f][c][kh][kw] = scale * sum over (n, oh, ow) of g[n][oh][ow][f] * float(x[n][c][4 oh + kh][4 ow + kw])
+ *   g        float [N][OH][OW][32], the gradient w.r.t. the conv output AFTER the ReLU
+ *            mask (mirl_relu_bwd_bias_rows), NHWC memory like y
+ *   dw       float, logical [32][4][8][8] written with element strides ws_o, ws_c, ws_h, ws_w
+ *   scratch  *out of mirl_conv1_u8_wrw_scratch_floats() floats (per-workgroup partial slabs; summed
+ *            in slab order by a second kernel: fixed partition and order, no float atomics,
+ *            bit-identical reruns)
+ * Same shape coverage as mirl_conv1_u8_fwd.                                             */
+int mirl_conv1_u8_wrw_scratch_floats(int64_t* out);
+int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
+                      float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                      void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

@@ -175,6 +175,158 @@ k_conv1_u8_fwd(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
 #undef C1_TILE_READ
 #undef C1_TILE_COMPUTE
 
+// ---------------------------------------------------------------------------
+// Weight gradient of the same layer from the same uint8 frames:
+//   dW[f][c][kh][kw] = scale * sum over (n, oh, ow) of g[n][oh][ow][f] * float(x[n][c][4 oh + kh][4 ow + kw])
+// (what autograd derives for cnn.py:44-49; the layer's input needs no gradient).
+// GEMM view: D[32 filters][256 taps] = G^T [32][P] x Patch [P][256] with the
+// reduction over the P = N * OH * OW output positions.  One v_mfma_f32_16x16x4_f32
+// takes 4 positions (k), 16 filters (rows) and 16 taps (columns); a wave keeps the
+// WHOLE 32 x 256 result in registers (2 x 16 accumulator tiles = 128 VGPRs, all
+// independent: no dependent-issue stalls) and streams positions through it:
+//   A operand  g[pos][2j], g[pos][2j+1] — one 8 B load per lane per k-step, a wave
+//              load covers 4 consecutive 128 B rows of g (row i <-> filter 2i + half);
+//              the next block's loads are issued before the current block's chain
+//   B operand  one byte per (lane, tap group) from the frame staged in LDS as in the
+//              forward: lane (tap j, position q) reads x[c][4 oh_q + kh][4 ow_q + kw]
+//              for the 16 groups t -> c = t>>2, kh = 2 (t&3) + (j>>3), kw = j&7, so that
+//              group*16 + j IS the flattened (c, kh, kw) index; with the frame shape a
+//              template constant the 16 offsets fold into the ds_read immediates
+// Work split as in the forward (persistent workgroups, FPI frames per LDS fill, the 4
+// waves interleave blocks of 4 k-steps).  Partials: the 4 waves of a workgroup add
+// up in LDS in wave order, the workgroup writes one 32 KB slab, k_conv1_wrw_reduce
+// sums the slabs in index order — fixed partition, fixed order, no float atomics.
+// Algorithmic bytes: 28 224 B of pixels + 51 200 B of g per frame (as the forward);
+// 6.55 MFLOP per frame on the f32 MFMA pipe.
+constexpr int C1_WU = 4;                      // k-steps (4 positions each) per block
+constexpr int C1_DW = C1_F * C1_PLANES * C1_TAPS;   // 8192 weight-gradient elements
+
+#define C1_WRW_LOAD(bb_, gv_, po_, f_)                                                          \
+  {                                                                                             \
+    f_ = (FPI > 1 && bb_ >= blocks) ? 1 : 0;                                                    \
+    const int ks0_ = (bb_ - f_ * blocks) * C1_WU;                                               \
+    const float* gf_ = g + (int64_t)(n0 + f_) * OHW * C1_F + 2 * j;                            \
+    _Pragma("unroll") for (int w = 0; w < C1_WU; ++w) {                                         \
+      const int p_ = (ks0_ + w) * 4 + q;                                                        \
+      const bool ok_ = p_ < OHW;                                                                \
+      const int pc_ = ok_ ? p_ : OHW - 1;                                                       \
+      const float2 t_ = *reinterpret_cast<const float2*>(gf_ + pc_ * C1_F);                    \
+      gv_[w].x = ok_ ? t_.x : 0.f; gv_[w].y = ok_ ? t_.y : 0.f;                                 \
+      const int oh_ = OW == 1 ? pc_ : (int)__umulhi((unsigned)pc_, ow_magic);                   \
+      po_[w] = (oh_ * C1_S) * Wd + (pc_ - oh_ * OW) * C1_S;                                     \
+    }                                                                                           \
+  }
+#define C1_WRW_COMPUTE(gv_, po_, f_)                                                            \
+  {                                                                                             \
+    const uint8_t* fl_ = c1_lds + f_ * C1_PLANES * Pd + tap_off;                                \
+    _Pragma("unroll") for (int w = 0; w < C1_WU; ++w) {                                         \
+      const uint8_t* pb_ = fl_ + po_[w];                                                        \
+      _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                          \
+        const float v = (float)pb_[(t >> 2) * Pd + (t & 3) * 2 * Wd];                           \
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].x, v, acc0[t], 0, 0, 0);          \
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].y, v, acc1[t], 0, 0, 0);          \
+      }                                                                                         \
+    }                                                                                           \
+  }
+
+// WC / PC: frame width and LDS plane pitch as compile-time constants (0 = runtime)
+template <int FPI, int WC, int PC>
+__global__ void __launch_bounds__(256, 2)
+k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, const uint8_t* __restrict__ x,
+               const float* __restrict__ g, float* __restrict__ partial) {
+  extern __shared__ __align__(16) uint8_t c1_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int Wd = WC ? WC : W, Pd = PC ? PC : pitch;
+  const int HW = H * Wd, OHW = OH * OW, hw16 = HW >> 4;
+  const int ksteps = (OHW + 3) >> 2, blocks = (ksteps + C1_WU - 1) / C1_WU;
+  const int tap_off = (j >> 3) * Wd + (j & 7);
+  cv_f4 acc0[16], acc1[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { acc0[t] = cv_f4{0.f, 0.f, 0.f, 0.f}; acc1[t] = cv_f4{0.f, 0.f, 0.f, 0.f}; }
+  const int units = (N + FPI - 1) / FPI;
+  bool first = true;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int n0 = u * FPI;
+    const int frames = N - n0 < FPI ? N - n0 : FPI;
+    if (!first) __syncthreads();
+    first = false;
+    {
+      const int vecs = frames * C1_PLANES * hw16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(x + (int64_t)n0 * (C1_PLANES * HW));
+      for (int o0 = tid; o0 < vecs; o0 += 256 * C1_LD) {
+        uint4 v[C1_LD];
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; v[k] = s4[o < vecs ? o : vecs - 1]; }
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) {
+          const int o = o0 + k * 256;
+          if (o < vecs) { const int pl = o / hw16; *reinterpret_cast<uint4*>(c1_lds + pl * Pd + (o - pl * hw16) * 16) = v[k]; }
+        }
+      }
+    }
+    __syncthreads();
+    const int bend = frames * blocks;
+    int bb = wave;
+    if (bb >= bend) continue;
+    float2 ga[C1_WU], gb[C1_WU];
+    int pa[C1_WU], pb[C1_WU], fa, fb = 0;
+    C1_WRW_LOAD(bb, ga, pa, fa);
+    for (;;) {
+      const bool more_b = bb + 4 < bend;
+      if (more_b) C1_WRW_LOAD(bb + 4, gb, pb, fb);
+      __builtin_amdgcn_sched_barrier(0);            // next block's g loads in flight before this chain
+      C1_WRW_COMPUTE(ga, pa, fa);
+      if (!more_b) break;
+      bb += 8;
+      const bool more_a = bb < bend;
+      if (more_a) C1_WRW_LOAD(bb, ga, pa, fa);
+      __builtin_amdgcn_sched_barrier(0);
+      C1_WRW_COMPUTE(gb, pb, fb);
+      if (!more_a) break;
+    }
+  }
+  // workgroup partial: waves add up in LDS in wave order.  Accumulator tile (half m, tap
+  // group t): row (lane>>4)*4 + r <-> filter 2*row + m, column lane&15 <-> tap t*16 + column
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(c1_lds);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = (2 * (q * 4 + r)) * (C1_PLANES * C1_TAPS) + t * 16 + j, i1 = i0 + C1_PLANES * C1_TAPS;
+          red[i0] = (w ? red[i0] : 0.f) + acc0[t][r];
+          red[i1] = (w ? red[i1] : 0.f) + acc1[t][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* out = partial + (int64_t)blockIdx.x * C1_DW;
+  for (int k = tid; k < C1_DW; k += 256) out[k] = red[k];
+}
+#undef C1_WRW_LOAD
+#undef C1_WRW_COMPUTE
+
+// dw[f][c][kh][kw] (element strides so, sc, sh, sw) = scale * sum of the slabs in slab order
+__global__ void __launch_bounds__(256)
+k_conv1_wrw_reduce(const float* __restrict__ partial, int parts, float scale, float* __restrict__ dw, int64_t so, int64_t sc,
+                   int64_t sh, int64_t sw) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C1_DW) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = 0;
+  for (; p + 4 <= parts; p += 4) {
+    s0 += partial[(int64_t)p * C1_DW + t]; s1 += partial[(int64_t)(p + 1) * C1_DW + t];
+    s2 += partial[(int64_t)(p + 2) * C1_DW + t]; s3 += partial[(int64_t)(p + 3) * C1_DW + t];
+  }
+  for (; p < parts; ++p) s0 += partial[(int64_t)p * C1_DW + t];
+  const int f = t >> 8, tap = t & 255;
+  dw[f * so + (tap >> 6) * sc + ((tap >> 3) & 7) * sh + (tap & 7) * sw] = ((s0 + s1) + (s2 + s3)) * scale;
+}
+
 // LDS plane pitch in bytes: >= HW, a multiple of 16 B, and 16 (mod 64) in dwords
 static int c1_pitch(int HW) {
   int dw = (HW + 3) / 4;
@@ -248,4 +400,42 @@ extern "C" int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t*
                                  float* y, void* stream) {
   static const int flags = getenv("MIRL_CONV1_FLAGS") ? atoi(getenv("MIRL_CONV1_FLAGS")) : 0;
   return mirl_conv1_u8_fwd_ex(N, H, W, x, weight, ws_o, ws_c, ws_h, ws_w, bias, scale, wpk, y, flags, stream);
+}
+
+extern "C" int mirl_conv1_u8_wrw_scratch_floats(int64_t* out) {
+  if (!out) return mirl::fail(MIRL_ERR_ARG, "null out");
+  *out = (int64_t)512 * mirl::C1_DW;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
+                                 float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                                 void* stream) {
+  using namespace mirl;
+  if (N <= 0 || N >= (1LL << 30) || !x || !g || !scratch || !dw) return fail(MIRL_ERR_ARG, "bad conv1_u8_wrw arguments");
+  if (!mirl_conv1_u8_supported(C1_PLANES, H, W, C1_F, C1_K, C1_S)) return fail(MIRL_ERR_ARG, "conv1_u8_wrw: unsupported frame shape");
+  if (((uintptr_t)x % 16) || ((uintptr_t)g % 16) || ((uintptr_t)scratch % 16))
+    return fail(MIRL_ERR_ARG, "conv1_u8_wrw: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
+  const int fpi = (N >= 1024 && 2 * C1_PLANES * pitch <= 64 * 1024) ? 2 : 1;
+  const int64_t units = (N + fpi - 1) / fpi;
+  const unsigned grid = (unsigned)(units < 512 ? units : 512);
+  size_t lds = (size_t)fpi * C1_PLANES * pitch;
+  if (lds < (size_t)C1_DW * 4) lds = (size_t)C1_DW * 4;          // the workgroup's 32 KB partial is reduced there
+  const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
+  {
+    ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
+#define C1_WLAUNCH(FPI_, WC_, PC_) \
+  hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch)
+    const bool atari = W == 84 && pitch == 7232;
+    if (fpi == 2) { if (atari) C1_WLAUNCH(2, 84, 7232); else C1_WLAUNCH(2, 0, 0); }
+    else          { if (atari) C1_WLAUNCH(1, 84, 7232); else C1_WLAUNCH(1, 0, 0); }
+#undef C1_WLAUNCH
+    MIRL_LAUNCH_CHECK();
+  }
+  ProfScope ps("k_conv1_wrw_reduce", (double)grid * C1_DW * 4, st);
+  hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((C1_DW + 255) / 256), dim3(256), 0, st, scratch, (int)grid, scale, dw, ws_o, ws_c, ws_h, ws_w);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
 }

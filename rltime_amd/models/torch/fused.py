@@ -21,6 +21,7 @@ expressions; parity tests in tests/test_fused_gpu.py compare against those):
                      backward that never materialises g*x / g*emb / the mask
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -154,6 +155,9 @@ def conv_u8_supported(x, conv):
                                                    conv.kernel_size[0], conv.stride[0]))
 
 
+_U8_WRW = os.environ.get("MIRL_CONV1_WRW", "1") != "0"     # 0: MIOpen weight gradient on a converted copy
+
+
 class _ConvU8BiasReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, scale, stride):
@@ -178,8 +182,19 @@ class _ConvU8BiasReLU(torch.autograd.Function):
         grad = grad.contiguous(memory_format=torch.channels_last)
         g, db = relu_bwd_bias_rows(grad, y, y.shape[1])
         dw = None
-        if ctx.needs_input_grad[1]:
-            # the weight gradient is the only consumer of float pixels: convert here, for
+        if ctx.needs_input_grad[1] and _U8_WRW and x.shape[0]:
+            # weight gradient from the uint8 frames as well (csrc/conv_in.hip): no float pixels anywhere
+            L = _lib()
+            n, _, h, w = x.shape
+            need = C.c_int64()
+            L.check(L.lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
+            scratch = torch.empty(need.value, dtype=torch.float32, device=x.device)
+            dw = torch.empty_like(weight)
+            so, sc, sh, sw = dw.stride()
+            L.check(L.lib.mirl_conv1_u8_wrw(n, h, w, _p(x), _p(g), float(ctx.scale), _p(scratch), _p(dw), so, sc, sh, sw,
+                                            _stream()), "mirl_conv1_u8_wrw")
+        elif ctx.needs_input_grad[1]:
+            # library weight gradient: the only consumer of float pixels, converted here for
             # the rows that take part in the backward only
             xf = frames_to_f32_nhwc(x, ctx.scale)
             _, dw, _ = torch.ops.aten.convolution_backward(

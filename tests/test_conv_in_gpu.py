@@ -121,3 +121,52 @@ def test_unsupported_shapes_are_refused_and_the_module_falls_back():
     xs = torch.randint(0, 256, (3, 4, 42, 42), dtype=torch.uint8, device="cuda", generator=g)
     assert small.prepare_input(xs) is not None
     assert small(xs).shape == (3, 64, 3, 3)
+
+
+def _wrw(x, g, scale, like):
+    from rltime_amd._lib import lib, check
+    need = C.c_int64()
+    check(lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
+    scratch = torch.empty(need.value, device="cuda")
+    dw = torch.full_like(like, float("nan"))
+    n, _, h, w = x.shape
+    so, sc, sh, sw = dw.stride()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(lib.mirl_conv1_u8_wrw(n, h, w, p(x), p(g), scale, p(scratch), p(dw), so, sc, sh, sw,
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv1_wrw")
+    return dw
+
+
+def _wrw_reference(x, g, scale):
+    # d/dW of sum(conv2d(x*scale, W) * g) in float64
+    w = torch.zeros(32, 4, 8, 8, dtype=torch.float64, device="cuda", requires_grad=True)
+    (F.conv2d(x.double() * scale, w, None, 4) * g.double()).sum().backward()
+    return w.grad
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 84, 84), (2, 84, 84), (3, 36, 36), (2, 44, 52), (4, 12, 16), (3, 8, 8), (1, 100, 100)])
+def test_weight_gradient_integer_case_is_bit_exact(n, h, w):
+    g_ = torch.Generator(device="cuda").manual_seed(n * 100 + w)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g_)
+    oh, ow = (h - 8) // 4 + 1, (w - 8) // 4 + 1
+    g = torch.randint(-3, 4, (n, 32, oh, ow), device="cuda", generator=g_).float().contiguous(memory_format=torch.channels_last)
+    want = _wrw_reference(x, g, 1.0).float()          # |sums| <= n*oh*ow*255*3 < 2^24: exact in fp32 in any order
+    for like in (torch.empty(32, 4, 8, 8, device="cuda"),
+                 torch.empty(32, 4, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)):
+        got = _wrw(x, g, 1.0, like)
+        assert got.stride() == like.stride() and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,h,w", [(5, 84, 84), (1025, 84, 84), (2051, 84, 84), (1030, 44, 52)])
+def test_weight_gradient_within_tolerance_and_reproducible(n, h, w):
+    g_ = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g_)
+    oh, ow = (h - 8) // 4 + 1, (w - 8) // 4 + 1
+    g = (torch.randn(n, 32, oh, ow, device="cuda", generator=g_)
+         * (torch.rand(n, 32, oh, ow, device="cuda", generator=g_) < 0.5)).contiguous(memory_format=torch.channels_last)
+    like = torch.empty(32, 4, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    a, b = _wrw(x, g, 1.0 / 255.0, like), _wrw(x, g, 1.0 / 255.0, like)
+    assert torch.equal(a, b)                          # fixed partition and order: bit-identical reruns
+    want = _wrw_reference(x, g, 1.0 / 255.0)
+    err = float((a.double() - want).abs().max()) / float(want.abs().max())
+    assert err <= 1e-4, err

@@ -69,5 +69,37 @@ def main():
                               "hbm_GBps": round(n * (28224 + 51200) / ms / 1e6, 1)}), flush=True)
 
 
+def wrw_probe(sizes):
+    from rltime_amd.models.torch.fused import relu_bwd_bias_rows  # noqa: F401
+    p = lambda t: C.c_void_p(t.data_ptr())
+    need = C.c_int64()
+    check(lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
+    for n in sizes:
+        x = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, device="cuda")
+        g = torch.randn(n, 32, 20, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+        wt = torch.empty(32, 4, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+        dw = torch.empty_like(wt)
+        scratch = torch.empty(need.value, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        so, sc, sh, sw = dw.stride()
+        flop = n * 400 * 2.0 * 256 * 32
+        iters = 20
+
+        def lib_path():
+            xf = frames_to_f32_nhwc(x, 1 / 255.0)
+            return torch.ops.aten.convolution_backward(g, xf, wt, None, [4, 4], [0, 0], [1, 1], False, [0, 0], 1,
+                                                       [False, True, False])[1]
+        ms = timed(lib_path, iters)
+        print(json.dumps({"frames": n, "variant": "weight gradient: convert + MIOpen wrw", "ms": round(ms, 4),
+                          "tflops": round(flop / ms / 1e9, 1)}), flush=True)
+        ms = timed(lambda: check(lib.mirl_conv1_u8_wrw(n, 84, 84, p(x), p(g), 1 / 255.0, p(scratch), p(dw), so, sc, sh, sw, st)), iters)
+        print(json.dumps({"frames": n, "variant": "weight gradient: conv1_u8_wrw (+ slab reduce)", "ms": round(ms, 4),
+                          "tflops": round(flop / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(flop / ms / 1e9 / PEAK_TFLOPS, 3)}),
+              flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wrw":
+        wrw_probe([int(a) for a in sys.argv[2:]] or [22016])
+        sys.exit(0)
     main()
