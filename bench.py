@@ -491,8 +491,9 @@ def main():
                      "achieved_GBps": round(gbps, 1) if gbps else None,
                      "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4) if gbps else None,
                      "bound": "hbm" if by >= 1 << 20 else "latency"}
-            if row["name"] == "k_conv1_u8_fwd" and by > 0:
-                # the input conv layer is bound by the f32 MFMA pipe, not by HBM: price it in flop.
+            if row["name"] in ("k_conv1_u8_fwd", "k_conv1_u8_wrw") and by > 0:
+                # the input conv layer (forward and weight gradient) is bound by the f32 MFMA pipe, not by HBM:
+                # price it in flop.
                 # Per (4,84,84) frame: 28 224 B in + 20*20*32*4 B out; 20*20 positions x 2*256*32 flop
                 flop = by / (F + 400 * 32 * 4.0) * (400 * 2.0 * 256 * 32)
                 tf = flop / (avg_us * 1e-6) / 1e12
@@ -534,7 +535,7 @@ def main():
                 "how": "%d extra steps after the timed region with a HIP event pair around every librltime_hip launch "
                        "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
                        "latency-bound kernels (tree / sampling / bookkeeping) report us per call only; the input conv layer "
-                       "(k_conv1_u8_fwd) is priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
+                       "(k_conv1_u8_fwd / _wrw) is priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
                 "ms_per_step_with_events": prof_step_ms, "kernels": kernels} if kernels else None,
         }
         if args.config == "iqn_lstm":
