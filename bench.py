@@ -491,13 +491,21 @@ def main():
                      "achieved_GBps": round(gbps, 1) if gbps else None,
                      "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4) if gbps else None,
                      "bound": "hbm" if by >= 1 << 20 else "latency"}
-            if row["name"] in ("k_conv1_u8_fwd", "k_conv1_u8_wrw") and by > 0:
-                # the input conv layer (forward and weight gradient) is bound by the f32 MFMA pipe, not by HBM:
-                # price it in flop.
-                # Per (4,84,84) frame: 28 224 B in + 20*20*32*4 B out; 20*20 positions x 2*256*32 flop
-                flop = by / (F + 400 * 32 * 4.0) * (400 * 2.0 * 256 * 32)
+            if row["name"] in ("k_conv1_u8_fwd", "k_conv1_u8_wrw", "k_conv2_bwd_data") and by > 0:
+                # the hand-written conv kernels are bound by the f32 MFMA pipe, not by HBM: price them in flop.
+                # Input layer, per (4,84,84) frame: 28 224 B in + 20*20*32*4 B out (or g in); 20*20 positions x
+                # 2*256*32 flop.  Second layer's data gradient, per frame: 9*9*64*4 B of g in + 20*20*32*4 B out;
+                # 4 parity classes x 10*10 pixels x 2*256*32 flop ISSUED, of which 81*2*512*64 are the convolution's
+                # own (the rest multiplies the zero border that replaces edge masks).
+                if row["name"] == "k_conv2_bwd_data":
+                    frames = by / (81 * 64 * 4.0 + 400 * 32 * 4.0)
+                    flop, useful = frames * (400 * 2.0 * 256 * 32), frames * (81 * 2.0 * 512 * 64)
+                else:
+                    frames = by / (F + 400 * 32 * 4.0)
+                    flop = useful = frames * (400 * 2.0 * 256 * 32)
                 tf = flop / (avg_us * 1e-6) / 1e12
                 entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
+                              "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
             kernels.append(entry)
         out = {
@@ -535,7 +543,7 @@ def main():
                 "how": "%d extra steps after the timed region with a HIP event pair around every librltime_hip launch "
                        "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
                        "latency-bound kernels (tree / sampling / bookkeeping) report us per call only; the input conv layer "
-                       "(k_conv1_u8_fwd / _wrw) is priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
+                       "(k_conv1_u8_fwd / _wrw) and the second layer's data gradient (k_conv2_bwd_data) are priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
                 "ms_per_step_with_events": prof_step_ms, "kernels": kernels} if kernels else None,
         }
         if args.config == "iqn_lstm":

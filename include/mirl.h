@@ -376,6 +376,26 @@ int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const f
                       float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
                       void* stream);
 
+/* ---- data gradient of the second conv layer (csrc/conv_mid.hip).  For the backward
+ * autograd derives for `F.relu(conv(x))` (rltime/models/torch/modules/cnn.py:47-49) at
+ * Conv2d(32 -> 64, kernel 4, stride 2) (configs/models/cnn_*.json), input IH x IW =
+ * (2 OH + 2) x (2 OW + 2):
+ *   dx[n][ih][iw][c] = sum over f, kh, kw with ih = 2 oh + kh, iw = 2 ow + kw of
+ *                      g[n][oh][ow][f] * weight[f][c][kh][kw]
+ *   g       float [N][OH][OW][64]  (gradient w.r.t. the conv output after the ReLU mask; NHWC)
+ *   weight  float, logical [64][32][4][4], element strides ws_o, ws_c, ws_h, ws_w
+ *   dx      float [N][IH][IW][32]  (NHWC), every element written
+ *   wpk     scratch, 32768 floats (weights in MFMA operand order, rewritten by every call)
+ * f32 MFMA, four parity-class GEMMs with K = 256, N = 32; fp32 tolerance 1e-4
+ * (tests/test_conv_mid_gpu.py; bit-exact on integer-valued operands).
+ * mirl_conv2_bwd_data_supported() gates the shape; otherwise MIRL_ERR_ARG and the caller
+ * keeps the library path.                                                           */
+int mirl_conv2_bwd_data_supported(int32_t C, int32_t F, int32_t K, int32_t S, int32_t IH, int32_t IW,
+                                  int32_t OH, int32_t OW);
+int mirl_conv2_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight,
+                        int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx,
+                        void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

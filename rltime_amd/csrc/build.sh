@@ -12,7 +12,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 "$HIPCC" $FLAGS -c "$HERE/nnops.hip" -o "$HERE/nnops.o"
 "$HIPCC" $FLAGS -c "$HERE/acting.hip" -o "$HERE/acting.o"
 "$HIPCC" $FLAGS -c "$HERE/conv_in.hip" -o "$HERE/conv_in.o"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" "$HERE/lstm.o" "$HERE/convert.o" "$HERE/nnops.o" "$HERE/acting.o" "$HERE/conv_in.o" -o "$OUT"
+"$HIPCC" $FLAGS -c "$HERE/conv_mid.hip" -o "$HERE/conv_mid.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" "$HERE/lstm.o" "$HERE/convert.o" "$HERE/nnops.o" "$HERE/acting.o" "$HERE/conv_in.o" "$HERE/conv_mid.o" -o "$OUT"
 # plain-C consumer of the C-ABI (gcc, no Python / torch): proves the boundary is self-contained
 ROCM="${ROCM_PATH:-/opt/rocm}"
 gcc -O2 -std=c99 -D__HIP_PLATFORM_AMD__ -I "$ROCM/include" -I "$HERE/../../include" "$HERE/../../examples/mirl_demo.c" \

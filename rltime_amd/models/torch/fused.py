@@ -120,9 +120,36 @@ class _ConvBiasReLU(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(grad, y, 0.0)
             db = g.sum((0, 2, 3))
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx, dw, _ = torch.ops.aten.convolution_backward(
-            g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False])
-        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+        dx = None
+        if need_x and _CONV2_BWD and g.shape[0] and conv2_bwd_data_supported(x, weight, ctx.stride, g):
+            dx = conv2_bwd_data(g, weight, x)          # f32 MFMA, four parity-class GEMMs (csrc/conv_mid.hip)
+            need_x = False
+        lib_dx, dw, _ = torch.ops.aten.convolution_backward(
+            g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False]) \
+            if (need_x or need_w) else (None, None, None)
+        return (dx if dx is not None else lib_dx), dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+_CONV2_BWD = os.environ.get("MIRL_CONV2_BWD", "1") != "0"   # 0: MIOpen data gradient for the second conv layer
+
+
+def conv2_bwd_data_supported(x, weight, stride, g):
+    if not (g.is_contiguous(memory_format=torch.channels_last) and g.data_ptr() % 16 == 0
+            and tuple(stride) == (2, 2) and weight.shape[2] == weight.shape[3]):
+        return False
+    return bool(_lib().lib.mirl_conv2_bwd_data_supported(weight.shape[1], weight.shape[0], weight.shape[2], 2, x.shape[2],
+                                                         x.shape[3], g.shape[2], g.shape[3]))
+
+
+def conv2_bwd_data(g, weight, x_like):
+    """d loss / d input of conv2d(x, weight, stride 2) for the (32 -> 64, k 4) layer; g is NHWC."""
+    L = _lib()
+    dx = torch.empty_like(x_like, memory_format=torch.channels_last)
+    wpk = torch.empty(32768, dtype=torch.float32, device=g.device)
+    so, sc, sh, sw = weight.stride()
+    L.check(L.lib.mirl_conv2_bwd_data(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
+                                      _stream()), "mirl_conv2_bwd_data")
+    return dx
 
 
 def conv_bias_relu(x, conv):

@@ -1,0 +1,82 @@
+"""GPU: the second conv layer's data gradient on the f32 MFMA pipe (csrc/conv_mid.hip,
+mirl_conv2_bwd_data) against what autograd derives for conv2d(x, W, stride 2)
+(rltime/models/torch/modules/cnn.py:47-49 at Conv2d(32 -> 64, k 4, s 2)).  Integer-
+valued operands make every partial sum exact in fp32: indexing is checked bit-exactly;
+real operands to the north-star 1e-4."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _call(g, w):
+    from rltime_amd._lib import lib, check
+    n, _, oh, ow = g.shape
+    dx = torch.full((n, 32, 2 * oh + 2, 2 * ow + 2), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
+    wpk = torch.empty(32768, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    so, sc, sh, sw = w.stride()
+    check(lib.mirl_conv2_bwd_data(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), p(dx),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv2_bwd_data")
+    return dx
+
+
+def _reference(g, w):
+    n, _, oh, ow = g.shape
+    x = torch.zeros(n, 32, 2 * oh + 2, 2 * ow + 2, dtype=torch.float64, device="cuda", requires_grad=True)
+    (F.conv2d(x, w.double(), None, 2) * g.double()).sum().backward()
+    return x.grad
+
+
+@pytest.mark.parametrize("n,oh,ow", [(1, 9, 9), (2, 9, 9), (3, 9, 9), (1025, 9, 9), (2, 1, 1), (3, 4, 7), (5, 12, 3), (1027, 5, 6)])
+def test_integer_operands_are_bit_exact(n, oh, ow):
+    gen = torch.Generator(device="cuda").manual_seed(n * 31 + oh)
+    g = torch.randint(-3, 4, (n, 64, oh, ow), device="cuda", generator=gen).float().contiguous(memory_format=torch.channels_last)
+    w = torch.randint(-2, 3, (64, 32, 4, 4), device="cuda", generator=gen).float()
+    want = _reference(g, w).float()
+    got = _call(g, w)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
+    assert torch.equal(_call(g, w.contiguous(memory_format=torch.channels_last)), want)
+
+
+@pytest.mark.parametrize("n,oh,ow", [(4, 9, 9), (1031, 9, 9)])
+def test_real_operands_within_tolerance(n, oh, ow):
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    g = torch.randn(n, 64, oh, ow, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 32, 4, 4, device="cuda", generator=gen) * 0.05
+    want = _reference(g, w)
+    got = _call(g, w)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_layer_backward_uses_it_and_matches_the_library_path(monkeypatch):
+    import rltime_amd.models.torch.fused as fused
+    from rltime_amd._lib import lib
+    assert lib.mirl_conv2_bwd_data_supported(32, 64, 4, 2, 20, 20, 9, 9) == 1
+    for args in [(16, 64, 4, 2, 20, 20, 9, 9), (32, 32, 4, 2, 20, 20, 9, 9), (32, 64, 3, 1, 20, 20, 9, 9),
+                 (32, 64, 4, 2, 21, 20, 9, 9), (32, 64, 4, 2, 20, 20, 9, 8)]:
+        assert lib.mirl_conv2_bwd_data_supported(*args) == 0, args
+    torch.manual_seed(0)
+    conv = nn.Conv2d(32, 64, 4, 2).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(37, 32, 20, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    up = None
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(fused, "_CONV2_BWD", on)
+        conv.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = fused.conv_bias_relu(xi, conv)
+        up = torch.randn_like(y) if up is None else up
+        (y * up).sum().backward()
+        res.append((xi.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for a, b, what in zip(res[0], res[1], ("dx", "dW", "db")):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), what
+    # a 21-row input leaves a forward row uncovered: the library path must take it
+    x2 = torch.randn(3, 32, 21, 20, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    monkeypatch.setattr(fused, "_CONV2_BWD", True)
+    fused.conv_bias_relu(x2, conv).sum().backward()
+    assert x2.grad is not None and x2.grad.shape == x2.shape

@@ -98,7 +98,32 @@ def wrw_probe(sizes):
               flush=True)
 
 
+def bwd2_probe(sizes):
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for n in sizes:
+        g = torch.randn(n, 64, 9, 9, device="cuda").contiguous(memory_format=torch.channels_last)
+        x = torch.empty(n, 32, 20, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn(64, 32, 4, 4, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        wpk = torch.empty(32768, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        so, sc, sh, sw = wt.stride()
+        useful = n * 81 * 2.0 * 512 * 64
+        issued = n * 400 * 2.0 * 256 * 32
+        ms = timed(lambda: torch.ops.aten.convolution_backward(g, x, wt, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                               [True, False, False]), 20)
+        print(json.dumps({"frames": n, "variant": "conv2 data gradient: MIOpen", "ms": round(ms, 4),
+                          "useful_tflops": round(useful / ms / 1e9, 1)}), flush=True)
+        ms = timed(lambda: check(lib.mirl_conv2_bwd_data(n, 9, 9, p(g), p(wt), so, sc, sh, sw, p(wpk), p(dx), st)), 20)
+        print(json.dumps({"frames": n, "variant": "conv2 data gradient: conv2_bwd_data", "ms": round(ms, 4),
+                          "useful_tflops": round(useful / ms / 1e9, 1), "issued_tflops": round(issued / ms / 1e9, 1),
+                          "issued_frac_of_f32_mfma_peak": round(issued / ms / 1e9 / PEAK_TFLOPS, 3)}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd2":
+        bwd2_probe([int(a) for a in sys.argv[2:]] or [42496])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wrw":
         wrw_probe([int(a) for a in sys.argv[2:]] or [22016])
         sys.exit(0)
