@@ -121,6 +121,13 @@ def bwd2_probe(sizes):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "all":          # one process for a counter pass
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 42496
+        sys.argv = [sys.argv[0], str(n)]
+        main()
+        wrw_probe([n])
+        bwd2_probe([n])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bwd2":
         bwd2_probe([int(a) for a in sys.argv[2:]] or [42496])
         sys.exit(0)

@@ -20,6 +20,30 @@ for k in d["roofline_all"]["kernels"][:12]:
     print(k["kernel"], k["launches_per_step"], k["avg_us"], k["ms_per_step"], k["frac_of_hbm_peak"])
 PY
     ;;
+    cpmc)    R="$(pwd)"; export TMPDIR=/tmp
+             (cd /tmp && timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$R/$OUT/cpmc" -o c -- python "$R/tools/conv_in_probe.py" all 42496 > "$R/$OUT/cpmc_probe.jsonl" 2> "$R/$OUT/cpmc_probe.err"); echo "cpmc rc=$?"
+             python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections, json
+out = sys.argv[1]
+f = glob.glob(os.path.join(out, "cpmc", "**", "*counter_collection.csv"), recursive=True)
+if not f:
+    print("no counter csv"); print(open(os.path.join(out, "cpmc_probe.err")).read()[-1500:]); sys.exit(0)
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter(); dur = collections.Counter(); seen = set()
+for r in csv.DictReader(open(f[0])):
+    n = r["Kernel_Name"]
+    if not ("conv" in n.lower() or "igemm" in n): continue
+    n = n.split("(")[0][:70]
+    acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in seen:
+        seen.add(r["Dispatch_Id"]); calls[n] += 1; dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+res = {}
+for n, c in acc.items():
+    mf, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), c.get("GRBM_GUI_ACTIVE", 0)
+    res[n] = {"dispatches": calls[n], "avg_ms_under_counters": round(dur[n] / max(calls[n], 1), 4), "SQ_VALU_MFMA_BUSY_CYCLES": mf,
+              "SQ_BUSY_CYCLES": c.get("SQ_BUSY_CYCLES", 0), "GRBM_GUI_ACTIVE": gui, "mfma_busy_per_gui_active_cycle": round(mf / gui, 2) if gui else None}
+print(json.dumps(res, indent=1)); json.dump(res, open(os.path.join(out, "conv_mfma_util.json"), "w"), indent=1)
+PY
+             find "$OUT/cpmc" -name "*.csv" -size +1M -delete; find "$OUT/cpmc" -name "*.db" -delete;;
     probe)   timeout 300 python tools/convert_probe.py > "$OUT/convert_probe.jsonl" 2> "$OUT/convert_probe.err"; echo "probe rc=$?"; cat "$OUT/convert_probe.jsonl"; tail -3 "$OUT/convert_probe.err";;
     prof)    R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -60 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     gprobe)  for nt in 1 2; do PROBE_SIZE=1000000 PROBE_NT=$nt PROBE_ITERS=10 timeout 300 python tools/gather_probe.py >> "$OUT/gather_probe.jsonl" 2>> "$OUT/gather_probe.err"; done; echo "gprobe rc=$?"; cat "$OUT/gather_probe.jsonl";;
