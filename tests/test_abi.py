@@ -132,3 +132,27 @@ def test_mirror_classes_keep_the_reference_signatures():
             if any(p[0].startswith("**") for p in ref) and not any(p[0].startswith("**") for p in got):
                 problems.append("%s.%s: reference forwards **kwargs, mirror does not" % (key, m))
     assert not problems, "\n".join(problems)
+
+
+def test_conv_kernel_shape_gates_are_host_logic():
+    """The shape gates of the hand-written conv kernels (include/mirl.h:
+    mirl_conv1_u8_supported, mirl_conv2_bwd_data_supported) and the weight-gradient
+    scratch size are pure host code: callable without a GPU, and they refuse every
+    shape the kernels' register / LDS plans do not cover."""
+    import ctypes as C
+    from rltime_amd._lib import lib
+    assert lib.mirl_conv1_u8_supported(4, 84, 84, 32, 8, 4) == 1          # the Atari input layer
+    assert lib.mirl_conv1_u8_supported(4, 8, 8, 32, 8, 4) == 1            # a single output position
+    assert lib.mirl_conv1_u8_supported(4, 100, 100, 32, 8, 4) == 1        # 4 padded planes = 40 KB of LDS
+    for bad in [(1, 84, 84, 32, 8, 4), (4, 84, 84, 64, 8, 4), (4, 84, 84, 32, 4, 4), (4, 84, 84, 32, 8, 2),
+                (4, 84, 82, 32, 8, 4), (4, 7, 84, 32, 8, 4), (4, 42, 42, 32, 8, 4), (4, 128, 132, 32, 8, 4)]:
+        assert lib.mirl_conv1_u8_supported(*bad) == 0, bad
+    assert lib.mirl_conv2_bwd_data_supported(32, 64, 4, 2, 20, 20, 9, 9) == 1
+    assert lib.mirl_conv2_bwd_data_supported(32, 64, 4, 2, 4, 4, 1, 1) == 1
+    for bad in [(32, 64, 4, 2, 21, 20, 9, 9), (32, 64, 4, 2, 20, 20, 9, 10), (64, 64, 4, 2, 20, 20, 9, 9),
+                (32, 64, 3, 2, 20, 20, 9, 9), (32, 64, 4, 1, 20, 20, 9, 9), (32, 64, 4, 2, 2, 2, 0, 0),
+                (32, 64, 4, 2, 130, 130, 64, 64)]:
+        assert lib.mirl_conv2_bwd_data_supported(*bad) == 0, bad
+    need = C.c_int64()
+    assert lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)) == 0 and need.value == 512 * 32 * 4 * 8 * 8
+    assert lib.mirl_conv1_u8_wrw_scratch_floats(None) < 0                 # null out pointer: error code, no crash
