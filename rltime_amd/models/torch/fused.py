@@ -220,6 +220,8 @@ class _ConvU8BiasReLU(torch.autograd.Function):
             so, sc, sh, sw = dw.stride()
             L.check(L.lib.mirl_conv1_u8_wrw(n, h, w, _p(x), _p(g), float(ctx.scale), _p(scratch), _p(dw), so, sc, sh, sw,
                                             _stream()), "mirl_conv1_u8_wrw")
+        elif ctx.needs_input_grad[1] and not x.shape[0]:
+            dw = torch.zeros_like(weight)
         elif ctx.needs_input_grad[1]:
             # library weight gradient: the only consumer of float pixels, converted here for
             # the rows that take part in the backward only
