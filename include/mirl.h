@@ -355,7 +355,8 @@ int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const f
                       int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
                       float scale, float* wpk, float* y, void* stream);
 /* the same with explicit launch shape (tuning probe): flags bit 0 = cached output
- * stores (default non-temporal), bits 8-15 = frames per LDS fill (1 | 2, 0 = heuristic),
+ * stores (default non-temporal), bit 2 = conversions interleaved with the MFMA chain (default:
+ * hoisted in front of it), bits 8-15 = frames per LDS fill (1 | 2, 0 = heuristic),
  * bits 16-23 = workgroups sharing one frame's tiles (0 = heuristic).               */
 int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
                          int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
@@ -375,6 +376,11 @@ int mirl_conv1_u8_wrw_scratch_floats(int64_t* out);
 int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
                       float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
                       void* stream);
+/* the same with an explicit variant (tuning probe): flags bit 0 = byte->float conversions
+ * interleaved with the MFMAs instead of hoisted in front of each k-step's 32 MFMAs.      */
+int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
+                         float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                         int32_t flags, void* stream);
 
 /* ---- data gradient of the second conv layer (csrc/conv_mid.hip).  For the backward
  * autograd derives for `F.relu(conv(x))` (rltime/models/torch/modules/cnn.py:47-49) at

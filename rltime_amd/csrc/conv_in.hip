@@ -93,11 +93,14 @@ __device__ __forceinline__ float c1_byte(uint32_t v, int b) { return (float)((v 
 #define C1_TILE_COMPUTE(px_, f_, p_)                                                            \
   {                                                                                             \
     cv_f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};                                 \
+    float vv_[C1_TAPS];                                                                         \
+    /* tap s = kh*8 + kw: word kh*2 + (kw>>2), byte kw&3 */                                     \
+    _Pragma("unroll") for (int s = 0; s < C1_TAPS; ++s)                                         \
+      vv_[s] = (DBG & 1) ? __uint_as_float(px_[s >> 2] & 0x3fffffffu) : c1_byte(px_[s >> 2], s & 3); \
+    if (BULK) __builtin_amdgcn_sched_barrier(0);   /* all conversions before the chain */       \
     _Pragma("unroll") for (int s = 0; s < C1_TAPS; ++s) {                                       \
-      /* tap s = kh*8 + kw: word kh*2 + (kw>>2), byte kw&3 */                                   \
-      const float v = (DBG & 1) ? __uint_as_float(px_[s >> 2] & 0x3fffffffu) : c1_byte(px_[s >> 2], s & 3); \
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr0[s], v, a0, 0, 0, 0);                        \
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[s], v, a1, 0, 0, 0);                        \
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr0[s], vv_[s], a0, 0, 0, 0);                   \
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr1[s], vv_[s], a1, 0, 0, 0);                   \
     }                                                                                           \
     if ((DBG & 2) ? (a0.x == 12345.678f) : (p_ < OHW)) {                                        \
       cv_f4 o0 = a0 + b0, o1 = a1 + b1;                                                         \
@@ -109,7 +112,7 @@ __device__ __forceinline__ float c1_byte(uint32_t v, int b) { return (float)((v 
     }                                                                                           \
   }
 
-template <int FPI, int NTS, int DBG>
+template <int FPI, int NTS, int DBG, int BULK = 0>
 __global__ void __launch_bounds__(256, 2)
 k_conv1_u8_fwd(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, int split, const uint8_t* __restrict__ x,
                const float* __restrict__ wpk, const float* __restrict__ bias, float* __restrict__ y) {
@@ -221,16 +224,18 @@ constexpr int C1_DW = C1_F * C1_PLANES * C1_TAPS;   // 8192 weight-gradient elem
     const uint8_t* fl_ = c1_lds + f_ * C1_PLANES * Pd + tap_off;                                \
     _Pragma("unroll") for (int w = 0; w < C1_WU; ++w) {                                         \
       const uint8_t* pb_ = fl_ + po_[w];                                                        \
+      float vv_[16];                                                                            \
+      _Pragma("unroll") for (int t = 0; t < 16; ++t) vv_[t] = (float)pb_[(t >> 2) * Pd + (t & 3) * 2 * Wd]; \
+      if (BULK) __builtin_amdgcn_sched_barrier(0);   /* the k-step's 16 conversions before its 32 MFMAs */ \
       _Pragma("unroll") for (int t = 0; t < 16; ++t) {                                          \
-        const float v = (float)pb_[(t >> 2) * Pd + (t & 3) * 2 * Wd];                           \
-        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].x, v, acc0[t], 0, 0, 0);          \
-        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].y, v, acc1[t], 0, 0, 0);          \
+        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].x, vv_[t], acc0[t], 0, 0, 0);     \
+        acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv_[w].y, vv_[t], acc1[t], 0, 0, 0);     \
       }                                                                                         \
     }                                                                                           \
   }
 
 // WC / PC: frame width and LDS plane pitch as compile-time constants (0 = runtime)
-template <int FPI, int WC, int PC>
+template <int FPI, int WC, int PC, int BULK = 0>
 __global__ void __launch_bounds__(256, 2)
 k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, const uint8_t* __restrict__ x,
                const float* __restrict__ g, float* __restrict__ partial) {
@@ -343,7 +348,8 @@ extern "C" int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t 
   return C1_PLANES * c1_pitch(H * W) <= 64 * 1024 ? 1 : 0;
 }
 
-// flags: bit 0 = plain (cached) output stores instead of non-temporal ones; bits 8.. =
+// flags: bit 0 = plain (cached) output stores instead of non-temporal ones; bit 2 = byte->float
+// conversions interleaved with the MFMA chain instead of hoisted in front of it; bits 8.. =
 // frames per LDS fill override (1 or 2), bits 16.. = split override; bits 24-26 =
 // timing-experiment variants (see the kernel).
 extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight, int64_t ws_o,
@@ -385,6 +391,11 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
       case 4: C1_LAUNCH(2, 1, 4); break;  case 7: C1_LAUNCH(2, 1, 7); break;
       default: return fail(MIRL_ERR_ARG, "conv1_u8_fwd: unknown debug variant");
     }
+  } else if (fpi == 2 && nts && !(flags & 4)) {
+    // all 64 byte->float conversions of a tile in front of its MFMA chain: 2.20 vs 2.41 ms per
+    // 41 472 frames (conversions interleaved with the chain delay MFMA issue; 250 VGPRs, still
+    // 2 waves per SIMD).  Bit 2 of flags keeps the interleaved variant for the probe.
+    hipLaunchKernelGGL((k_conv1_u8_fwd<2, 1, 0, 1>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, split, x, wpk, bias, y);
   } else if (fpi == 2) {
     if (nts) C1_LAUNCH(2, 1, 0); else C1_LAUNCH(2, 0, 0);
   } else {
@@ -408,9 +419,10 @@ extern "C" int mirl_conv1_u8_wrw_scratch_floats(int64_t* out) {
   return MIRL_OK;
 }
 
-extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
-                                 float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
-                                 void* stream) {
+// flags bit 0: conversions interleaved with the MFMAs (the first version) instead of hoisted per k-step
+extern "C" int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
+                                    float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                                    int32_t flags, void* stream) {
   using namespace mirl;
   if (N <= 0 || N >= (1LL << 30) || !x || !g || !scratch || !dw) return fail(MIRL_ERR_ARG, "bad conv1_u8_wrw arguments");
   if (!mirl_conv1_u8_supported(C1_PLANES, H, W, C1_F, C1_K, C1_S)) return fail(MIRL_ERR_ARG, "conv1_u8_wrw: unsupported frame shape");
@@ -429,8 +441,10 @@ extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t*
 #define C1_WLAUNCH(FPI_, WC_, PC_) \
   hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch)
     const bool atari = W == 84 && pitch == 7232;
-    if (fpi == 2) { if (atari) C1_WLAUNCH(2, 84, 7232); else C1_WLAUNCH(2, 0, 0); }
-    else          { if (atari) C1_WLAUNCH(1, 84, 7232); else C1_WLAUNCH(1, 0, 0); }
+    if (fpi == 2 && atari && !(flags & 1))
+      hipLaunchKernelGGL((k_conv1_u8_wrw<2, 84, 7232, 1>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch);
+    else if (fpi == 2) { if (atari) C1_WLAUNCH(2, 84, 7232); else C1_WLAUNCH(2, 0, 0); }
+    else               { if (atari) C1_WLAUNCH(1, 84, 7232); else C1_WLAUNCH(1, 0, 0); }
 #undef C1_WLAUNCH
     MIRL_LAUNCH_CHECK();
   }
@@ -438,4 +452,11 @@ extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t*
   hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((C1_DW + 255) / 256), dim3(256), 0, st, scratch, (int)grid, scale, dw, ws_o, ws_c, ws_h, ws_w);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
+}
+
+extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
+                                 float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                                 void* stream) {
+  static const int flags = getenv("MIRL_CONV1_WRW_FLAGS") ? atoi(getenv("MIRL_CONV1_WRW_FLAGS")) : 1;
+  return mirl_conv1_u8_wrw_ex(N, H, W, x, g, scale, scratch, dw, ws_o, ws_c, ws_h, ws_w, flags, stream);
 }

@@ -60,6 +60,8 @@ def test_launch_shapes_agree_bitwise(n, h, w):
             for cached in (0, 1):
                 got = _call(x, wt, b, 1.0 / 255.0, flags=cached | (fpi << 8) | (split << 16))
                 assert torch.equal(got, base), (fpi, split, cached)
+    # conversions hoisted in front of the MFMA chain (flag bit 2): same sums in the same order
+    assert torch.equal(_call(x, wt, b, 1.0 / 255.0, flags=4 | (2 << 8)), base)
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 84, 84), (257, 84, 84), (2050, 84, 84), (5, 44, 52)])
@@ -123,7 +125,7 @@ def test_unsupported_shapes_are_refused_and_the_module_falls_back():
     assert small(xs).shape == (3, 64, 3, 3)
 
 
-def _wrw(x, g, scale, like):
+def _wrw(x, g, scale, like, flags=None):
     from rltime_amd._lib import lib, check
     need = C.c_int64()
     check(lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
@@ -132,8 +134,11 @@ def _wrw(x, g, scale, like):
     n, _, h, w = x.shape
     so, sc, sh, sw = dw.stride()
     p = lambda t: C.c_void_p(t.data_ptr())
-    check(lib.mirl_conv1_u8_wrw(n, h, w, p(x), p(g), scale, p(scratch), p(dw), so, sc, sh, sw,
-                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv1_wrw")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if flags is None:
+        check(lib.mirl_conv1_u8_wrw(n, h, w, p(x), p(g), scale, p(scratch), p(dw), so, sc, sh, sw, st), "conv1_wrw")
+    else:
+        check(lib.mirl_conv1_u8_wrw_ex(n, h, w, p(x), p(g), scale, p(scratch), p(dw), so, sc, sh, sw, flags, st), "conv1_wrw_ex")
     return dw
 
 
@@ -167,6 +172,8 @@ def test_weight_gradient_within_tolerance_and_reproducible(n, h, w):
     like = torch.empty(32, 4, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
     a, b = _wrw(x, g, 1.0 / 255.0, like), _wrw(x, g, 1.0 / 255.0, like)
     assert torch.equal(a, b)                          # fixed partition and order: bit-identical reruns
+    # both instruction schedules (conversions hoisted / interleaved) do the same sums in the same order
+    assert torch.equal(_wrw(x, g, 1.0 / 255.0, like, flags=0), a) and torch.equal(_wrw(x, g, 1.0 / 255.0, like, flags=1), a)
     want = _wrw_reference(x, g, 1.0 / 255.0)
     err = float((a.double() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-4, err

@@ -49,7 +49,8 @@ def main():
         print(json.dumps({"frames": n, "variant": "convert + MIOpen conv + bias/ReLU pass", "ms": round(ms, 4),
                           "ms_without_convert": round(ms_conv, 4), "tflops": round(flop / ms / 1e9, 1)}), flush=True)
         if n > 1000:
-            variants = [("default", None), ("fpi2 nt", 2 << 8), ("fpi1 nt", 1 << 8), ("fpi2 cached", (2 << 8) | 1)]
+            variants = [("default", None), ("fpi2 nt", 2 << 8), ("fpi1 nt", 1 << 8), ("fpi2 cached", (2 << 8) | 1),
+                        ("fpi2 nt conversions-before-chain", (2 << 8) | 4)]
             # timing experiments (results are NOT the convolution): what each part costs
             for dbg, what in ((1, "no u8->f32 conversion"), (2, "no output stores"), (4, "no LDS refill"), (7, "MFMA chain only")):
                 variants.append(("fpi2 nt EXPERIMENT " + what, (2 << 8) | (dbg << 24)))
@@ -92,10 +93,12 @@ def wrw_probe(sizes):
         ms = timed(lib_path, iters)
         print(json.dumps({"frames": n, "variant": "weight gradient: convert + MIOpen wrw", "ms": round(ms, 4),
                           "tflops": round(flop / ms / 1e9, 1)}), flush=True)
-        ms = timed(lambda: check(lib.mirl_conv1_u8_wrw(n, 84, 84, p(x), p(g), 1 / 255.0, p(scratch), p(dw), so, sc, sh, sw, st)), iters)
-        print(json.dumps({"frames": n, "variant": "weight gradient: conv1_u8_wrw (+ slab reduce)", "ms": round(ms, 4),
-                          "tflops": round(flop / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(flop / ms / 1e9 / PEAK_TFLOPS, 3)}),
-              flush=True)
+        for name, fl in (("conversions hoisted per k-step", 0), ("conversions interleaved", 1)):
+            ms = timed(lambda fl=fl: check(lib.mirl_conv1_u8_wrw_ex(n, 84, 84, p(x), p(g), 1 / 255.0, p(scratch), p(dw), so, sc, sh,
+                                                                    sw, fl, st)), iters)
+            print(json.dumps({"frames": n, "variant": "weight gradient: conv1_u8_wrw (+ slab reduce), " + name, "ms": round(ms, 4),
+                              "tflops": round(flop / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(flop / ms / 1e9 / PEAK_TFLOPS, 3)}),
+                  flush=True)
 
 
 def bwd2_probe(sizes):
