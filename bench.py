@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the rltime Q-learning hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          # N=1
+    python bench.py --gpus N --steps K --warmup W          # any N: starts its own N ranks when not under torchrun
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python bench.py --config {iqn_lstm,rainbow_iqn,dqn_uniform} [--scaling {weak,strong}]
+    python bench.py --config {iqn_lstm,rainbow_iqn,dqn_uniform} [--scaling {both,strong,weak}]
+    python bench.py --gpus N --dry-launch                  # print the launch command only
 
 Workloads (`--config`, default = the one BASELINE.json's
 metric is quoted on):
@@ -24,11 +25,14 @@ One *step* = one pass of THE LOOP body of the reference
   -> forward/backward -> grad all-reduce (N>1) -> clip + Adam -> update_losses.
 Nothing is skipped inside the timed region.
 
-Multi-GPU (`--scaling`): every rank owns a replay shard (its envs).  weak (default,
-what `scaling` reports): each rank trains the configured batch on its own full-size
-shard; strong: the configured batch / envs / replay size are
-whole-job values split over the ranks.  Gradients are all-reduced, importance
-weights globalised (rltime_amd/parallel.py).
+Multi-GPU (`--scaling`): every rank owns a replay shard (its envs).  The headline
+at N>1 is STRONG scaling: the configured batch (global B=512),
+envs (256) and replay size (1M) are whole-job values split over the ranks, so
+learner steps/s is the same job at every N.  The default `both` then runs the WEAK
+mode too (every rank trains the configured batch on its own full-size shard) and
+reports it as the `weak` sub-record of the same line.  Gradients are all-reduced
+(RCCL; the `rccl` record says how many ranks the collective saw and what it cost
+per step), importance weights globalised (rltime_amd/parallel.py).
 
 Prints ONE JSON line (rank 0).  `value` comes from the wall time of exactly K steps
 between barriers (max over ranks); `step_ms` holds median / p10 / p90 of the K
@@ -77,7 +81,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="iqn_lstm", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="both", choices=["both", "strong", "weak"],
+                    help="N>1: both = strong-scaling headline + a `weak` sub-record in the same line")
+    ap.add_argument("--dry-launch", action="store_true", help="print the N-rank launch command as JSON and exit")
+    ap.add_argument("--master-port", type=int, default=None)
     ap.add_argument("--mbatch", type=int, default=None, help="override mbatch_size (whole job under --scaling strong)")
     ap.add_argument("--nstep-train", type=int, default=None)
     ap.add_argument("--burn-in", type=int, default=None)
@@ -88,7 +95,7 @@ def parse():
     ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen benchmarks its solvers "
                     "per conv shape instead of taking the immediate-mode pick (experiment)")
@@ -99,7 +106,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_config(args, rank, world):
+def build_config(args, rank, world, scaling):
     from rltime_amd.general.config import load_config
     from rltime_amd.general.utils import deep_dictionary_update
     from rltime_amd.parallel import shard_config
@@ -118,7 +125,7 @@ def build_config(args, rank, world):
         targs["history_mode"]["args"]["frame_stack_dedup"] = True
         config.setdefault("env_args", {})["frame_stack"] = True
     deep_dictionary_update(config, {"acting": {"actor_envs": args.envs or spec["envs"]}, "training": {"args": targs}})
-    return shard_config(config, rank, world, args.scaling)
+    return shard_config(config, rank, world, scaling)
 
 
 def build_trainer(config, device, use_graph, data_parallel):
@@ -303,7 +310,8 @@ def cpu_baseline(args, seconds):
     learner_step, ingest_rate = cpu.learner_step, cpu.ingest_rate
 
     def leg(threads, plan, budget):
-        """plan: [(B, max steps)] -> seconds per B=512 learner step from the largest B that ran."""
+        """plan: [(B, runs)] -> seconds per B=512 learner step from the largest B that ran
+        (the MEDIAN of its runs), {B: (min, median, runs)}, seconds spent."""
         torch.set_num_threads(threads)
         per_b, spent = {}, 0.0
         for Bs, reps in plan:
@@ -316,26 +324,26 @@ def cpu_baseline(args, seconds):
                 times.append(time.time() - t1)
                 spent += times[-1]
             if times:
-                per_b[Bs] = (min(times), len(times))
+                per_b[Bs] = (min(times), float(np.median(times)), len(times))
             if spent > budget:
                 break
         Bmax = max(per_b)
-        return per_b[Bmax][0] * (B_full / Bmax), per_b, spent
+        return per_b[Bmax][1] * (B_full / Bmax), per_b, spent
 
     learner_step(2)                                           # untimed warm-up (allocator, MKL)
-    one_s, one_b, one_spent = leg(1, [(4, 1), (16, 1)], seconds * 0.5)
+    one_s, one_b, one_spent = leg(1, [(4, 3), (16, 3)], seconds * 0.7)
     # "all cores": torch intra-op threads capped at 32 — the LSTMCell time loop is a chain of
     # small GEMMs; with one thread per logical core of a 256-core host the same step measured
-    # 33x SLOWER than 1 thread (profiles/README.md, round 2).  B=4 first; B=16 only if the
+    # 33x SLOWER than 1 thread (profiles/README.md, round 2).  B=4 first; B=32 only if the
     # threads actually help, so a pathological setting cannot eat minutes of the budget.
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = nproc
     many = max(2, min(usable, 32))
-    all_s, all_b, all_spent = leg(many, [(4, 1)], seconds * 0.2)
-    if all_b[4][0] < one_b[4][0]:
-        s2, b2, sp2 = leg(many, [(32, 1)], seconds * 0.3)
+    all_s, all_b, all_spent = leg(many, [(4, 3)], seconds * 0.1)
+    if all_b[4][1] < one_b[4][1]:
+        s2, b2, sp2 = leg(many, [(32, 3)], seconds * 0.4)
         all_s, all_spent = s2, all_spent + sp2
         all_b.update(b2)
     torch.set_num_threads(1)
@@ -343,39 +351,82 @@ def cpu_baseline(args, seconds):
     acted_per_step = B_full * T / 4                        # train_frequency=4
     extra = acted_per_step / ingest_rate + acted_per_step / act_rate
     P, n = CpuPath.P, CpuPath.n
-    fmt = lambda d: ", ".join("B=%d: %.2f s/step (%d run%s)" % (b, t, k, "" if k == 1 else "s") for b, (t, k) in sorted(d.items()))  # noqa: E731
+    fmt = lambda d: ", ".join("B=%d: median %.2f / min %.2f s/step (%d run%s)" % (b, md, mn, k, "" if k == 1 else "s")  # noqa: E731
+                              for b, (mn, md, k) in sorted(d.items()))
     return {
         "value": B_full * T / (one_s + extra), "unit": "transitions/s", "cores": 1, "kind": "port",
         "learner_steps_per_sec": 1.0 / (one_s + extra),
         "host_nproc": nproc,
+        "runs": {str(b): {"min_s": mn, "median_s": md, "runs": k} for b, (mn, md, k) in sorted(one_b.items())},
         "all_cores": {"value": B_full * T / (all_s + extra), "unit": "transitions/s", "cores": many, "usable_cores": usable,
                       "learner_steps_per_sec": 1.0 / (all_s + extra),
                       "sample": "same oracle path with torch.set_num_threads(%d): %s, scaled x%d to B=512; acting/ingest shares as in the 1-thread leg"
                                 % (many, fmt(all_b), B_full // max(all_b))},
         "sample": "oracle (reference algorithm restated, config D: T=80, burn-in 40, n=2, torch-CPU fp32, 1 thread like the "
-                  "reference's torch.set_num_threads(1)): %s; the largest B scaled linearly x%d to B=512 (%.1f s of CPU work); "
+                  "reference's torch.set_num_threads(1)): %s; the largest B's MEDIAN scaled linearly x%d to B=512 (%.1f s of CPU work); "
                   "+ acting %.0f and ingest %.0f transitions/s for the step's %d acted transitions; host has %d logical cores; "
                   "oracle / reference time ratio at identical inputs: BASELINE.md (tools/ref_vs_oracle_cpu.py)"
                   % (fmt(one_b), B_full // max(one_b), one_spent + all_spent, act_rate, ingest_rate, acted_per_step, nproc)}
 
 
-def main():
-    args = parse()
-    from rltime_amd import parallel
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    import torch.distributed as dist
-    rank, world, local, dp = parallel.init_from_env(device=device)
+def launch_argv(argv, n, port):
+    """The command the driver would use for N ranks on one node (one process per
+    GPU over RCCL), built around THIS script and its own arguments."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks
+    ourselves.  Rank 0's JSON line passes through on stdout."""
+    import subprocess
+    cmd = launch_argv([a for a in argv if a != "--dry-launch"], args.gpus, args.master_port or free_port())
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def copy_peak(device, stream_ptr_fn):
+    """Measured HBM copy rate of this box (read + write bytes of one mirl_copy_bytes
+    pass over the frame gather's byte count), next to the spec peak."""
+    import ctypes as C
+    from rltime_amd._lib import lib, check
+    n = 122 * 512 * 28224
+    a = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 256)
+    b = torch.empty_like(a)
+    f = lambda: check(lib.mirl_copy_bytes(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, stream_ptr_fn()))  # noqa: E731
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2.0 * n / ms / 1e6
+
+
+def run_mode(args, scaling, rank, world, device, dp, want_tables):
+    """Build the trainer for one scaling mode, pre-fill its replay shard, run W
+    warm-up + K timed steps between barriers.  Returns the raw measurements."""
+    import gc
+    import torch.distributed as dist
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
-    if args.miopen_find:
-        torch.backends.cudnn.benchmark = True
-    spec = CONFIGS[args.config]
-    config = build_config(args, rank, world)
+    config = build_config(args, rank, world, scaling)
     targs = config["training"]["args"]
     trainer = build_trainer(config, device, use_graph=not args.no_acting_graph, data_parallel=dp)
     hist = trainer.history_buffer
@@ -421,6 +472,8 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.timing = []
     if world > 1:
         dist.barrier()
     hist.profile(True)
@@ -443,10 +496,21 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    rccl = None
+    if dp is not None:
+        pairs, dp.timing = dp.timing, None
+        ar_ms = [a.elapsed_time(b) for a, b in pairs]
+        rccl = {"backend": dist.get_backend(), "ranks_seen": dp.ranks_seen(device), "world_size": world,
+                "allreduce_calls_per_step": len(ar_ms) / max(args.steps, 1),
+                "allreduce_ms_per_step": float(np.sum(ar_ms)) / max(args.steps, 1) if ar_ms else None,
+                "allreduce_ms_median": float(np.median(ar_ms)) if ar_ms else None,
+                "bucket_bytes": dp.bucket_bytes,
+                "source": "HIP events around the gradient all-reduce on rank 0's stream inside the timed region; "
+                          "ranks_seen = all-reduced sum of one int per rank over the same process group"}
 
     # ---- per-kernel pass (untimed): HIP events around every librltime_hip launch
     table, prof_step_ms = [], None
-    if args.profile_steps > 0:
+    if want_tables and args.profile_steps > 0:
         from rltime_amd import _lib
         _lib.check(_lib.lib.mirl_profile_reset())
         _lib.check(_lib.lib.mirl_profile_set(2))
@@ -459,18 +523,83 @@ def main():
         _lib.check(_lib.lib.mirl_profile_set(0))
         table = _lib.profile_table()
 
+    T, P, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs["mbatch_size"]
+    n = targs.get("nstep_target") or targs["nstep_train"]
+    res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
+               table=table, prof_step_ms=prof_step_ms, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
+               hist_stats=hist_stats, fill_s=fill_s, rccl=rccl)
+    trainer.actors = real_actors
+    hist.close()
+    if hasattr(real_actors, "_graphed"):
+        real_actors._graphed = None
+    del trainer, hist, real_actors, feeder, probe
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def summary(res, world, steps):
+    """Throughput figures of one run_mode result."""
+    B, T, dt = res["B"], res["T"], res["dt"]
+    sm = res["step_ms"]
+    return {"value": world * B * T * steps / dt, "unit": "transitions/s", "learner_steps_per_sec": steps / dt,
+            "ms_per_step": dt / steps * 1e3,
+            "step_ms": {"median": float(np.median(sm)), "p10": float(np.percentile(sm, 10)),
+                        "p90": float(np.percentile(sm, 90)), "source": "HIP events at step boundaries, rank 0"},
+            "mbatch_per_gpu": B, "global_mbatch": B * world, "envs_per_gpu": res["envs"],
+            "replay_transitions_per_gpu": res["hist_stats"]["total_items"],
+            "acted_transitions_per_step_per_gpu": res["acted"] / steps}
+
+
+def main():
+    args = parse()
+    launched = "WORLD_SIZE" in os.environ
+    force = bool(os.environ.get("BENCH_FORCE_DIST"))
+    if not launched and (args.gpus > 1 or force or args.dry_launch):
+        sys.exit(self_launch(args, sys.argv[1:]))
+    from rltime_amd import parallel
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start it as `python bench.py --gpus N` "
+                 "(self-launching) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    rank, world, local, dp = parallel.init_from_env(device=device)
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
+    spec = CONFIGS[args.config]
+
+    # N = 1: both modes are the same job.  N > 1: the headline is STRONG scaling (SURVEY 8d
+    # config 5: the configured batch / envs / replay are whole-job values split over the ranks,
+    # so learner steps/s is comparable across N); the weak run (every rank keeps the full
+    # configured batch on its own full-size shard) rides along as the `weak` sub-record.
+    modes = [args.scaling] if args.scaling != "both" else (["strong", "weak"] if world > 1 else ["strong"])
+    runs = [run_mode(args, m, rank, world, device, dp, want_tables=(i == 0)) for i, m in enumerate(modes)]
+    res = runs[0]
+    measured_peak = None
     if rank == 0:
-        T, P, n, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs.get("nstep_target") or targs["nstep_train"], targs["mbatch_size"]
-        L = T + P
+        try:
+            import ctypes as C
+            measured_peak = copy_peak(device, lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        except Exception as e:
+            measured_peak = None
+            print("copy peak pass failed: %r" % (e,), file=sys.stderr)
+
+    if rank == 0:
+        T, P, n, B = res["T"], res["P"], res["n"], res["B"]
+        per, hist_stats, envs = res["per"], res["hist_stats"], res["envs"]
+        table, launches, gather_ms = res["table"], res["launches"], res["gather_ms"]
         F = 4 * 84 * 84
-        rows = hist._rows
+        rows = res["rows"]
         algo_bytes = 2.0 * rows * B * F
         if args.frame_dedup:           # every stack written once, every distinct plane of a window read once
             algo_bytes = rows * B * F + B * (rows + 3) * (F / 4.0)
         avg_ms = gather_ms / max(launches, 1)
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
         traffic, traffic_src = None, None
-        if args.config == "iqn_lstm" and os.path.isfile(args.pmc_traffic):
+        if args.config == "iqn_lstm" and world == 1 and os.path.isfile(args.pmc_traffic):
             try:
                 traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/gather_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) over " \
@@ -508,35 +637,39 @@ def main():
                               "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
             kernels.append(entry)
+        head = summary(res, world, args.steps)
+        mode_text = {"strong": "strong scaling: the configured batch (global B=%d), envs and replay size are whole-job values "
+                               "split evenly over the ranks" % (B * world),
+                     "weak": "weak scaling: every rank keeps the configured batch, envs and replay size"}
         out = {
             "metric": spec["metric"],
-            "value": world * B * T * args.steps / dt,
-            "unit": "transitions/s",
-            "learner_steps_per_sec": args.steps / dt,
+            "value": head["value"], "unit": "transitions/s",
+            "learner_steps_per_sec": head["learner_steps_per_sec"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "step_ms": {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
-                        "p90": float(np.percentile(step_ms, 90)), "source": "HIP events at step boundaries, rank 0"},
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": head["ms_per_step"], "step_ms": head["step_ms"],
+            "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None,
             "dtype": "f32" if args.amp == "none" else "bf16(network autocast)+f32(hot path)",
             "data": "synthetic",
             "config": {
-                "workload": spec["workload"] + (" [%s scaling: %s]" % (
-                    args.scaling, "global batch split over ranks" if args.scaling == "strong" else "per-rank batch fixed")),
+                "workload": spec["workload"] + " [%s]" % mode_text[res["scaling"]],
                 "mbatch_per_gpu": B, "global_mbatch": B * world, "nstep_train": T, "burn_in": P, "nstep_target": n,
                 "frame": "(4,84,84) u8" + (" stack-consistent, stored de-duplicated (one 84x84 plane per transition)" if args.frame_dedup else ""),
                 "replay_transitions_per_gpu": hist_stats["total_items"],
                 "active_sequences_per_gpu": hist_stats["active_sequences"],
                 "tree_capacity": hist_stats["tree_capacity"] if per else None,
-                "envs_per_gpu": envs, "acted_transitions_per_step_per_gpu": acted / args.steps,
+                "envs_per_gpu": envs, "acted_transitions_per_step_per_gpu": res["acted"] / args.steps,
                 "acting_policy_forward_in_step": not args.no_acting,
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world,
-                "replay_fill_seconds": round(fill_s, 2)},
+                "replay_fill_seconds": round(res["fill_s"], 2)},
             "roofline": {
                 "kernel": "k_gather_rows_dedup (frames)" if args.frame_dedup else "k_gather_rows (frames)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "measured_copy_peak_GBps": measured_peak,
+                "frac_of_measured_copy_peak": (achieved / measured_peak) if (achieved and measured_peak) else None,
+                "measured_copy_peak_how": "read + written bytes of mirl_copy_bytes (16 B/lane device copy) over the gather's "
+                                          "3.5 GB on this box, after the timed region; `peak` is the HBM3E spec figure",
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches": launches,
                 "traffic": traffic, "traffic_source": traffic_src},
             "roofline_all": {
@@ -544,8 +677,16 @@ def main():
                        "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
                        "latency-bound kernels (tree / sampling / bookkeeping) report us per call only; the input conv layer "
                        "(k_conv1_u8_fwd / _wrw) and the second layer's data gradient (k_conv2_bwd_data) are priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
-                "ms_per_step_with_events": prof_step_ms, "kernels": kernels} if kernels else None,
+                "ms_per_step_with_events": res["prof_step_ms"], "kernels": kernels} if kernels else None,
         }
+        if res["rccl"] is not None:
+            out["rccl"] = res["rccl"]
+        for other in runs[1:]:
+            sub = summary(other, world, args.steps)
+            sub["workload"] = mode_text[other["scaling"]]
+            if other["rccl"] is not None:
+                sub["rccl"] = other["rccl"]
+            out[other["scaling"]] = sub
         if args.config == "iqn_lstm":
             out["config"]["lstm_state"] = "2x512 f32 per transition"
         if world == 1 and not args.no_cpu_baseline and args.config == "iqn_lstm":
@@ -555,9 +696,9 @@ def main():
             except Exception as e:            # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    trainer.actors = real_actors
-    hist.close()
     if dp is not None:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

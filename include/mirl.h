@@ -307,7 +307,7 @@ int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, co
                        float* h_out, float* c_out, float* h_next, float* c_next, void* stream);
 /* One whole LSTM step in one launch: gates [B][4H] holds the input projection (+ biases)
  * on entry; the recurrent contribution h_in [B][H] x w_hh [4H][H]^T is accumulated on
- * f32 MFMA (v_mfma_f32_32x32x2_f32, exact f32) and the cell applied in the epilogue —
+ * f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32) and the cell applied in the epilogue —
  * same outputs as mirl_lstm_cell_fwd after `gates += h_in @ w_hh^T`.  B, H multiples
  * of 32.                                                                            */
 int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates,

@@ -34,8 +34,9 @@
 //   epilogue      accumulator rows are 4 consecutive filters: + bias, ReLU, two
 //                 16 B stores per lane; a wave writes 2 KiB of contiguous NHWC rows.
 //
-// Only the forward needs this shape; the weight gradient keeps MIOpen (the input
-// needs no gradient), see rltime_amd/models/torch/fused.py:_ConvU8BiasReLU.
+// The layer's input needs no gradient; its weight gradient (k_conv1_u8_wrw, further
+// down in this file) reads the same uint8 frames.  Autograd wiring:
+// rltime_amd/models/torch/fused.py:_ConvU8BiasReLU.
 #include "common.hpp"
 
 namespace mirl {

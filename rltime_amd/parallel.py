@@ -74,6 +74,7 @@ class DataParallel:
         self.force = bool(os.environ.get("BENCH_FORCE_DIST")) if force is None else force
         self.host_group = host_group
         self._backend = dist.get_backend(group)
+        self.timing = None      # a list: (start, end) HIP event pairs around every gradient all-reduce (bench.py)
 
     @property
     def active(self):
@@ -132,11 +133,29 @@ class DataParallel:
         p = self._params[-1]            # a set_to_none zero_grad elsewhere would silently detach the views
         assert p.grad is not None and p.grad.untyped_storage().data_ptr() == self._flat.untyped_storage().data_ptr(), \
             "parameter .grad no longer aliases the gradient bucket"
+        ev = None
+        if self.timing is not None and self._flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if self._backend == "nccl":
             dist.all_reduce(self._flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
             self._all_reduce(self._flat, dist.ReduceOp.SUM)
             self._flat.div_(self.world)
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(ev)
+
+    def ranks_seen(self, device):
+        """How many ranks actually take part in a collective on this group: the
+        all-reduced sum of a one per rank (bench.py's `rccl.ranks_seen`)."""
+        one = torch.ones(1, dtype=torch.int32, device=device)
+        self._all_reduce(one, dist.ReduceOp.SUM)
+        return int(one.item())
+
+    @property
+    def bucket_bytes(self):
+        return 0 if self._flat is None else self._flat.numel() * self._flat.element_size()
 
     # -- importance weights ---------------------------------------------------------
     def exchange_rows(self, mine):
