@@ -197,6 +197,14 @@ int mirl_replay_sample(mirl_replay* h, int32_t mbatch, double train_progress,
  * (p / P_g * N_g)^-beta, un-normalised; stats (4 device doubles): P_g, the local max
  * raw weight, strata kept, strata dropped because they exceeded `rows`.
  * Quota / NEED_MORE behave like mirl_replay_sample with mbatch_local.             */
+/* Host bookkeeping only (no device work, no side effect): *ready = 1 when a sample call
+ * for `mbatch` would NOT return MIRL_NEED_MORE (replay_history.py:110-114,
+ * prioritized_replay_history.py:295-299).  Multi-rank callers agree on it BEFORE
+ * entering any collective; a rank that then skips the call uses mirl_replay_sample_skip,
+ * which has exactly the side effects of a NEED_MORE return (quota charged,
+ * replay_history.py:176-181; device-RNG step counter advanced).                      */
+int mirl_replay_sample_ready(mirl_replay* h, int32_t mbatch, int32_t* ready);
+int mirl_replay_sample_skip(mirl_replay* h, int32_t mbatch);
 int mirl_replay_tree_root(mirl_replay* h, double* root_dev, void* stream);
 int mirl_replay_sample_global(mirl_replay* h, int32_t mbatch_local, int32_t mbatch_global, int32_t rows,
                               int32_t rank, int32_t world, const double* shard_totals,

@@ -112,6 +112,8 @@ _SIGNATURES = {
     "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
     "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_replay_sample_ready": [_vp, _i32, _P(_i32)],
+    "mirl_replay_sample_skip": [_vp, _i32],
     "mirl_replay_tree_root": [_vp, _vp, _vp],
     "mirl_replay_sample_global": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_replay_profile": [_vp, _i32, _P(_i64), _P(_f64)],

@@ -1,19 +1,26 @@
 #!/bin/bash
 # Build librltime_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# Objects are rebuilt only when their source (or any header) is newer; the
+# translation units compile in parallel.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../librltime_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
-"$HIPCC" $FLAGS -c "$HERE/replay.hip" -o "$HERE/replay.o"
-"$HIPCC" $FLAGS -c "$HERE/qmath.hip" -o "$HERE/qmath.o"
-"$HIPCC" $FLAGS -c "$HERE/lstm.hip" -o "$HERE/lstm.o"
-"$HIPCC" $FLAGS -c "$HERE/convert.hip" -o "$HERE/convert.o"
-"$HIPCC" $FLAGS -c "$HERE/nnops.hip" -o "$HERE/nnops.o"
-"$HIPCC" $FLAGS -c "$HERE/acting.hip" -o "$HERE/acting.o"
-"$HIPCC" $FLAGS -c "$HERE/conv_in.hip" -o "$HERE/conv_in.o"
-"$HIPCC" $FLAGS -c "$HERE/conv_mid.hip" -o "$HERE/conv_mid.o"
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$HERE/replay.o" "$HERE/qmath.o" "$HERE/lstm.o" "$HERE/convert.o" "$HERE/nnops.o" "$HERE/acting.o" "$HERE/conv_in.o" "$HERE/conv_mid.o" -o "$OUT"
+UNITS="replay qmath lstm lstm_seq convert nnops acting conv_in conv_mid"
+newest_hdr=$(ls -t "$HERE"/*.h "$HERE"/*.hpp "$HERE"/../../include/*.h "$HERE/build.sh" | head -1)
+pids=()
+objs=()
+for u in $UNITS; do
+  [ -f "$HERE/$u.hip" ] || continue
+  objs+=("$HERE/$u.o")
+  if [ ! -f "$HERE/$u.o" ] || [ "$HERE/$u.hip" -nt "$HERE/$u.o" ] || [ "$newest_hdr" -nt "$HERE/$u.o" ]; then
+    "$HIPCC" $FLAGS -c "$HERE/$u.hip" -o "$HERE/$u.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 # plain-C consumer of the C-ABI (gcc, no Python / torch): proves the boundary is self-contained
 ROCM="${ROCM_PATH:-/opt/rocm}"
 gcc -O2 -std=c99 -D__HIP_PLATFORM_AMD__ -I "$ROCM/include" -I "$HERE/../../include" "$HERE/../../examples/mirl_demo.c" \

@@ -1197,6 +1197,21 @@ extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progre
   return h->staging.mark(st);
 }
 
+extern "C" int mirl_replay_sample_ready(mirl_replay* h, int32_t mbatch, int32_t* ready) {
+  if (!h || mbatch <= 0 || !ready) return fail(MIRL_ERR_ARG, "bad sample_ready arguments");
+  const Book& bk = h->book;
+  *ready = bk.per ? (bk.active >= mbatch) : (bk.uniform_total() >= mbatch);
+  return MIRL_OK;
+}
+
+extern "C" int mirl_replay_sample_skip(mirl_replay* h, int32_t mbatch) {
+  if (!h || mbatch <= 0) return fail(MIRL_ERR_ARG, "bad sample_skip arguments");
+  int rc = h->book.charge_quota(mbatch);              // replay_history.py:176-181: charged even when None is returned
+  if (rc) { last_error_ref() = h->book.err; return rc; }
+  ++h->sample_calls;                                  // the Philox step counter advances like in a NEED_MORE return
+  return MIRL_OK;
+}
+
 extern "C" int mirl_replay_tree_root(mirl_replay* h, double* root_dev, void* stream) {
   if (!h || !h->d.per || !root_dev) return fail(MIRL_ERR_ARG, "bad tree_root arguments");
   hipLaunchKernelGGL(k_tree_root, dim3(1), dim3(1), 0, (hipStream_t)stream, h->d, (double)h->book.active, root_dev);

@@ -334,11 +334,11 @@ class ReplayHistoryBuffer(History):
     def get_train_data(self, mbatch_size, train_progress=None):
         """replay_history.py:173-184 -> history.py:203-286.  Returns None when
         more samples must be fed first."""
-        if self._h is None:
-            return None
         B = mbatch_size
         if getattr(self, "_global", None) is not None:
             return self._get_train_data_global(B, train_progress)
+        if self._h is None:
+            return None
         rng = None if self._device_rng else self._draw_host_rng(B)
         dev = self.device
         slot = torch.empty(B, dtype=torch.int32, device=dev)
@@ -505,27 +505,71 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
             assert overlap < self.nstep_train, "Overlap must be < nstep_train"
 
     # -- exact global sampling over env-sharded replays ------------------
-    def enable_global_sampling(self, data_parallel, slack=0.25, min_slack=4):
+    def enable_global_sampling(self, data_parallel, row_quantum=None):
         """Sample like ONE tree over the concatenation of all ranks' shards instead of
         per-shard proportionally: every rank draws the same Philox uniforms for the
         B_global = mbatch * world strata of the global priority mass and takes the
         strata that fall into its own cumulative range (include/mirl.h,
-        mirl_replay_sample_global).  The per-rank count is data-dependent, so batches
-        are padded to mbatch * (1 + slack) rows; padding rows carry weight 0 and no loss
-        index, and the real rows' importance weights are scaled so that the all-reduced
-        mean over the padded batches equals the mean over the B_global global rows."""
+        mirl_replay_sample_global).  The per-rank count is data-dependent, but bounded:
+        a range of mass P_r holds at most ceil(B_global * P_r / P_g) + 1 strata of width
+        P_g / B_global.  Every call therefore sizes this rank's batch from the table of
+        shard totals it has just exchanged — rows = that bound + 1 for rounding, rounded
+        up to a multiple of `row_quantum` (default max(4, mbatch // 8): few distinct batch
+        shapes) — so NO stratum can be dropped, whatever the imbalance between the
+        shards.  Padding rows carry weight 0 and no loss index, and the real rows'
+        importance weights are scaled by rows / mbatch so that the all-reduced mean over
+        the padded per-rank batches equals the mean over the B_global global rows.
+        Reading the (world, 2) table costs one small device->host copy per call; the
+        kernel still counts strata beyond `rows` and `check_dropped_strata()` (called
+        at every log interval) raises if that counter is ever non-zero."""
         if not self._device_rng:
             raise ValueError("global sampling draws its uniforms on the device: construct the buffer with device_rng=True")
-        self._global = (data_parallel, float(slack), int(min_slack))
+        self._global = (data_parallel, row_quantum)
+        self._dropped_dev = None
+        self.global_rows_log = []          # (rows, strata bound) of the most recent calls (tests / logging)
+
+    def global_rows_for(self, B, share):
+        """Rows of this rank's padded batch for a shard holding `share` = P_r / P_g of
+        the global priority mass (see enable_global_sampling)."""
+        dp, quantum = self._global
+        q = int(quantum) if quantum else max(4, B // 8)
+        bound = int(np.ceil(B * dp.world * float(share))) + 2
+        return ((bound + q - 1) // q) * q, bound
+
+    def check_dropped_strata(self):
+        """Strata that did not fit a padded batch since the last check (one host read;
+        the trainer calls it at log intervals).  Must be 0 by construction: raises."""
+        if getattr(self, "_dropped_dev", None) is None:
+            return 0
+        n = int(self._dropped_dev.item())
+        if n:
+            raise _lib.MirlError("global sampling dropped %d strata: a shard owned more strata than its padded batch "
+                                 "holds (the sample would be biased) — rows are sized from the exchanged shard totals, "
+                                 "so this means the totals changed between the exchange and the draw" % n)
+        return 0
 
     def _get_train_data_global(self, B, train_progress):
-        dp, slack, min_slack = self._global
+        dp, _ = self._global
         R, rank = dp.world, dp.rank
-        rows = B + max(min_slack, int(np.ceil(B * slack)))
+        # whether THIS shard can form a batch is host bookkeeping; all ranks agree on it BEFORE
+        # any collective is entered (a rank that returned None while its peer went on to the
+        # next all-reduce would leave mismatched collective sequences)
+        ready = C.c_int32(0)
+        if self._h is not None:
+            check(lib.mirl_replay_sample_ready(self._h, B, C.byref(ready)), "mirl_replay_sample_ready")
+        if not dp.all_ready(bool(ready.value)):
+            if self._h is not None:
+                check(lib.mirl_replay_sample_skip(self._h, B), "mirl_replay_sample_skip")
+                self._seed += 1
+            return None
         dev = self.device
         root = torch.empty(2, dtype=torch.float64, device=dev)
         check(lib.mirl_replay_tree_root(self._h, _ptr(root), _stream()), "mirl_replay_tree_root")
         shard = dp.exchange_rows(root).contiguous()                 # (R, 2): sum of priorities, active sequences
+        table = shard.cpu()                                         # the one host read of this path
+        share = float(table[rank, 0]) / float(table[:, 0].sum())
+        rows, bound = self.global_rows_for(B, share)
+        self.global_rows_log = (self.global_rows_log + [(rows, bound)])[-64:]
         slot = torch.empty(rows, dtype=torch.int32, device=dev)
         env = torch.empty(rows, dtype=torch.int32, device=dev)
         start = torch.empty(rows, dtype=torch.int64, device=dev)
@@ -538,13 +582,17 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
             self._h, B, B * R, rows, rank, R, _ptr(shard), float(train_progress or 0.0), self._seed,
             _ptr(slot), _ptr(env), _ptr(start), _ptr(loss_start), _ptr(raw), _ptr(stratum), _ptr(stats), _stream()),
             "mirl_replay_sample_global")
-        if rc == _lib.MIRL_NEED_MORE:
-            return None
+        if rc == _lib.MIRL_NEED_MORE:                               # cannot happen after the agreed readiness check
+            raise _lib.MirlError("mirl_replay_sample_global disagreed with mirl_replay_sample_ready")
+        if self._dropped_dev is None:
+            self._dropped_dev = torch.zeros((), dtype=torch.float64, device=dev)
+        self._dropped_dev += stats[3]
         self.last_beta = self._current_beta(train_progress)
         top = dp.exchange_rows(stats[1:2]).max()                    # batch max over ALL ranks (prioritized_replay_history.py:353-354)
-        weight = (raw / top * (float(R * rows) / float(B * R))).to(torch.float32)
+        weight = (raw / top * (float(rows) / float(B))).to(torch.float32)
         self.last_sample = {"slot": slot, "env": env, "start": start, "weight": weight, "stats": stats,
-                            "loss_start": loss_start, "stratum": stratum, "raw": raw, "shard": shard, "global": True}
+                            "loss_start": loss_start, "stratum": stratum, "raw": raw, "shard": shard, "global": True,
+                            "rows": rows}
         return self._gather(rows, env, start, weight, loss_start)
 
     def _per_config(self, cfg):

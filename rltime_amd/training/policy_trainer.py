@@ -172,6 +172,10 @@ class PolicyTrainer:
             self.value_log.log(key, val, group="this_interval")
         self.value_log.log("seconds", total_seconds, group="total")
         self.value_log.log("steps_acted", rates["steps_acted"], agg="sum", group="total", scope=None)
+        hist = getattr(self, "history_buffer", None)
+        if hist is not None and getattr(hist, "_global", None) is not None:
+            # exact global sampling: strata lost to a too-small padded batch (0 by construction; raises otherwise)
+            self.value_log.log("global_sampling_dropped_strata", hist.check_dropped_strata(), group="train")
         row = self.value_log.get()
         deep_dictionary_update(row, {"acting": {"actions": self.episodes.action_histogram()}})
         self.logger.log_result("train", row, self.steps)

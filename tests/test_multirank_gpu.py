@@ -96,7 +96,7 @@ def _rank_main(rank, world, port, out_dir, global_sampling=False):
     def tap(extra):
         w = inner(extra)
         if global_sampling:
-            assert hist.last_sample.get("global") and w.reshape(T, -1).shape[1] > 4      # padded rows
+            assert hist.last_sample.get("global") and w.reshape(T, -1).shape[1] == hist.last_sample["rows"] >= 4   # padded rows
             rec["w"].append(np.zeros(1)); rec["slots"].append(np.zeros(1, np.int64))     # noqa: E702
             rec["leaf_v"].append(np.zeros(1)); rec["leaf_k"].append(np.zeros(1, np.uint8))   # noqa: E702
             rec["active"].append(0); rec["beta"].append(hist.last_beta)                  # noqa: E702
@@ -221,7 +221,7 @@ GS = dict(size=600, train_frequency=0, nstep_target=2, nstep_train=8, prefix_ste
 GS_B, GS_DRAWS = 8, 6
 
 
-def _global_rank(rank, world, port, out_dir):
+def _global_rank(rank, world, port, out_dir, imbalance=1.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -241,7 +241,7 @@ def _global_rank(rank, world, port, out_dir):
                       done_prob=0.05, env_base=rank * E)
     buf = PrioritizedReplayHistoryBuffer(**GS, gamma=0.99, device_rng=True, num_envs=E, env_base=rank * E)
     buf.enable_global_sampling(dp)
-    rec = {k: [] for k in ("stratum", "slot", "weight", "leaf", "seed", "call", "beta", "active", "kept", "dropped")}
+    rec = {k: [] for k in ("stratum", "slot", "weight", "leaf", "seed", "call", "beta", "active", "kept", "dropped", "rows", "mass")}
     step_no, calls = 0, 0
     feeds = [70, 12, 0, 25, 9, 40]
     for draw in range(GS_DRAWS):
@@ -255,11 +255,18 @@ def _global_rank(rank, world, port, out_dir):
         assert batch is not None
         last = buf.last_sample
         rows = last["slot"].shape[0]
-        assert batch["states"]["x"].shape[1] == rows and rows >= GS_B + 4
+        # rows come from the exchanged shard totals: the strata bound of THIS shard, rounded up to the quantum
+        share = float(last["shard"][rank, 0] / last["shard"][:, 0].sum())
+        assert batch["states"]["x"].shape[1] == rows == buf.global_rows_for(GS_B, share)[0]
+        assert rows >= int(np.ceil(GS_B * world * share)) + 2 and rows % 4 == 0
+        pad_to = rows + (-rows) % 64
+        rec["rows"].append(rows)
+        rec["mass"].append(float(last["shard"][rank, 0]))
         cap = len(v) // 2
-        rec["stratum"].append(last["stratum"].cpu().numpy())
-        rec["slot"].append(last["slot"].cpu().numpy())
-        rec["weight"].append(last["weight"].double().cpu().numpy())
+        fill = lambda a, v: np.concatenate([a, np.full(pad_to - rows, v, a.dtype)])   # noqa: E731  (rows vary per draw)
+        rec["stratum"].append(fill(last["stratum"].cpu().numpy(), -1))
+        rec["slot"].append(fill(last["slot"].cpu().numpy(), -1))
+        rec["weight"].append(fill(last["weight"].double().cpu().numpy(), 0.0))
         rec["leaf"].append(v[cap:].copy())
         rec["seed"].append(buf._seed)
         rec["call"].append(calls)
@@ -275,15 +282,20 @@ def _global_rank(rank, world, port, out_dir):
         P = GS["prefix_steps"]
         idx = batch["extra_data"]["loss_indices"][P:].reshape(-1, 2)
         g = torch.Generator(device="cuda").manual_seed(draw * 10 + rank)
-        buf.update_losses(idx, torch.randn(idx.shape[0], device="cuda", generator=g) * 0.7)
-    np.savez(os.path.join(out_dir, "gs_rank%d.npz" % rank), **{k: np.array(v) for k, v in rec.items()}, rows=rows)
+        buf.update_losses(idx, torch.randn(idx.shape[0], device="cuda", generator=g) * 0.7 * (imbalance if rank == 1 else 1.0))
+    assert buf.check_dropped_strata() == 0
+    np.savez(os.path.join(out_dir, "gs_rank%d.npz" % rank), **{k: np.array(v) for k, v in rec.items()})
     buf.close()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
 
 
-def test_global_sampling_is_one_tree_over_the_union_of_shards(tmp_path):
-    """`enable_global_sampling` (mirl_replay_sample_global): with the same Philox
+@pytest.mark.parametrize("imbalance", [1.0, 40.0])
+def test_global_sampling_is_one_tree_over_the_union_of_shards(tmp_path, imbalance):
+    """imbalance 40: rank 1 reports 40x larger TD errors, so after a few draws its shard holds
+    well over 3x the priority mass of rank 0 and owns most strata — no stratum may be lost
+    (every rank sizes its padded batch from the exchanged shard totals).
+    `enable_global_sampling` (mirl_replay_sample_global): with the same Philox
     stream on both ranks, the strata of the GLOBAL priority mass go to the shard whose
     cumulative range contains them.  Checked against ONE reference tree
     (oracle.sumtree.SumTree, float64 leaves) over the concatenation of both shards'
@@ -296,11 +308,15 @@ def test_global_sampling_is_one_tree_over_the_union_of_shards(tmp_path):
     from oracle.sumtree import SumTree
     from tests.test_replay_gpu import _philox_u53
     world = 2
-    mp.spawn(_global_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_global_rank, args=(world, _free_port(), str(tmp_path), imbalance), nprocs=world, join=True)
     r = [np.load(tmp_path / ("gs_rank%d.npz" % i)) for i in range(world)]
     Bg = GS_B * world
-    rows = int(r[0]["rows"])
     exact = near = 0
+    if imbalance > 1:
+        ratio = r[1]["mass"][-1] / r[0]["mass"][-1]
+        assert ratio >= 3.0, ratio                                   # the scenario really is imbalanced
+        assert r[1]["rows"][-1] > r[0]["rows"][-1] and r[1]["rows"][-1] > GS_B * 1.25 + 4   # beyond the old fixed padding
+        print("priority-mass ratio rank1/rank0 at the last draw: %.1f, rows %d vs %d" % (ratio, r[1]["rows"][-1], r[0]["rows"][-1]))
     for s in range(GS_DRAWS):
         assert r[0]["seed"][s] == r[1]["seed"][s] and r[0]["call"][s] == r[1]["call"][s]
         n0 = r[0]["leaf"][s].shape[0]
@@ -339,7 +355,7 @@ def test_global_sampling_is_one_tree_over_the_union_of_shards(tmp_path):
             raws[st] = ((leaves[leaf_got] / Pg) * Ng) ** (-beta)
         top = max(raws.values())
         for st in range(Bg):
-            want_w = raws[st] / top * (float(world * rows) / float(Bg))
+            want_w = raws[st] / top * (float(r[got[st][0]]["rows"][s]) / float(GS_B))
             assert abs(got[st][2] - want_w) <= 5e-6 * want_w, (s, st)
     assert exact >= GS_DRAWS * Bg - 2
     print("global sampling: %d strata identical to the union tree, %d at a leaf boundary" % (exact, near))
