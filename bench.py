@@ -85,6 +85,8 @@ def parse():
                     help="N>1: both = strong-scaling headline + a `weak` sub-record in the same line")
     ap.add_argument("--dry-launch", action="store_true", help="print the N-rank launch command as JSON and exit")
     ap.add_argument("--master-port", type=int, default=None)
+    ap.add_argument("--share-gpu", action="store_true", help="launcher check on a box with fewer GPUs than ranks: ranks share "
+                    "the visible GPUs (rank % device_count) and talk over gloo (RCCL refuses two ranks per device); not a scaling number")
     ap.add_argument("--mbatch", type=int, default=None, help="override mbatch_size (whole job under --scaling strong)")
     ap.add_argument("--nstep-train", type=int, default=None)
     ap.add_argument("--burn-in", type=int, default=None)
@@ -563,10 +565,12 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; start it as `python bench.py --gpus N` "
                  "(self-launching) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if args.share_gpu:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    rank, world, local, dp = parallel.init_from_env(device=device)
+    rank, world, _, dp = parallel.init_from_env(backend="gloo" if args.share_gpu else None, device=device)
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
     spec = CONFIGS[args.config]
@@ -660,7 +664,7 @@ def main():
                 "envs_per_gpu": envs, "acted_transitions_per_step_per_gpu": res["acted"] / args.steps,
                 "acting_policy_forward_in_step": not args.no_acting,
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
-                "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world,
+                "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2)},
             "roofline": {
                 "kernel": "k_gather_rows_dedup (frames)" if args.frame_dedup else "k_gather_rows (frames)", "bound": "hbm",

@@ -8,9 +8,11 @@ import time
 
 
 class NullLogger:
-    def __init__(self, echo=False):
+    def __init__(self, echo=False, path=None):
         self.echo = echo
         self.rows = []
+        if path is not None:        # a rank that does not log still knows the run directory (per-rank checkpoints)
+            self.path = path
 
     def log_config(self, config):
         pass

@@ -122,7 +122,7 @@ class ReplayHistoryBuffer(History):
 
     def __init__(self, size, train_frequency, avoid_episode_crossing=False,
                  num_envs=None, env_base=None, device=None, device_rng=False,
-                 keep_policy_outputs=True, env_ring_slack=0, frame_stack_dedup=False, **kwargs):
+                 keep_policy_outputs=True, env_ring_slack=0, frame_stack_dedup=False, seed=None, **kwargs):
         """frame_stack_dedup (not a reference argument; the reference notes buffer-side
         stacking support as planned, history.py:56-59): True = the observation's leading
         axis is a frame stack produced by the stack-shift contract of
@@ -150,7 +150,11 @@ class ReplayHistoryBuffer(History):
         self._slack = env_ring_slack
         self._h = None
         self._layout = None
-        self._seed = 0x5EED
+        # key of the device-RNG (Philox) sampling stream; the shard's env_base is mixed in at
+        # creation so that ranks draw different streams (exact global sampling undoes it: all
+        # ranks must draw the SAME uniforms there)
+        self._seed_base = 0x5EED if seed is None else int(seed) & 0x7FFFFFFF
+        self._seed = self._seed_base
         self._policy_f32 = 0
 
     # -- lifetime ----------------------------------------------------------
@@ -163,6 +167,8 @@ class ReplayHistoryBuffer(History):
         self._num_envs = num_envs
         self._env_base = env_base
         self._policy_f32 = policy_f32
+        if getattr(self, "_global", None) is None and self._seed == self._seed_base:
+            self._seed = self._seed_base + (int(env_base or 0) << 32)
         cfg = _lib.ReplayConfig(
             size=self.size, num_envs=num_envs, env_base=env_base,
             frame_bytes=layout.frame_bytes, extra_f32=layout.extra_f32,
@@ -525,6 +531,7 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
         if not self._device_rng:
             raise ValueError("global sampling draws its uniforms on the device: construct the buffer with device_rng=True")
         self._global = (data_parallel, row_quantum)
+        self._seed = self._seed_base + (self._seed - self._seed_base) % (1 << 32)    # same Philox key on every rank
         self._dropped_dev = None
         self.global_rows_log = []          # (rows, strata bound) of the most recent calls (tests / logging)
 

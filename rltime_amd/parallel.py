@@ -32,12 +32,25 @@ import torch
 import torch.distributed as dist
 
 
+STEP_FIELDS = ("total_steps", "early_stop_steps", "warmup_steps", "target_update_freq", "log_freq",
+               "actor_update_frequency_steps")
+
+
 def shard_config(config, rank, world, scaling="strong"):
     """Per-rank view of a whole-job config.  Envs and replay capacity are always
     split evenly (rank r owns envs [r*E/R, (r+1)*E/R)).  scaling="strong": the
     configured mbatch_size is the GLOBAL batch and every rank trains B/R
     sequences; "weak": every rank keeps the
-    configured mbatch_size, envs and replay size (the job grows with R)."""
+    configured mbatch_size, envs and replay size (the job grows with R).
+
+    Step-denominated settings (total_steps, early_stop_steps, warmup_steps,
+    target_update_freq, log_freq, actor_update_frequency_steps) are compared against
+    a rank's OWN acted-step counter.  strong: the configured values count whole-job
+    acted steps, every rank acts 1/R of them, so they are divided by R (rounded up) —
+    an R-GPU strong run acts `total_steps` transitions in total, syncs the target
+    network every `target_update_freq` GLOBAL steps and anneals eps / lr / beta over
+    the same global horizon as the 1-GPU run.  weak: they stay per-rank values (the
+    job acts R x total_steps transitions)."""
     assert scaling in ("strong", "weak")
     cfg = copy.deepcopy(config)
     acting = cfg.setdefault("acting", {})
@@ -55,6 +68,9 @@ def shard_config(config, rank, world, scaling="strong"):
         if mb:
             assert mb % world == 0, "mbatch_size must divide by the number of ranks"
             targs["mbatch_size"] = mb // world
+        for key in STEP_FIELDS:
+            if targs.get(key):
+                targs[key] = max(1, -(-int(targs[key]) // world))
     else:
         per = envs
         acting["total_envs"] = envs * world
@@ -185,6 +201,22 @@ class DataParallel:
         top = (allr[:, 2] * k).max()
         scale = (allr[self.rank, 2] * k[self.rank] / top)
         return weights * scale.to(weights.dtype)
+
+    # -- host-side helpers -----------------------------------------------------------
+    def _host(self):
+        return self.host_group if self.host_group is not None else self.group
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self._host())
+
+    def broadcast_object(self, obj, src=0):
+        """A small picklable object from rank `src` to everyone (run directory names)."""
+        if self.world == 1:
+            return obj
+        box = [obj]
+        dist.broadcast_object_list(box, src=src, group=self._host())
+        return box[0]
 
     # -- lock-step guard -------------------------------------------------------------
     def all_ready(self, ready):

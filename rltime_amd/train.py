@@ -67,6 +67,21 @@ def train(config, logger=None, device="cuda", device_acting=True, data_parallel=
     return trainer
 
 
+def make_logger(rank, dp, log_dir, log_name=None):
+    """Rank 0 writes the log rows; EVERY rank knows the run directory, because full
+    checkpoints are one file set per rank (training/resume.py).  create_new()
+    uniquifies the name, so rank 0's choice is broadcast."""
+    if not log_dir:
+        return NullLogger(echo=(rank == 0))
+    logger, path = None, None
+    if rank == 0:
+        logger = DirectoryLogger.create_new(log_dir, log_name)
+        path = logger.path
+    if dp is not None:
+        path = dp.broadcast_object(path)
+    return logger if rank == 0 else NullLogger(echo=False, path=path)
+
+
 def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=None, log_name=None,
                       scaling="strong", backend=None, resume=None, seed=None):
     """train.py:66-111, plus the one-process-per-GPU launch."""
@@ -91,10 +106,10 @@ def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=N
         import random
         import numpy as np
         random.seed(seed + rank); np.random.seed(seed + rank); torch.manual_seed(seed + rank)
-    if rank == 0 and log_dir:
-        logger = DirectoryLogger.create_new(log_dir, log_name)
-    else:
-        logger = NullLogger(echo=(rank == 0))
+    if seed is not None:
+        hm = config["training"]["args"].setdefault("history_mode", {}).setdefault("args", {})
+        hm.setdefault("seed", seed)          # device-RNG sampling stream (the shard mixes its env_base in)
+    logger = make_logger(rank, dp, log_dir, log_name)
     try:
         return train(config, logger, device=device, data_parallel=dp, resume=resume)
     finally:

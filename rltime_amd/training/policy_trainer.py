@@ -192,6 +192,8 @@ class PolicyTrainer:
             raise ValueError("full_checkpoints needs a directory logger (train.py --log-dir)")
         self._resolve_gpu_spans()
         resume.save(self, path)
+        if self.data_parallel is not None:
+            self.data_parallel.barrier()         # the checkpoint is complete only when every rank's files are
         self._full_checkpoint_due = False
 
     def train(self, total_steps, log_freq=10000, target_update_freq=0, clip_rewards=False,

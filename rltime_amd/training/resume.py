@@ -63,6 +63,10 @@ def collect(trainer):
                     "num_envs": getattr(hist, "_num_envs", None), "env_base": getattr(hist, "_env_base", None),
                     "policy_f32": getattr(hist, "_policy_f32", 0)},
         "actors": trainer.actors.get_state() if hasattr(trainer.actors, "get_state") else None,
+        # overlapped acting (multi_step_trainer._loop_iteration_overlapped): whether the next
+        # iteration's feed is already in the replay, and its not yet applied target-sync / log flags
+        "overlap": None if getattr(trainer, "_ov", None) is None
+        else {"fed": trainer._ov["fed"], "deferred": trainer._ov["deferred"]},
     }
     return state
 
@@ -118,6 +122,14 @@ def load(trainer, base_dir):
         # schedule runs on it; update_actors refreshes it only every
         # actor_update_frequency_steps, multi_step_trainer.py:369-373)
         trainer.actors.set_state(state["actors"])
+    ov = getattr(trainer, "_ov", None)
+    if ov is not None:
+        # the actors' weight copy was snapshotted from the freshly initialised policy before
+        # this load; at a checkpoint (end of an iteration) it equals the online weights
+        ov["actor_policy"].copy_from(trainer.policy)
+        ov["weights_ready"].record()
+        if state.get("overlap") is not None:
+            ov["fed"], ov["deferred"] = state["overlap"]["fed"], state["overlap"]["deferred"]
     # RNG streams last: nothing above may consume them afterwards
     rng = state["rng"]
     random.setstate(rng["python"])

@@ -17,7 +17,7 @@ CNN = {"type": "cnn", "args": {"channels_last": True, "layers": [{"filters": 8, 
                                                                 {"filters": 8, "kernel": 3, "stride": 1}]}}
 
 
-def config(total, stop, full):
+def config(total, stop, full, overlap=False):
     return {
         "acting": {"actor_envs": 8, "exploration": {"type": "epsilon_greedy", "args": {
             "eps_start": 1.0, "eps_final": 0.05, "exploration_fraction": 0.5}}},
@@ -30,7 +30,7 @@ def config(total, stop, full):
             "burn_in_timesteps": 4, "nstep_target": 2, "lr": 1e-3, "lr_anneal": True, "double_q": True,
             "rnn_bootstrap": True, "clip_grad": 10.0, "clip_grad_dynamic_alpha": 0.9, "target_update_freq": 160,
             "total_steps": total, "early_stop_steps": stop, "log_freq": total // 2, "warmup_steps": 0,
-            "full_checkpoints": full,
+            "full_checkpoints": full, "overlap_acting": bool(overlap),
             "history_mode": {"type": "prioritized_replay", "args": {
                 "size": 600, "train_frequency": 4, "alpha": 0.9, "beta": 0.6, "beta_anneal": True}}}},
     }
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--full", type=int, default=1)
     ap.add_argument("--resume", default=None)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--overlap", type=int, default=0)
     a = ap.parse_args()
     torch.backends.cudnn.deterministic = True          # MIOpen: no atomically-accumulating solvers
     random.seed(1); np.random.seed(2); torch.manual_seed(3)   # noqa: E702
@@ -63,11 +64,28 @@ def main():
             return orig(key, value, *args, **kw)
         trainer.value_log.log = tap
 
-    logger = DirectoryLogger(os.path.join(a.log_dir, a.name), echo=False)
-    trainer = train(config(a.total, a.stop, bool(a.full)), logger, resume=a.resume, on_trainer=hook)
+    cfg = config(a.total, a.stop, bool(a.full), a.overlap)
+    dp, rank = None, 0
+    if "WORLD_SIZE" in os.environ:
+        # one rank of a torch.distributed.run launch: both ranks share GPU 0, so gloo (RCCL refuses
+        # two ranks per device); the same entry path as rltime_amd.train.train_from_config
+        from rltime_amd import parallel
+        from rltime_amd.train import make_logger
+        torch.cuda.set_device(0)
+        rank, world, _, dp = parallel.init_from_env(backend="gloo")
+        cfg = parallel.shard_config(cfg, rank, world, "strong")
+        random.seed(1 + rank); np.random.seed(2 + rank); torch.manual_seed(3 + rank)   # noqa: E702
+        logger = make_logger(rank, dp, a.log_dir, a.name)
+        assert logger.path == os.path.join(a.log_dir, a.name)
+    else:
+        logger = DirectoryLogger(os.path.join(a.log_dir, a.name), echo=False)
+    trainer = train(cfg, logger, resume=a.resume, on_trainer=hook, data_parallel=dp)
     series["final_steps"] = trainer.steps
     series["param_sum"] = float(sum(p.double().sum().item() for p in trainer.policy.parameters()))
-    json.dump(series, open(a.out, "w"))
+    json.dump(series, open(a.out if dp is None else a.out.replace(".json", "_rank%d.json" % rank), "w"))
+    if dp is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

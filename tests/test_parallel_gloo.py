@@ -89,6 +89,14 @@ def test_shard_config():
     assert shards[3]["training"]["args"]["history_mode"]["args"]["size"] == 125000
     assert shards[3]["training"]["args"]["mbatch_size"] == 64       # global B=512
     assert cfg["acting"]["actor_envs"] == 256       # input untouched
+    # strong: step-denominated settings count whole-job acted steps -> 1/R per rank (rounded up)
+    from rltime_amd.parallel import STEP_FIELDS
+    full = cfg["training"]["args"]
+    for key in STEP_FIELDS:
+        if full.get(key):
+            assert shards[5]["training"]["args"][key] == -(-full[key] // 8), key
+            assert shard_config(cfg, 1, 4, "weak")["training"]["args"][key] == full[key], key
+    assert any(full.get(k) for k in ("total_steps", "target_update_freq"))
     weak = [shard_config(cfg, r, 4, "weak") for r in range(4)]     # weak: every rank keeps the configured job
     assert [s["acting"]["actor_envs"] for s in weak] == [256] * 4
     assert [s["acting"]["env_base"] for s in weak] == [0, 256, 512, 768]

@@ -97,6 +97,16 @@ print(json.dumps(res, indent=1))
 PY
              find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -size +1M -delete; find "$OUT" -name "*.db" -delete;;
     dist1)   BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_rccl_forced_world1.json" 2> "$OUT/bench_rccl_forced_world1.err"; echo "dist1 rc=$?"; tail -c 500 "$OUT/bench_rccl_forced_world1.err"; head -c 600 "$OUT/bench_rccl_forced_world1.json"; echo;;
+    selflaunch) BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_selflaunch_world1.json" 2> "$OUT/bench_selflaunch_world1.err"; echo "selflaunch rc=$?"; tail -c 500 "$OUT/bench_selflaunch_world1.err"; head -c 1500 "$OUT/bench_selflaunch_world1.json"; echo
+             timeout 900 python bench.py --gpus 2 --share-gpu --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_gpus2_shared_gloo.json" 2> "$OUT/bench_gpus2_shared_gloo.err"; echo "gpus2 rc=$?"; tail -c 800 "$OUT/bench_gpus2_shared_gloo.err"; python - "$OUT/bench_gpus2_shared_gloo.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print({k: d[k] for k in ("value", "learner_steps_per_sec", "n_gpus", "ms_per_step", "scaling", "rccl")}); print("weak:", d.get("weak"))
+except Exception as e:
+    print("no json line:", e)
+PY
+    ;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
