@@ -151,6 +151,12 @@ class MultiStepTrainer(PolicyTrainer):
             return
         while not self.train_is_done():
             self.loop_iteration()
+        if self._ov is not None:
+            # overlapped acting hands the target sync / log row / checkpoint triggered by a feed to the
+            # START of the next iteration; the feed that ended the run has no next iteration
+            self._ov_apply_deferred()
+            if self._full_checkpoint_due:
+                self.save_full_checkpoint()
 
     def setup(self, **train_args):
         """Everything `train(**args)` does before THE LOOP (policies, optimizer,
