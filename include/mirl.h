@@ -321,6 +321,28 @@ int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, co
 int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates,
                        const float* c_in, const float* keep_next, float* h_out, float* c_out,
                        float* h_next, float* c_next, void* stream);
+/* A whole forward sweep of the recurrent layer (all T steps of all B sequences) in ONE
+ * persistent launch (csrc/lstm_seq.hip; replaces the T-step loop of
+ * rltime/models/torch/modules/lstm.py:83-116): W_hh stays resident in LDS, the cell runs
+ * in the MFMA accumulators' lanes, workgroups exchange h(t) through write-through stores
+ * and per-row-tile arrival counters (no grid barrier).  gx [T][B][4H] holds the input
+ * projection x W_ih^T + b_ih + b_hh on entry; with save_gates it holds the activated
+ * gates (i, f, g, o) on exit, as mirl_lstm_cell_fwd leaves them.  h0 / c0 [B][H] are the
+ * states before step 0 (the reset mask keep[0] is applied inside), keep [T][B] = 1 -
+ * initials.  Optional outputs: out [T][B][H] = h(t); c_all [T][B][H] = c(t); hm / cm
+ * [T+1][B][H] = the masked inputs of every step (row T = final state); h_last / c_last
+ * [B][H] = that final state alone.  At least one of (hm, cm) / (h_last, c_last).
+ * workspace: mirl_lstm_seq_workspace_bytes(B, H) bytes, 256-byte aligned, private to the
+ * call until the stream has passed it.  Shapes: mirl_lstm_seq_supported (B multiple of
+ * 16, H in {128, 256, 512}).  A workgroup that waits for a peer longer than ~seconds
+ * gives up; the next call then returns MIRL_ERR_STATE (mirl_lstm_seq_status reads the
+ * flag without clearing it).                                                           */
+int mirl_lstm_seq_supported(int32_t T, int32_t B, int32_t H);
+int mirl_lstm_seq_workspace_bytes(int32_t B, int32_t H, int64_t* bytes);
+int mirl_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, float* gx, const float* w_hh, const float* h0,
+                      const float* c0, const float* keep, float* out, float* c_all, float* hm, float* cm,
+                      float* h_last, float* c_last, int32_t save_gates, void* workspace, void* stream);
+int mirl_lstm_seq_status(int32_t* status);
 /* Backward of one step: gates holds the activated gates on entry and
  * d loss / d pre-activation on exit; d_out [B][H] = grad of this step's output h
  * (NULL = 0); dh_rec / dc_rec = grads w.r.t. the next step's masked inputs

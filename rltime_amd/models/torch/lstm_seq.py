@@ -34,8 +34,70 @@ import os
 _FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "0") == "1"
 
 
+# The persistent sequence kernel (csrc/lstm_seq.hip: one launch per sweep, W_hh resident in
+# LDS, h exchanged between workgroups through write-through stores + arrival counters) is
+# the default wherever it supports the shape; MIRL_LSTM_PERSISTENT=0 keeps the per-step path.
+_PERSISTENT = os.environ.get("MIRL_LSTM_PERSISTENT", "1") != "0"
+
+
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def persistent_supported(T, B, H):
+    return _PERSISTENT and T >= 2 and bool(lib.mirl_lstm_seq_supported(T, B, H))
+
+
+def _forward_sweep(gates, w, h0, c0, keep, need_grad):
+    """The time loop over `gates` (T, B, 4H) = the input projection (+ biases), in place.
+    Returns (out, hm, cm, c_all, h_last, c_last); hm / cm / c_all are None unless need_grad
+    (then `gates` holds the activated gates on return)."""
+    T, B, G = gates.shape
+    H = G // 4
+    dev = gates.device
+    out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+    st = _stream()
+    if persistent_supported(T, B, H) and w.data_ptr() % 16 == 0:
+        nbytes = C.c_int64()
+        check(lib.mirl_lstm_seq_workspace_bytes(B, H, C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        assert ws.data_ptr() % 256 == 0
+        hm = cm = c_all = h_last = c_last = None
+        if need_grad:
+            hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+            cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+            c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        else:
+            h_last = torch.empty((B, H), dtype=torch.float32, device=dev)
+            c_last = torch.empty((B, H), dtype=torch.float32, device=dev)
+        check(lib.mirl_lstm_seq_fwd(
+            T, B, H, _p(gates), _p(w), _p(h0), _p(c0), _p(keep), _p(out), _p(c_all), _p(hm), _p(cm),
+            _p(h_last), _p(c_last), 1 if need_grad else 0, _p(ws), st), "mirl_lstm_seq_fwd")
+        ws.record_stream(torch.cuda.current_stream())
+        if need_grad:
+            h_last, c_last = hm[T], cm[T]
+        return out, hm, cm, c_all, h_last, c_last
+    hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)     # masked h inputs; hm[T] = final h
+    cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+    c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev) if need_grad else None
+    torch.mul(h0, keep[0].unsqueeze(-1), out=hm[0])
+    torch.mul(c0, keep[0].unsqueeze(-1), out=cm[0])
+    wt = w.t()
+    fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
+    for t in range(T):
+        if fused_step:
+            # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
+            check(lib.mirl_lstm_step_fwd(
+                B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+                "mirl_lstm_step_fwd")
+            continue
+        gates[t].addmm_(hm[t], wt)
+        check(lib.mirl_lstm_cell_fwd(
+            B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
+            _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
+            "mirl_lstm_cell_fwd")
+    return out, hm, cm, c_all, hm[T], cm[T]
 
 
 def _stream():
@@ -57,31 +119,10 @@ class _LSTMSequence(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:4])
         dev = x.device
         gates = torch.addmm(bias.float(), x, w_ih.float().t()).view(T, B, 4 * H)
-        hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)     # masked h inputs; hm[T] = final h
-        cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
-        out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
-        c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev) if need_grad else None
-        torch.mul(h0.float(), keep[0].unsqueeze(-1), out=hm[0])
-        torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
-        wt = w.t()
-        st = _stream()
-        fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
-        for t in range(T):
-            if fused_step:
-                # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
-                check(lib.mirl_lstm_step_fwd(
-                    B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
-                    _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
-                    "mirl_lstm_step_fwd")
-                continue
-            gates[t].addmm_(hm[t], wt)
-            check(lib.mirl_lstm_cell_fwd(
-                B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
-                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
-                "mirl_lstm_cell_fwd")
+        out, hm, cm, c_all, h_last, c_last = _forward_sweep(
+            gates, w, h0.float().contiguous(), c0.float().contiguous(), keep, need_grad)
         if need_grad:
             ctx.save_for_backward(x, w_ih, gates, c_all, cm, hm, keep, w)
-        h_last, c_last = hm[T], cm[T]
         ctx.mark_non_differentiable(h_last, c_last)
         return out, h_last, c_last
 
@@ -123,31 +164,10 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dev = gx.device
         gates = gx.float().clone(memory_format=torch.contiguous_format)
-        hm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
-        cm = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
-        out = torch.empty((T, B, H), dtype=torch.float32, device=dev)
-        c_all = torch.empty((T, B, H), dtype=torch.float32, device=dev) if need_grad else None
-        torch.mul(h0.float(), keep[0].unsqueeze(-1), out=hm[0])
-        torch.mul(c0.float(), keep[0].unsqueeze(-1), out=cm[0])
-        wt = w.t()
-        st = _stream()
-        fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
-        for t in range(T):
-            if fused_step:
-                # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
-                check(lib.mirl_lstm_step_fwd(
-                    B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
-                    _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
-                    "mirl_lstm_step_fwd")
-                continue
-            gates[t].addmm_(hm[t], wt)
-            check(lib.mirl_lstm_cell_fwd(
-                B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
-                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
-                "mirl_lstm_cell_fwd")
+        out, hm, cm, c_all, h_last, c_last = _forward_sweep(
+            gates, w, h0.float().contiguous(), c0.float().contiguous(), keep, need_grad)
         if need_grad:
             ctx.save_for_backward(gates, c_all, cm, hm, keep, w)
-        h_last, c_last = hm[T], cm[T]
         ctx.mark_non_differentiable(h_last, c_last)
         return out, h_last, c_last
 

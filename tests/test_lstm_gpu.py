@@ -9,14 +9,22 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("T,B,I,H", [(1, 3, 5, 4), (7, 5, 12, 8), (20, 33, 40, 64), (80, 16, 64, 512),
-                                     (5, 32, 24, 64), (12, 64, 40, 128), (9, 256, 48, 512)])
-@pytest.mark.parametrize("step_kernel", [False, True])
-def test_fused_lstm_matches_loop(T, B, I, H, step_kernel, monkeypatch):
+                                     (5, 32, 24, 64), (12, 64, 40, 128), (9, 256, 48, 512),
+                                     (80, 512, 32, 512), (6, 48, 20, 256), (3, 80, 8, 128)])
+@pytest.mark.parametrize("mode", ["gemm+cell", "step_kernel", "persistent"])
+def test_fused_lstm_matches_loop(T, B, I, H, mode, monkeypatch):
+    """persistent = the one-launch-per-sweep kernel (csrc/lstm_seq.hip), incl. the config-D
+    shape T=80, B=512, H=512 with mid-sequence resets (20 % of the initials set), a ragged
+    row block (B=48, 80: 3 and 5 sixteen-row tiles) and H = 128 / 256."""
     from rltime_amd.models.torch import lstm_seq
     from rltime_amd.models.torch.modules import LSTM
+    step_kernel = mode == "step_kernel"
     if step_kernel and (B % 32 or H % 64):
         pytest.skip("the one-launch step kernel needs B % 32 == 0 and H % 64 == 0")
     monkeypatch.setattr(lstm_seq, "_FUSED_STEP", step_kernel)
+    monkeypatch.setattr(lstm_seq, "_PERSISTENT", mode == "persistent")
+    if mode == "persistent" and not lstm_seq.persistent_supported(T, B, H):
+        pytest.skip("shape outside the persistent kernel (B % 16, H in {128, 256, 512}, T >= 2)")
     torch.manual_seed(T * 100 + B)
     a = LSTM((I,), H).cuda()
     b = LSTM((I,), H).cuda()
@@ -155,3 +163,72 @@ def test_fused_lstm_step_kernel_matches_gemm_plus_cell(B, H):
         outs.append((gates, h_out, c_out, h_next, c_next))
     for name, a, b in zip(("gates", "h", "c", "h_next", "c_next"), outs[0], outs[1]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+
+
+def _sweep_inputs(T, B, H, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)   # noqa: E731
+    gx = rnd(T, B, 4 * H)
+    w = (rnd(4 * H, H) * (1.5 / H ** 0.5)).contiguous()
+    h0, c0 = rnd(B, H) * 0.5, rnd(B, H)
+    keep = (torch.rand(T, B, device="cuda", generator=g) > 0.15).float()
+    return gx, w, h0, c0, keep
+
+
+@pytest.mark.parametrize("T,B,H", [(80, 512, 512), (40, 512, 512), (7, 1024, 512), (5, 16, 128), (33, 208, 256)])
+@pytest.mark.parametrize("need_grad", [False, True])
+def test_persistent_sweep_equals_the_per_step_path(T, B, H, need_grad, monkeypatch):
+    """mirl_lstm_seq_fwd against the rocBLAS-GEMM + cell-kernel loop on the same projection:
+    outputs, final state and — with need_grad — everything the backward pass reads
+    (activated gates, c(t), the masked step inputs).  B = 1024 makes clusters loop over two
+    row blocks (512 workgroups would not be co-resident)."""
+    from rltime_amd.models.torch import lstm_seq
+    gx, w, h0, c0, keep = _sweep_inputs(T, B, H, T + B + H)
+    assert lstm_seq.persistent_supported(T, B, H)
+    res = []
+    for persistent in (True, False):
+        monkeypatch.setattr(lstm_seq, "_PERSISTENT", persistent)
+        gates = gx.clone()
+        out, hm, cm, c_all, h_last, c_last = lstm_seq._forward_sweep(gates, w, h0, c0, keep, need_grad)
+        res.append(dict(out=out, h_last=h_last.clone(), c_last=c_last.clone(),
+                        gates=gates if need_grad else None, hm=hm if need_grad else None,
+                        cm=cm if need_grad else None, c_all=c_all))
+    for k, a in res[0].items():
+        b = res[1][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=3e-6, err_msg=k)
+
+
+def test_persistent_sweep_under_uneven_load_and_back_to_back():
+    """The inter-workgroup hand-off must not depend on timing or placement: 12 sweeps back to
+    back (re-used workspace memory, poisoned with NaN first) while a second stream keeps the
+    chip unevenly busy with GEMMs of varying size; every sweep must reproduce the first
+    result bit for bit, and no workgroup may have timed out."""
+    import ctypes as C
+    from rltime_amd._lib import lib, check
+    from rltime_amd.models.torch import lstm_seq
+    T, B, H = 40, 512, 512
+    gx, w, h0, c0, keep = _sweep_inputs(T, B, H, 7)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    junk = torch.full((8 << 20,), float("nan"), device="cuda")
+    del junk                                      # the allocator hands these NaN bytes to the next workspaces
+    first = None
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for k in range(1 + rep % 4):
+                n = 512 * (1 + (rep + k) % 7)
+                _ = a[:n, :n] @ a[:n, :n]
+        gates = gx.clone()
+        out, _, _, _, h_last, c_last = lstm_seq._forward_sweep(gates, w, h0, c0, keep, False)
+        got = torch.cat([out.reshape(-1), h_last.reshape(-1), c_last.reshape(-1)]).clone()
+        if first is None:
+            first = got
+            assert torch.isfinite(first).all()
+        else:
+            assert torch.equal(got, first), "sweep %d differs" % rep
+    torch.cuda.synchronize()
+    st = C.c_int32(-1)
+    check(lib.mirl_lstm_seq_status(C.byref(st)))
+    assert st.value == 0

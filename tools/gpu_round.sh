@@ -107,6 +107,8 @@ except Exception as e:
     print("no json line:", e)
 PY
     ;;
+    lstm)    timeout 900 python -m pytest tests/test_lstm_gpu.py -x -q --timeout 300 -k "lstm or persistent" > "$OUT/pytest_lstm.log" 2>&1; echo "pytest lstm rc=$?"; tail -15 "$OUT/pytest_lstm.log"
+             timeout 300 python tools/lstm_probe.py > "$OUT/lstm_probe.jsonl" 2> "$OUT/lstm_probe.err"; echo "lstm probe rc=$?"; cat "$OUT/lstm_probe.jsonl"; tail -3 "$OUT/lstm_probe.err";;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
