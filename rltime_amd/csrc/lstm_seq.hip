@@ -26,7 +26,8 @@
 //     and differs from the zero fill — and a reader re-sweeps its 16 x H panel until
 //     every word carries the expected tag, then clears it (x ^ tag: one VALU op per
 //     register that is both the check value and the operand).  No drain of the store
-//     queue, no atomic, no separate poll: one store -> load visibility hop per step.
+//     queue, no atomic, no separate poll: one store -> load visibility hop per step
+//     (a sweep that finds an old tag is followed by one agent-scope acquire, see below).
 //     Only the initial state (arbitrary user values) goes through the classic form
 //     R1: sc1 stores, `s_waitcnt vmcnt(0)`, one relaxed agent-scope arrival per wave
 //     on the tile's counter, one polling lane.  blockIdx % clusters keeps a cluster
@@ -98,6 +99,9 @@ k_lstm_seq_fwd(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t 
   const int pr = lane >> 2, pq = lane & 3;
   const int pk0 = 16 * cg + 4 * pq;
   const int p_slot = (((pk0 % KG) >> 2) * 64 + (pr + 16 * (pk0 / KG))) * 4;     // float offset inside the tile's [KQ][64][4] block
+  // the word lane l polls for producer l (column group l): last row, last quad of its 16 x 16 block
+  const int poll_k0 = 16 * (lane % NCG) + 12;
+  const int poll_slot = (((poll_k0 % KG) >> 2) * 64 + (15 + 16 * (poll_k0 / KG))) * 4;
   const int nrb = (B + 63) >> 6;
   const int b_off = (li * PW + KG * lk);             // + g * 16 * PW + 4 q
   for (int rb = cluster; rb < nrb; rb += nclusters) {
@@ -151,6 +155,19 @@ k_lstm_seq_fwd(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t 
           const unsigned tmask = t >= 1 ? sq_tag(t - 1) : 0u;
           const int xb = (int)(((t == 0 ? 2 * x_half_floats : (t & 1) * x_half_floats) + x_tile) * 4) + lane * 16;
           unsigned spins = 0;
+          if (t >= 1) {
+            // cheap pre-poll: lane l < NCG watches ONE word of producer l's block (a relaxed agent-scope
+            // atomic load: 4 bytes per producer instead of 32 KB sweeps while the data is not there yet)
+            const unsigned* probe = (const unsigned*)(X + (t & 1) * x_half_floats + x_tile + poll_slot);
+            for (;;) {
+              const unsigned wv = lane < NCG ? __hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tmask;
+              if (__all(((wv ^ tmask) & 0x40000000u) == 0u)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > SQ_SPIN_CAP) { failed = true; break; }
+            }
+            if (failed) break;
+            asm volatile("" ::: "memory");
+          }
           for (;;) {
             sq_u4 rv[KQ];
 #pragma unroll
@@ -164,6 +181,11 @@ k_lstm_seq_fwd(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t 
               av[q] = __builtin_bit_cast(sq_f4, y);
             }
             if (t == 0 || __all((seen & 0x40000000u) == 0u)) break;
+            // A failed sweep may leave lines without the expected tag in this CU's L1 (sc1 buffer loads
+            // can allocate there) and a re-sweep would hit them for ever: one agent-scope acquire
+            // (buffer_inv sc1) before every RE-sweep.  A stale line can delay a wave but never be
+            // accepted: the previous content of a slot always carries the opposite tag.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SQ_SPIN_CAP) { failed = true; break; }
           }

@@ -200,15 +200,16 @@ def test_persistent_sweep_equals_the_per_step_path(T, B, H, need_grad, monkeypat
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=3e-6, err_msg=k)
 
 
-def test_persistent_sweep_under_uneven_load_and_back_to_back():
-    """The inter-workgroup hand-off must not depend on timing or placement: 12 sweeps back to
+@pytest.mark.parametrize("T,B,H", [(40, 512, 512), (24, 256, 512), (24, 192, 256), (30, 64, 512)])
+def test_persistent_sweep_under_uneven_load_and_back_to_back(T, B, H):
+    """B = 512: one cluster per XCD; B = 256 / 192 / 64: 4 / 3 / 1 clusters, every cluster spread
+    over several XCDs (cross-XCD hand-offs).  The inter-workgroup hand-off must not depend on timing or placement: 12 sweeps back to
     back (re-used workspace memory, poisoned with NaN first) while a second stream keeps the
     chip unevenly busy with GEMMs of varying size; every sweep must reproduce the first
     result bit for bit, and no workgroup may have timed out."""
     import ctypes as C
     from rltime_amd._lib import lib, check
     from rltime_amd.models.torch import lstm_seq
-    T, B, H = 40, 512, 512
     gx, w, h0, c0, keep = _sweep_inputs(T, B, H, 7)
     side = torch.cuda.Stream()
     a = torch.randn(4096, 4096, device="cuda")
@@ -228,6 +229,17 @@ def test_persistent_sweep_under_uneven_load_and_back_to_back():
             assert torch.isfinite(first).all()
         else:
             assert torch.equal(got, first), "sweep %d differs" % rep
+    # and the repeated result is the right one
+    from rltime_amd.models.torch import lstm_seq as ls
+    keep_flag = ls._PERSISTENT
+    ls._PERSISTENT = False
+    try:
+        gates = gx.clone()
+        out, _, _, _, h_last, c_last = ls._forward_sweep(gates, w, h0, c0, keep, False)
+    finally:
+        ls._PERSISTENT = keep_flag
+    want = torch.cat([out.reshape(-1), h_last.reshape(-1), c_last.reshape(-1)])
+    np.testing.assert_allclose(first.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=3e-6)
     torch.cuda.synchronize()
     st = C.c_int32(-1)
     check(lib.mirl_lstm_seq_status(C.byref(st)))
