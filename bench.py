@@ -438,8 +438,10 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
 
     # ---- pre-fill the replay shard (untimed) ---------------------------------
     t0 = time.time()
+    sink, real_actors._sink = getattr(real_actors, "_sink", None), None       # the probe step comes back as tensors
     probe = real_actors.get_samples(envs)                    # one real acting step: learns the transition layout
     hist.update(probe)
+    real_actors._sink = sink
     feeder = SyntheticFeeder(probe, device, seed=99 + rank,
                              stacked_env=real_actors._vec_env if args.frame_dedup else None)
     trainer.actors = feeder            # pre-generated actor output (no policy forward) for the fill

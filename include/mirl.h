@@ -149,6 +149,12 @@ int mirl_replay_destroy(mirl_replay* h);
  * device write per vector step.                                               */
 int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream);
 
+/* mirl_replay_ingest issues ONE fused kernel per call (frame / state / q-value rows, scalars,
+ * plan, tree fix) unless the shard de-duplicates frame stacks or initialises priorities at
+ * acting time; 0 selects the separate kernels of rounds 1-2 for every shard (A/B tests; the
+ * environment variable MIRL_INGEST_FUSED=0 does the same).                                  */
+int mirl_ingest_fused_set(int32_t on);
+
 /* needed_feed_count (replay_history.py:62-75).  *out = -1 for None.           */
 int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_envs, int64_t* out);
 
@@ -485,6 +491,25 @@ int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t 
 int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
                     const double* eps, const double* expo, double eps_min, const float* u, const int64_t* rnd,
                     int32_t* actions, float* qvalues, float* eps_used, void* stream);
+/* The same head with its epsilon-greedy draws made inside the kernel (one Philox4x32-10
+ * block per (step, env), keyed by rng_seed and the device word *rng_step that
+ * mirl_actor_pre advances): no torch.rand / torch.randint launches per vector step.   */
+int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
+                        const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
+                        const uint64_t* rng_step, int32_t* actions, float* qvalues, float* eps_used, void* stream);
+/* Everything between env.step and the policy forward of the device-resident actor in ONE
+ * launch (acting/actor.py:124-131 -> modules/lstm.py:131-161 state reset on `done`;
+ * policy_trainer.py:93-131 episode statistics; :252-254 reward sign clipping): h_in = h *
+ * (1 - done) -> xh_tail rows (pitch xh_pitch floats: the tail of the LSTM GEMM's
+ * [features | h_in] input), c_in = c * (1 - done), state_pack [E][2H] = [h_in | c_in] and
+ * initials = done (the transition's stored recurrent state), rewards_out (clipped when
+ * clip_rewards), dones_out (uint8), the mirl_episode_track accumulators (optional) and
+ * *rng_step = step.                                                                    */
+int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, const uint8_t* dones,
+                   const int32_t* actions, const float* h, const float* c, float* xh_tail, int64_t xh_pitch,
+                   float* c_in, float* state_pack, float* initials, float* rewards_out, uint8_t* dones_out,
+                   int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
+                   int32_t* action_counts, uint64_t* rng_step, uint64_t step, void* stream);
 int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,
                        const int32_t* actions, float* ep_reward, int32_t* ep_len,
                        float* out_reward, int32_t* out_len, int32_t* action_counts, void* stream);

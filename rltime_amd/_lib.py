@@ -110,6 +110,7 @@ _SIGNATURES = {
     "mirl_replay_create": [_P(ReplayConfig), _P(_vp)],
     "mirl_replay_destroy": [_vp],
     "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
+    "mirl_ingest_fused_set": [_i32],
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
     "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_replay_sample_ready": [_vp, _i32, _P(_i32)],
@@ -165,6 +166,9 @@ _SIGNATURES = {
     "mirl_iqn_mul_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_dueling_tail_bwd": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
+    "mirl_actor_pre": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                       _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_copy_bytes": [_vp, _vp, _i64, _vp],
     "mirl_book_create": [_P(ReplayConfig), _P(_vp)],

@@ -108,6 +108,9 @@ class Actor(ActingInterface):
         self._device_mode = device
         self._use_graph = use_graph and device
         self._graphed = None
+        self._fast = None              # acting/fast_step.FastActingStep when the policy shape allows it
+        self._sink = None              # device replay the fast path ingests into directly (set_sink)
+        self.clip_rewards = False      # sign-clip rewards before they are stored (policy_trainer.py:252-254)
         self._tracker = None
         super().__init__(vec_env.observation_space, vec_env.action_space)
 
@@ -123,7 +126,16 @@ class Actor(ActingInterface):
         """actor.py:78-89: reset the envs and build the first input state."""
         self._policy = actor_policy
         obs = self._vec_env.reset()
+        self._reset_obs = obs
+        self._fast = None
         self.last_state = actor_policy.make_input_state(obs, np.array([True] * self._num_envs))
+
+    def set_sink(self, history, clip_rewards=False):
+        """Let the device actor write its vector steps straight into `history` (a device
+        replay with update_batch): get_samples then returns an already-ingested summary
+        (fast_step.IngestedSamples) and History.update is a no-op for it."""
+        self._sink = history if hasattr(history, "update_batch") else None
+        self.clip_rewards = bool(clip_rewards)
 
     def close(self):
         self._vec_env.close()
@@ -142,7 +154,9 @@ class Actor(ActingInterface):
                      for layer in rec]
             last = clone(self.last_state)
         env = self._vec_env.get_state() if hasattr(self._vec_env, "get_state") else None
-        return {"progress": self._progress, "carry": carry, "last_state": last, "env": env}
+        return {"progress": self._progress, "carry": carry, "last_state": last, "env": env,
+                "fast": self._fast.get_state() if self._fast else None,
+                "tracker": self._tracker.get_state() if self._tracker is not None else None}
 
     def set_state(self, state):
         dev = self._policy.device()
@@ -152,6 +166,14 @@ class Actor(ActingInterface):
         self.last_state = deep_apply(state["last_state"], lambda x: x.to(dev) if isinstance(x, torch.Tensor) else x)
         self._progress = state["progress"]
         self._graphed = None                   # the acting graph is re-captured from this state
+        self._fast_restore = state.get("fast")
+        self._tracker_restore = state.get("tracker")
+        if self._fast:
+            self._fast.set_state(self._fast_restore)
+            self._fast_restore = None
+        if self._tracker is not None and self._tracker_restore is not None:
+            self._tracker.set_state(self._tracker_restore)
+            self._tracker_restore = None
         if state["env"] is not None and hasattr(self._vec_env, "set_state"):
             self._vec_env.set_state(state["env"])
 
@@ -229,7 +251,60 @@ class Actor(ActingInterface):
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_actor_head")
         return actions, qvalues
 
+    def _fast_steps(self, iters):
+        """The fused vector step (acting/fast_step.py)."""
+        from .fast_step import FastActingStep, IngestedSamples
+        if self._fast is None:
+            self._fast = FastActingStep(self, self._reset_obs)
+            if self._tracker is None:
+                from .episode_tracker import EpisodeTracker
+                self._tracker = EpisodeTracker(self._num_envs, self._action_space.n, self._policy.device())
+            self._fast.tracker = self._tracker
+            if getattr(self, "_fast_restore", None) is not None:
+                self._fast.set_state(self._fast_restore)
+                self._fast_restore = None
+            if getattr(self, "_tracker_restore", None) is not None:
+                self._tracker.set_state(self._tracker_restore)
+                self._tracker_restore = None
+        fs, sink = self._fast, self._sink
+        fs.refresh()
+        fs.set_eps(self._eps())
+        fs.reselect()
+        keep_policy = False
+        if sink is not None:
+            if sink._h is None:
+                pf = self._action_space.n if sink._keep_policy else 0
+                sink.configure(fs.example, self._num_envs, self._base_env_id, policy_f32=pf)
+            keep_policy = bool(sink._policy_f32)
+        out = None
+        for _ in range(iters):
+            obs, rewards, dones, stats = self._vec_env.step_device(fs.actions)
+            assert stats is None, "the fused acting step keeps the episode statistics on the device"
+            fields = fs.step(obs, rewards, dones, sink=sink, keep_policy=keep_policy, clip=self.clip_rewards and sink is not None)
+            if sink is None:
+                if out is None:
+                    out = DeviceSamples(fs.example, self._num_envs, self._base_env_id)
+                out.append(**fields)
+        self._tracker.flush()
+        if sink is not None:
+            return IngestedSamples(iters * self._num_envs, self._tracker)
+        out.episode_tracker = self._tracker
+        return out
+
     def _device_steps(self, iters):
+        if self._use_graph and getattr(self, "fast_step", True) and self._fast is not False:
+            from .fast_step import FastActingStep
+            if self._fast is not None or FastActingStep.supports(self):
+                try:
+                    return self._fast_steps(iters)
+                except Exception as e:                    # e.g. graph capture refused: the generic path still works
+                    if self._fast is not None and self._fast.graph is not None:
+                        raise
+                    import logging
+                    logging.getLogger().warning("fused acting step unavailable (%s); using the generic device path", e)
+                    self._fast = False
+            else:
+                self._fast = False
         out, pending = None, None
         for it in range(iters):
             # (1)+(2) actor.py:108-122: action selection with the current weights
@@ -248,6 +323,9 @@ class Actor(ActingInterface):
                 if self._tracker is None:
                     from .episode_tracker import EpisodeTracker
                     self._tracker = EpisodeTracker(self._num_envs, self._action_space.n, rewards.device)
+                    if getattr(self, "_tracker_restore", None) is not None:
+                        self._tracker.set_state(self._tracker_restore)
+                        self._tracker_restore = None
                 self._tracker.step(rewards, dones8, actions)
             # (4) actor.py:128: next input state (+ the next action when replayed from the graph)
             fields, pending = None, None

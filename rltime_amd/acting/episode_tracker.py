@@ -43,6 +43,22 @@ class EpisodeTracker:
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_episode_track")
         self.row += 1
 
+    def begin_step(self):
+        """Reserve the ring row of the next vector step (the fused pre-step kernel of
+        acting/fast_step.py writes it): same bookkeeping as step()."""
+        if self.row - self.flushed == self.ROWS:
+            self.flush()
+        r = self.row % self.ROWS
+        self.row += 1
+        return r
+
+    def get_state(self):
+        return {"ep_reward": self.ep_reward.cpu(), "ep_len": self.ep_len.cpu()}
+
+    def set_state(self, state):
+        self.ep_reward.copy_(state["ep_reward"].to(self.device))
+        self.ep_len.copy_(state["ep_len"].to(self.device))
+
     def flush(self):
         """Start the asynchronous read-back of the rows written since the last flush."""
         n = self.row - self.flushed
@@ -85,6 +101,9 @@ class EpisodeTracker:
 
     def take_action_counts(self):
         """Action counts since the last call (synchronises: log-interval use only)."""
-        counts = self.action_counts.cpu().tolist()
-        self.action_counts.zero_()
-        return counts
+        # the counters only ever grow (an overlapped acting stream may be adding to them right
+        # now): report the difference to the last read instead of zeroing them under it
+        now = self.action_counts.cpu()
+        last = getattr(self, "_counts_read", None)
+        self._counts_read = now
+        return (now if last is None else now - last).tolist()

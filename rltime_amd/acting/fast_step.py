@@ -1,0 +1,275 @@
+"""The device-resident actor's vector step for the CNN -> LSTM -> FC (dueling DQN / IQN)
+policies, with the launch count cut to what the network itself needs.
+
+Reference order of one vector step (rltime/acting/actor.py:108-147): policy forward on
+the last input state -> epsilon-greedy -> env.step -> make_input_state (recurrent state
+reset on `done`) -> split into per-env sample dicts -> History.update.  The generic
+device path (actor.GraphedStep) replays that as ~48 kernels + 6 for the ingest; most of
+them are 2-5 us PyTorch glue (mask multiplies, cat, clones of graph outputs, bias adds,
+weight concatenations, rand / randint, fills).  Here one step is
+
+    env.step                                   (on the device; the synthetic env: no launch)
+    mirl_actor_pre            1 launch         reset masks, [h|c] pack, initials, reward clip,
+                                               episode statistics, RNG step
+    mirl_replay_ingest        1 copy + 1 launch  frames + state + scalars + plan + tree, straight
+                                               from the static buffers (no clones)
+    mirl_conv1_u8_fwd         2 launches       input layer from the env's uint8 frames
+    HIP graph                 ~17 launches     conv 2-3, [features | h] x [W_ih | W_hh]^T in ONE GEMM,
+                                               cell, quantile embedding, joint FC, outputs, head with
+                                               in-kernel Philox draws
+
+Everything that only depends on the weights (b_ih + b_hh, [W_ih | W_hh], the joint
+[last FC | dueling value-hidden] weights) is rebuilt once per get_samples call
+(`refresh`) into static buffers the graph reads, instead of inside every step.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from rltime_amd._lib import lib, check
+from rltime_amd.general.utils import deep_apply
+from rltime_amd.models.torch.fused import conv_bias_relu, conv_u8_supported, cos_embed
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class IngestedSamples:
+    """What get_samples returns when the steps went straight into the replay: only the
+    count and the episode statistics are left for the trainer."""
+    ingested = True
+
+    def __init__(self, count, tracker):
+        self.count = count
+        self.episode_tracker = tracker
+
+    def __len__(self):
+        return self.count
+
+    def __bool__(self):
+        return self.count > 0
+
+    def process(self, trainer):
+        if self.episode_tracker is not None:
+            for reward, length in self.episode_tracker.drain():
+                trainer._log_episode(reward, length)
+            trainer.episodes.device_tracker = self.episode_tracker
+
+
+class FastActingStep:
+    @staticmethod
+    def supports(actor):
+        """CNN (NHWC, input layer straight from uint8) -> LSTM -> one Linear+ReLU, dueling head,
+        IQN quantile layer (if any) injected before the last layer, epsilon-greedy or greedy."""
+        pol = actor._policy
+        try:
+            from rltime_amd.models.torch.modules import CNN, FC, LSTM
+            model = pol.model
+            if len(model.layers) != 3 or model.extra_input_layer is not None or not pol.is_cuda():
+                return False
+            cnn, lstm, fc = model.layers
+            if not (isinstance(cnn, CNN) and isinstance(lstm, LSTM) and isinstance(fc, FC)):
+                return False
+            if not (cnn.channels_last and cnn.direct_u8 and cnn.scale and lstm.fused and len(cnn.layers) >= 1):
+                return False
+            if pol._fused_tail_layer() is None or lstm.lstm_cell.bias_ih is None:
+                return False
+            pre = model.layer_pre_processors
+            iqn = hasattr(pol, "num_sampling_quantiles")
+            if (iqn and set(pre) != {2}) or (not iqn and pre):
+                return False
+            expl = actor._exploration
+            if expl is not None and not hasattr(expl, "_device_exponents"):
+                return False
+            space = actor._vec_env.observation_space
+            probe = torch.empty((1,) + tuple(space.shape), dtype=torch.uint8, device=pol.device())
+            return bool(conv_u8_supported(probe, cnn.layers[0])) and hasattr(actor._vec_env, "step_device")
+        except Exception:
+            return False
+
+    def __init__(self, actor, obs0):
+        self.actor = actor
+        pol = self.pol = actor._policy
+        self.cnn, self.lstm, self.fc_layer = pol.model.layers
+        self.fc = pol._fused_tail_layer()
+        self.iqn = hasattr(pol, "num_sampling_quantiles")
+        self.N = pol.num_sampling_quantiles if self.iqn else 1
+        dev = self.dev = pol.device()
+        E = self.E = actor._num_envs
+        H = self.H = self.lstm.num_units
+        F = self.F = self.lstm.inp_size
+        A = self.A = actor._action_space.n
+        f32 = dict(dtype=torch.float32, device=dev)
+        c1 = self.cnn.layers[0]
+        _, hh, ww = obs0.shape[1:]
+        k, s = c1.kernel_size[0], c1.stride[0]
+        self.y1 = torch.empty((E, c1.out_channels, (hh - k) // s + 1, (ww - k) // s + 1), memory_format=torch.channels_last, **f32)
+        self.wpk = torch.empty(8192, **f32)
+        self.xh = torch.zeros((E, F + H), **f32)                 # [conv features (NCHW order) | masked h]
+        self.c_in = torch.zeros((E, H), **f32)
+        self.h = torch.zeros((E, H), **f32)                      # raw carry (outputs of the last cell)
+        self.c = torch.zeros((E, H), **f32)
+        self.state_pack = torch.zeros((E, 2 * H), **f32)
+        self.initials = torch.ones(E, **f32)
+        self.rewards = torch.zeros(E, **f32)
+        self.dones = torch.ones(E, dtype=torch.uint8, device=dev)
+        self.gates = torch.empty((E, 4 * H), **f32)
+        self.actions = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.qvalues = torch.zeros((E, A), **f32)
+        self.eps = torch.zeros((), dtype=torch.float64, device=dev)
+        self.rng_step = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.step_no = 0
+        self.rng_seed = (int(torch.initial_seed()) ^ (int(actor._base_env_id) << 32) ^ 0xAC7) & 0x7FFFFFFFFFFFFFFF
+        cell = self.lstm.lstm_cell
+        self.bias_sum = torch.empty(4 * H, **f32)
+        self.wcat = torch.empty((4 * H, F + H), **f32)
+        h1, hv = self.fc.out_features, pol.value_hidden_layer.out_features
+        self.h1 = h1
+        self.fc_w = torch.empty((h1 + hv, self.fc.in_features), **f32)
+        self.fc_b = torch.empty(h1 + hv, **f32)
+        expl = actor._exploration
+        self.expo = expl._device_exponents(actor._env_ids, dev) if expl is not None else None
+        self.eps_min = float(expl.eps_min) if expl is not None else 0.0
+        self.last_obs = obs0
+        self.tracker = None
+        self.graph = None
+        assert cell.weight_ih.shape == (4 * H, F)
+        # the reference's first input state: every env starts an episode (actor.py:78-89)
+        self.refresh()
+        self._pre(torch.zeros(E, **f32), torch.ones(E, dtype=torch.uint8, device=dev), track=False)
+        self.example = {"x": obs0[0].cpu().numpy(), "layer0_state": {},
+                        "layer1_state": {"hx": np.zeros(H, np.float32), "cx": np.zeros(H, np.float32), "initials": np.float32(1.0)},
+                        "layer2_state": {}}
+        self._capture()
+
+    # -- weight-only quantities, once per get_samples call -------------------------------
+    def refresh(self):
+        pol, cell, F = self.pol, self.lstm.lstm_cell, self.F
+        with torch.no_grad():
+            torch.add(cell.bias_ih, cell.bias_hh, out=self.bias_sum)
+            self.wcat[:, :F].copy_(cell.weight_ih)
+            self.wcat[:, F:].copy_(cell.weight_hh)
+            self.fc_w[:self.h1].copy_(self.fc.weight)
+            self.fc_w[self.h1:].copy_(pol.value_hidden_layer.weight)
+            self.fc_b[:self.h1].copy_(self.fc.bias)
+            self.fc_b[self.h1:].copy_(pol.value_hidden_layer.bias)
+
+    def set_eps(self, eps):
+        self.eps.fill_(eps)
+
+    # -- pieces ------------------------------------------------------------------------------
+    def _pre(self, rewards, dones_u8, track=True, clip=False):
+        tr = self.tracker if track else None
+        row = tr.begin_step() if tr is not None else None
+        self.step_no += 1
+        check(lib.mirl_actor_pre(
+            self.E, self.H, self.A, _p(rewards), _p(dones_u8), _p(self.actions), _p(self.h), _p(self.c),
+            C.c_void_p(self.xh.data_ptr() + 4 * self.F), self.F + self.H, _p(self.c_in), _p(self.state_pack), _p(self.initials),
+            _p(self.rewards), _p(self.dones), 1 if clip else 0,
+            _p(tr.ep_reward) if tr is not None else None, _p(tr.ep_len) if tr is not None else None,
+            _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
+            _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), self.step_no, _stream()), "mirl_actor_pre")
+
+    def _conv1(self, obs):
+        c1 = self.cnn.layers[0]
+        so, sc, sh, sw = c1.weight.stride()
+        check(lib.mirl_conv1_u8_fwd(obs.shape[0], obs.shape[2], obs.shape[3], _p(obs), _p(c1.weight), so, sc, sh, sw, _p(c1.bias),
+                                    float(self.cnn.scale), _p(self.wpk), _p(self.y1), _stream()), "mirl_conv1_u8_fwd")
+
+    def _body(self):
+        """conv 2.. -> LSTM step -> head; reads y1 / xh tail / c_in, writes h, c, actions, qvalues."""
+        pol, E, H, F, N = self.pol, self.E, self.H, self.F, self.N
+        x = self.y1
+        for layer in self.cnn.layers[1:]:
+            x = conv_bias_relu(x, layer)
+        ch, hh, ww = x.shape[1:]
+        torch.as_strided(self.xh, (E, ch, hh, ww), (F + H, hh * ww, ww, 1)).copy_(x)       # NHWC -> the reference's (C, H, W) flatten
+        torch.addmm(self.bias_sum, self.xh, self.wcat.t(), out=self.gates)
+        check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
+              "mirl_lstm_cell_fwd")
+        feat = self.h
+        if self.iqn:
+            taus = pol._draw_taus(E * N)
+            phi = cos_embed(taus, pol.embedding_range * np.pi)
+            emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
+            prod = torch.empty_like(emb)
+            check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(prod), _stream()), "mirl_iqn_mul_fwd")
+            feat = prod
+        both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
+        adv = torch.addmm(pol.out_layer.bias, both[:, :self.h1], pol.out_layer.weight.t())
+        val = torch.addmm(pol.value_layer.bias, both[:, self.h1:], pol.value_layer.weight.t())
+        greedy = self.expo is None
+        check(lib.mirl_actor_head_rng(
+            E, N, self.A, _p(adv), _p(val), val.shape[1], None if greedy else _p(self.eps), None if greedy else _p(self.expo),
+            self.eps_min, self.rng_seed, None if greedy else _p(self.rng_step), _p(self.actions), _p(self.qvalues), None, _stream()),
+            "mirl_actor_head_rng")
+
+    def _capture(self):
+        keep = (self.h.clone(), self.c.clone())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():          # warm-up outside capture (MIOpen find, hipBLASLt workspaces)
+            self._conv1(self.last_obs)
+            for _ in range(3):
+                self._body()
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            self._body()
+        self.graph = graph
+        self.h.copy_(keep[0])
+        self.c.copy_(keep[1])
+        self.reselect()
+
+    # -- the acting loop's entry points ---------------------------------------------------------
+    def reselect(self):
+        """Forward + exploration on the CURRENT input state with the current weights (the first
+        action after a learner update, actor.py:108-122); idempotent on the recurrent carry."""
+        self._conv1(self.last_obs)
+        self.graph.replay()
+
+    def step(self, obs, rewards, dones, sink=None, keep_policy=False, clip=False):
+        """One vector step AFTER env.step(self.actions) returned (obs, rewards, dones).  With a
+        `sink` (device replay) the transition is ingested straight from the static buffers;
+        without one the caller gets clones of them (DeviceSamples fields)."""
+        dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
+        self._pre(rewards if rewards.dtype == torch.float32 else rewards.float(), dones_u8, clip=clip)
+        fields = None
+        if sink is not None:
+            sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
+                              policy=self.qvalues if keep_policy else None, transient=True)
+        else:
+            fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
+                          policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)
+        self.last_obs = obs
+        self._conv1(obs)
+        self.graph.replay()
+        return fields
+
+    # -- resume --------------------------------------------------------------------------------------
+    def get_state(self):
+        keys = ("h", "c", "xh", "c_in", "state_pack", "initials", "actions", "qvalues", "rewards", "dones")
+        st = {k: getattr(self, k).detach().clone().cpu() for k in keys}
+        st["xh"] = self.xh[:, self.F:].detach().clone().cpu()
+        st.update(step_no=self.step_no, last_obs=self.last_obs.detach().clone().cpu())
+        return st
+
+    def set_state(self, st):
+        for k in ("h", "c", "c_in", "state_pack", "initials", "actions", "qvalues", "rewards", "dones"):
+            getattr(self, k).copy_(st[k].to(self.dev))
+        self.xh[:, self.F:].copy_(st["xh"].to(self.dev))
+        self.step_no = st["step_no"]
+        self.rng_step.fill_(self.step_no)
+        self.last_obs = st["last_obs"].to(self.dev)
+
+
+def example_input_state(policy, obs, dones):
+    """One transition's next_state pytree as host arrays (the device replay's layout probe)."""
+    return deep_apply(policy.make_input_state(obs, dones), lambda x: x[0].cpu().numpy())

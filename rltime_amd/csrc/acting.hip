@@ -8,6 +8,7 @@
 // (reward, length; length 0 = no episode ended for that env this step) that the host
 // reads back asynchronously — the acting loop never synchronises.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace mirl {
 
@@ -36,7 +37,8 @@ __global__ void __launch_bounds__(256)
 k_actor_head(int E, int N, int A, const float* __restrict__ adv, const float* __restrict__ val, int Q,
              const double* __restrict__ eps, const double* __restrict__ expo, double eps_min,
              const float* __restrict__ u, const int64_t* __restrict__ rnd,
-             int32_t* __restrict__ actions, float* __restrict__ qvalues, float* __restrict__ eps_used) {
+             int32_t* __restrict__ actions, float* __restrict__ qvalues, float* __restrict__ eps_used,
+             uint64_t rng_seed, const uint64_t* __restrict__ rng_step) {
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= E) return;
@@ -72,14 +74,96 @@ k_actor_head(int E, int N, int A, const float* __restrict__ adv, const float* __
     if (eps) {                                          // epsilon_greedy.py:74-100
       double pe = pow(*eps, expo ? expo[e] : 1.0);
       float per = (float)(pe > eps_min ? pe : eps_min);
-      if (u[e] < per) act = (int)rnd[e];
+      if (rng_step) {
+        // the draws made here instead of two torch launches: one Philox4x32-10 block per (step, env)
+        uint32_t r[4];
+        philox_4x32(rng_seed, *rng_step, (uint32_t)e, r);
+        const float uf = (float)(r[0] >> 8) * (1.0f / 16777216.0f);          // 24-bit uniform in [0, 1) like torch.rand
+        if (uf < per) act = (int)(((uint64_t)r[1] * (uint64_t)A) >> 32);     // unbiased enough for A << 2^32
+      } else if (u[e] < per) act = (int)rnd[e];
       if (eps_used) eps_used[e] = per;
     }
     actions[e] = act;
   }
 }
 
+// Everything between the environment step and the policy forward of the device-resident
+// actor, ONE launch per vector step (reference: Actor.get_samples, acting/actor.py:124-131
+// -> make_input_state -> LSTM.get_state, modules/lstm.py:131-161, and the episode
+// statistics of PolicyTrainer._track_rewards, policy_trainer.py:93-131):
+//   * recurrent carry reset: h_in = h * (1 - done), c_in = c * (1 - done); h_in goes
+//     straight into the tail of the LSTM GEMM's input rows [features | h_in] (row pitch
+//     xh_pitch floats), c_in into the cell kernel's input;
+//   * the transition's stored recurrent state [h_in | c_in] (what mirl_replay_ingest takes
+//     as `state`) and `initials` = done;
+//   * reward clipping (np.sign, policy_trainer.py:252-254) AFTER the raw reward went into
+//     the episode statistics; dones as uint8;
+//   * episode reward / length accumulators and the action histogram (k_episode_track);
+//   * the step counter the acting head's Philox draws are keyed with.
+__global__ void __launch_bounds__(256)
+k_actor_pre(int E, int H, int A, const float* __restrict__ rewards_raw, const uint8_t* __restrict__ dones,
+            const int32_t* __restrict__ actions, const float* __restrict__ h, const float* __restrict__ c,
+            float* __restrict__ xh_tail, int64_t xh_pitch, float* __restrict__ c_in, float* __restrict__ state_pack,
+            float* __restrict__ initials, float* __restrict__ rewards_out, uint8_t* __restrict__ dones_out, int clip,
+            float* __restrict__ ep_reward, int32_t* __restrict__ ep_len, float* __restrict__ out_reward,
+            int32_t* __restrict__ out_len, int32_t* __restrict__ action_counts,
+            uint64_t* __restrict__ rng_step, uint64_t step) {
+  const int e = blockIdx.x;
+  const float keep = dones[e] ? 0.0f : 1.0f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const float hm = h[(int64_t)e * H + j] * keep, cm = c[(int64_t)e * H + j] * keep;
+    xh_tail[(int64_t)e * xh_pitch + j] = hm;
+    c_in[(int64_t)e * H + j] = cm;
+    state_pack[(int64_t)e * 2 * H + j] = hm;
+    state_pack[(int64_t)e * 2 * H + H + j] = cm;
+  }
+  if (threadIdx.x == 0) {
+    const float rr = rewards_raw[e];
+    const int dn = dones[e] ? 1 : 0;
+    initials[e] = dn ? 1.0f : 0.0f;
+    dones_out[e] = (uint8_t)dn;
+    rewards_out[e] = clip ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : rr;
+    if (ep_reward) {
+      float r = ep_reward[e] + rr;
+      int n = ep_len[e] + 1;
+      if (dn) { out_reward[e] = r; out_len[e] = n; r = 0.f; n = 0; }
+      else { out_reward[e] = 0.f; out_len[e] = 0; }
+      ep_reward[e] = r; ep_len[e] = n;
+      if (action_counts && actions) { const int a = actions[e]; if (a >= 0 && a < A) atomicAdd(action_counts + a, 1); }
+    }
+    if (e == 0 && rng_step) *rng_step = step;
+  }
+}
+
 }  // namespace mirl
+
+extern "C" int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, const uint8_t* dones,
+                              const int32_t* actions, const float* h, const float* c, float* xh_tail, int64_t xh_pitch,
+                              float* c_in, float* state_pack, float* initials, float* rewards_out, uint8_t* dones_out,
+                              int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
+                              int32_t* action_counts, uint64_t* rng_step, uint64_t step, void* stream) {
+  if (E <= 0 || H <= 0 || !rewards_raw || !dones || !h || !c || !xh_tail || !c_in || !state_pack || !initials || !rewards_out ||
+      !dones_out || (ep_reward && (!ep_len || !out_reward || !out_len)))
+    return mirl::fail(MIRL_ERR_ARG, "bad actor_pre arguments");
+  mirl::ProfScope ps("k_actor_pre", (double)E * H * 4.0 * 6.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(mirl::k_actor_pre, dim3(E), dim3(256), 0, (hipStream_t)stream, (int)E, (int)H, (int)A, rewards_raw, dones, actions,
+                     h, c, xh_tail, xh_pitch, c_in, state_pack, initials, rewards_out, dones_out, (int)clip_rewards, ep_reward,
+                     ep_len, out_reward, out_len, action_counts, rng_step, step);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
+                                   const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
+                                   const uint64_t* rng_step, int32_t* actions, float* qvalues, float* eps_used, void* stream) {
+  if (E <= 0 || N <= 0 || A <= 0 || !adv || !actions || !qvalues || (eps && !rng_step) || (val && Q <= 0))
+    return mirl::fail(MIRL_ERR_ARG, "bad actor_head_rng arguments");
+  mirl::ProfScope ps("k_actor_head", 0.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(mirl::k_actor_head, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, (int)E, (int)N, (int)A, adv, val, (int)Q,
+                     eps, expo, eps_min, (const float*)nullptr, (const int64_t*)nullptr, actions, qvalues, eps_used, rng_seed, rng_step);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
 
 extern "C" int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
                                const double* eps, const double* expo, double eps_min, const float* u, const int64_t* rnd,
@@ -88,7 +172,7 @@ extern "C" int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv
     return mirl::fail(MIRL_ERR_ARG, "bad actor_head arguments");
   mirl::ProfScope ps("k_actor_head", 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(mirl::k_actor_head, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, (int)E, (int)N, (int)A, adv, val, (int)Q,
-                     eps, expo, eps_min, u, rnd, actions, qvalues, eps_used);
+                     eps, expo, eps_min, u, rnd, actions, qvalues, eps_used, (uint64_t)0, (const uint64_t*)nullptr);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include "book.hpp"
 #include "np_emul.h"
+#include "philox.hpp"
 #include "vfscale.hpp"
 
 #include <cstring>
@@ -184,8 +185,7 @@ k_plan_apply(Dev d, int n_table, const TableOp* __restrict__ tops, int n_env, co
 // level per barrier (segment_tree.py:91-97; the result depends only on the
 // leaves, so the batch order is irrelevant).  Single workgroup: the tree is
 // latency-bound, not bandwidth-bound.
-__global__ void __launch_bounds__(1024)
-k_tree_fix(Dev d) {
+__device__ __forceinline__ void tree_fix_body(const Dev& d) {
   const int n = *d.dirty_count;
   for (int lvl = d.log2cap - 1; lvl >= 0; --lvl) {
     for (int i = threadIdx.x; i < n; i += 1024) {
@@ -199,6 +199,86 @@ k_tree_fix(Dev d) {
   }
   __syncthreads();
   if (threadIdx.x == 0) *d.dirty_count = 0;
+}
+
+__global__ void __launch_bounds__(1024)
+k_tree_fix(Dev d) { tree_fix_body(d); }
+
+// The whole device side of one History.update call (history.py:123-176 + the _sample_added /
+// _sample_removed hooks) in ONE launch — rounds 1-2 issued k_scatter_rows x 2-4,
+// k_ingest_scalars, k_plan_apply and k_tree_fix per vector step.  Grid (bx, K + 1):
+//   y < K   copy workgroups of transition y: frame row, extra / recurrent-state / q-value rows
+//           into their ring slots (16 B per lane when the geometry allows);
+//   y == K  ONE bookkeeping workgroup: per-transition scalars (so that the freshly ingested
+//           losses exist before a leaf activation reads them), the plan's table / env /
+//           leaf ops, and — when a leaf changed — the tree fix, in this order behind
+//           workgroup barriers.  Copy and bookkeeping workgroups touch disjoint arrays.
+struct IngestSrc {
+  const uint8_t* frames; const float* extra; const float* state; const float* policy;
+  const float* initials; const int32_t* actions; const float* rewards; const uint8_t* dones;
+  int vec_frames, vec_extra, vec_state, vec_policy;
+};
+
+__device__ __forceinline__ void copy_row(const uint8_t* s, uint8_t* t, int row_bytes, int vec, int part, int parts) {
+  if (!row_bytes) return;
+  if (vec) {
+    const int n = row_bytes >> 4;
+    const u32x4* s4 = (const u32x4*)s;
+    u32x4* t4 = (u32x4*)t;
+    for (int c = part * 1024 + threadIdx.x; c < n; c += parts * 1024) t4[c] = s4[c];
+  } else {
+    for (int c = part * 1024 + threadIdx.x; c < row_bytes; c += parts * 1024) t[c] = s[c];
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
+               int n_table, const TableOp* __restrict__ tops, int n_env, const EnvOp* __restrict__ eops,
+               int n_leaf, const LeafOp* __restrict__ lops) {
+  const int k = blockIdx.y;
+  if (k < K) {
+    const int64_t slot = (int64_t)s_env[k] * d.C + s_off[k] % d.C;
+    const int part = blockIdx.x, parts = gridDim.x;
+    copy_row(in.frames + (int64_t)k * d.F, d.frames + slot * (int64_t)d.Fp, d.F, in.vec_frames, part, parts);
+    if (d.X) copy_row((const uint8_t*)(in.extra + (int64_t)k * d.X), (uint8_t*)(d.extra + slot * (int64_t)d.X), d.X * 4, in.vec_extra, part, parts);
+    if (d.S) copy_row((const uint8_t*)(in.state + (int64_t)k * d.S), (uint8_t*)(d.state + slot * (int64_t)d.S), d.S * 4, in.vec_state, part, parts);
+    if (d.A) copy_row((const uint8_t*)(in.policy + (int64_t)k * d.A), (uint8_t*)(d.policy + slot * (int64_t)d.A), d.A * 4, in.vec_policy, part, parts);
+    return;
+  }
+  if (blockIdx.x) return;
+  for (int i = threadIdx.x; i < K; i += 1024) {
+    const int64_t sl = slot_of(d, s_env[i], s_off[i]);
+    if (d.has_init) d.initials[sl] = in.initials[i];
+    d.actions[sl] = in.actions[i];
+    d.rewards[sl] = in.rewards[i];
+    d.dones[sl] = in.dones[i] ? 1 : 0;
+    if (d.per) { d.loss[sl] = MIRL_LOSS_FRESH; d.prio_index[sl] = -1; d.stamp[sl] = 0ull; }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_table; i += 1024) d.prio_index[slot_of(d, tops[i].env, tops[i].off)] = tops[i].value;
+  for (int i = threadIdx.x; i < n_env; i += 1024) { d.first[eops[i].env] = eops[i].first; d.count[eops[i].env] = eops[i].count; }
+  for (int i = threadIdx.x; i < n_leaf; i += 1024) {
+    const LeafOp op = lops[i];
+    const int64_t leaf = d.cap + op.slot;
+    if (op.activate) {
+      d.slot_env[op.slot] = op.env; d.slot_base[op.slot] = op.base;
+      TV p = priority_of(d, op.env, op.base);
+      d.tv[leaf] = p.v; d.tk[leaf] = p.k;
+      if (d.tmin) d.tmin[leaf] = p.v;
+    } else {
+      d.slot_env[op.slot] = -1; d.slot_base[op.slot] = -1;
+      d.tv[leaf] = 0.0; d.tk[leaf] = KW;
+      if (d.tmin) d.tmin[leaf] = INFINITY;
+    }
+    const int at = atomicAdd(d.dirty_count, 1);
+    d.dirty[at] = op.slot;
+  }
+  if (n_leaf) {                                   // uniform over the workgroup
+    __threadfence_block();
+    __syncthreads();
+    tree_fix_body(d);
+  }
 }
 
 // full rebuild of one level (test hook mirl_replay_tree_set_leaves)
@@ -220,21 +300,7 @@ __global__ void k_set_leaves(Dev d, int64_t n, const double* v, const uint8_t* k
 // ---------------------------------------------------------------------------
 // sampling
 // ---------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al., SC'11) for the device-RNG mode.
-__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ double philox_u53(uint64_t seed, uint64_t call, uint32_t lane) {
-  uint32_t c[4] = {lane, (uint32_t)call, (uint32_t)(call >> 32), 0x52544D45u};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-  // 53-bit uniform in [0,1) like MT19937's genrand_res53
-  return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
-}
+// Philox4x32-10 for the device-RNG mode: philox.hpp
 
 // _refine_sample_range (replay_history.py:142-171) on absolute offsets.
 __device__ __forceinline__ int64_t refine_start(const Dev& d, int32_t e, int64_t start) {
@@ -1004,6 +1070,9 @@ static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s
 
 static int update_losses_impl(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, hipStream_t st);
 
+static int g_ingest_fused = -1;     // -1: take MIRL_INGEST_FUSED (default on) at the first ingest
+extern "C" int mirl_ingest_fused_set(int32_t on) { g_ingest_fused = on ? 1 : 0; return MIRL_OK; }
+
 extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream) {
   if (!h || !in || in->count <= 0) return fail(MIRL_ERR_ARG, "bad ingest arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -1031,6 +1100,26 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   rc = h->staging.upload(total, st); if (rc) return rc;
   const int32_t* s_env = (const int32_t*)(db + o_env);
   const int64_t* s_off = (const int64_t*)(db + o_off);
+  if (g_ingest_fused < 0) g_ingest_fused = (getenv("MIRL_INGEST_FUSED") && atoi(getenv("MIRL_INGEST_FUSED")) == 0) ? 0 : 1;
+  if (g_ingest_fused && !d.planes && !(h->book.cfg.acting_priority_init && d.per)) {
+    auto vec_ok = [](const void* src, const void* dst, int64_t row_bytes, int64_t src_stride, int64_t dst_stride) {
+      return (int)(row_bytes && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0 &&
+                   ((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0);
+    };
+    IngestSrc src{in->frames, in->extra, in->state, in->policy, in->initials, in->actions, in->rewards, in->dones,
+                  vec_ok(in->frames, d.frames, d.F, d.F, d.Fp), vec_ok(in->extra, d.extra, d.X * 4, d.X * 4, d.X * 4),
+                  vec_ok(in->state, d.state, d.S * 4, d.S * 4, d.S * 4), vec_ok(in->policy, d.policy, d.A * 4, d.A * 4, d.A * 4)};
+    const int nt = d.per ? (int)p.table_ops.size() : 0, ne = (int)p.env_ops.size(), nl = d.per ? (int)p.leaf_ops.size() : 0;
+    // 16 KB per copy workgroup: a (4, 84, 84) frame row takes 2
+    int parts = (int)((d.F + 16383) / 16384); if (parts < 1) parts = 1; if (parts > 8) parts = 8;
+    {
+      ProfScope ps("k_ingest_fused", 2.0 * K * ((double)d.F + 4.0 * (d.X + d.S + d.A) + 13 + (d.per ? 16 : 0)), st);
+      hipLaunchKernelGGL(k_ingest_fused, dim3(parts, K + 1), dim3(1024), 0, st, d, K, src, s_env, s_off, nt, (const TableOp*)(db + o_tab),
+                         ne, (const EnvOp*)(db + o_eop), nl, (const LeafOp*)(db + o_lop));
+    }
+    MIRL_LAUNCH_CHECK();
+    return h->staging.mark(st);
+  }
   if (d.planes) {
     // de-dup: verify the stack-shift contract against the stored planes, record the
     // depth, keep the newest plane only

@@ -208,6 +208,8 @@ class ReplayHistoryBuffer(History):
         """history.py:123-176.  ``new_samples`` is the list of per-env sample
         dicts the actor emits (acting_interface.py:83-90); it is regrouped into
         vector steps and written with one batched device copy each."""
+        if getattr(new_samples, "ingested", False):     # acting/fast_step.py: the actor wrote the steps itself
+            return {}
         if hasattr(new_samples, "vector_steps"):        # acting_interface.DeviceSamples
             if self._h is None:
                 pol = new_samples.vector_steps[0].get("policy")
@@ -277,7 +279,7 @@ class ReplayHistoryBuffer(History):
         self.update_batch(env_ids=env_ids, **dev)
 
     def update_batch(self, frames, actions, rewards, dones, extra=None, state=None,
-                     initials=None, policy=None, env_ids=None):
+                     initials=None, policy=None, env_ids=None, transient=False):
         """Fast path: one vector step of device tensors with leading dim K
         (frames u8 [K, ...], actions i32 [K], rewards f32 [K], dones u8 [K],
         extra/state/policy f32 [K, n], initials f32 [K]).  ``env_ids`` (host
@@ -302,10 +304,12 @@ class ReplayHistoryBuffer(History):
             rewards=_ptr(rewards), dones=_ptr(dones))
         check(lib.mirl_replay_ingest(self._h, C.byref(arg), _stream()), "mirl_replay_ingest")
         # the kernels read the payload asynchronously: tie its lifetime to the stream
-        s = torch.cuda.current_stream()
-        for t in keep:
-            if t is not None:
-                t.record_stream(s)
+        # (transient=True: the caller owns long-lived buffers it only rewrites in stream order)
+        if not transient:
+            s = torch.cuda.current_stream()
+            for t in keep:
+                if t is not None:
+                    t.record_stream(s)
 
     def configure(self, example_state, num_envs, env_base=0, policy_f32=0):
         """Create the shard up-front from one example ``next_state`` pytree

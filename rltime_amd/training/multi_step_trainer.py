@@ -100,6 +100,9 @@ class MultiStepTrainer(PolicyTrainer):
             **mode.get("args", {}), nstep_target=nstep_target, nstep_train=nstep_train,
             prefix_steps=prefix_steps, discount_function=self._get_discount_function(self.gamma),
             state_store=self.policy.get_state_store(async_history))
+        if getattr(self.actors, "_device_mode", False) and hasattr(self.actors, "set_sink"):
+            # the device actor's fused vector step writes straight into the device replay
+            self.actors.set_sink(self.history_buffer, clip_rewards=self.clip_rewards)
         dp = self.data_parallel
         if getattr(self, "global_sampling", False) and dp is not None and dp.active \
                 and hasattr(self.history_buffer, "enable_global_sampling"):

@@ -1,0 +1,142 @@
+"""GPU: the fused acting vector step (acting/fast_step.py + csrc/acting.hip k_actor_pre,
+in-kernel-RNG head) and the one-launch ingest (csrc/replay.hip k_ingest_fused) against the
+generic device path they replace (reference order: rltime/acting/actor.py:108-147,
+history.py:123-176)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NATURE = {"type": "cnn", "args": {"channels_last": True, "layers": [
+    {"filters": 32, "kernel": 8, "stride": 4}, {"filters": 64, "kernel": 4, "stride": 2}, {"filters": 64, "kernel": 3, "stride": 1}]}}
+MODEL = {"type": "sequential", "args": {"layer_configs": [
+    NATURE, {"type": "lstm", "args": {"num_units": 64}}, {"type": "fc", "args": {"fc_size": 64}}]}}
+EXPL = {"type": "epsilon_greedy", "args": {"eps_start": 0.3, "eps_final": 0.3, "exploration_fraction": 0.5}}
+
+
+def _make(kind, E, fast, exploration=None, seed=5, use_graph=True):
+    from rltime_amd.acting.actor import Actor
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    from rltime_amd.policies.dqn import DQNPolicy
+    from rltime_amd.policies.iqn import IQNPolicy
+    torch.manual_seed(0)
+    env = SyntheticAtariVecEnv(E, frame_shape=(4, 84, 84), n_actions=6, seed=seed, done_prob=0.05)
+    kw = dict(model_config=MODEL, observation_space=env.observation_space, action_space=env.action_space, dueling=True)
+    pol = IQNPolicy.create(embedding_dim=16, num_sampling_quantiles=8, **kw) if kind == "iqn" else DQNPolicy.create(**kw)
+    if kind == "iqn":
+        g = torch.Generator().manual_seed(9)
+        fixed = torch.rand(E * 8, generator=g).cuda()
+        pol.tau_source = lambda n: fixed[:n]                 # the same quantile fractions on both paths
+    actor = Actor(env, exploration_config=exploration, device=True, use_graph=use_graph)
+    actor.fast_step = fast
+    actor.set_actor_policy(pol)
+    return actor, pol, env
+
+
+@pytest.mark.parametrize("kind", ["dqn", "iqn"])
+def test_fused_step_matches_the_generic_device_path(kind):
+    """Greedy acting (no exploration noise): the fused step and the generic graph path emit the same
+    frames / rewards / dones, the same actions, and q-values / stored recurrent state within the
+    rounding of one merged GEMM ([features | h] x [W_ih | W_hh]^T)."""
+    E, steps = 32, 7
+    outs = []
+    for fast in (True, False):
+        actor, pol, env = _make(kind, E, fast)
+        batch = actor.get_samples(E * 3)
+        more = actor.get_samples(E * (steps - 3))            # a second call: re-selection with the "current" weights
+        assert (actor._fast is not None and actor._fast is not False) == fast
+        outs.append(batch.vector_steps + more.vector_steps)
+    assert len(outs[0]) == len(outs[1]) == steps
+    for t, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a["frames"], b["frames"]) and torch.equal(a["dones"], b["dones"]), t
+        assert torch.equal(a["rewards"], b["rewards"]) and torch.equal(a["initials"], b["initials"]), t
+        np.testing.assert_allclose(a["policy"].cpu().numpy(), b["policy"].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg="q %d" % t)
+        np.testing.assert_allclose(a["state"].cpu().numpy(), b["state"].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg="state %d" % t)
+        # actions agree wherever the greedy choice is not a near-tie
+        q = b["policy"].cpu()
+        top2 = q.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(a["actions"].cpu()[clear], b["actions"].cpu()[clear]), t
+        # a reset env stores a zero recurrent state
+        assert torch.all(a["state"][a["dones"].bool()] == 0)
+
+
+def test_fused_step_epsilon_greedy_draws():
+    """In-kernel Philox draws: the explored fraction matches epsilon, random actions are uniform,
+    different steps / envs draw differently, and greedy envs still take the arg-max."""
+    E = 256
+    actor, pol, env = _make("dqn", E, True, exploration=EXPL)
+    steps = actor.get_samples(E * 40).vector_steps
+    acts = torch.stack([s["actions"] for s in steps]).cpu()
+    greedy = torch.stack([s["policy"].argmax(1) for s in steps]).cpu().to(torch.int32)
+    explored = (acts != greedy).float().mean().item()
+    # per-actor epsilon = eps ** (1 + i / (N - 1) * 7): between eps^8 and eps; random picks hit the greedy action 1 / 6 of the time
+    expo = actor._exploration._device_exponents(actor._env_ids, acts.device).cpu().double()
+    want = ((0.3 ** expo).clamp(min=actor._exploration.eps_min) * (5.0 / 6.0)).mean().item()
+    assert abs(explored - want) < 0.02, (explored, want)
+    rand_acts = acts[acts != greedy]
+    counts = torch.bincount(rand_acts.long(), minlength=6).float()
+    assert counts.min() > 0 and (counts.max() / counts.sum()) < 0.4
+    assert not torch.equal(acts[3], acts[4])
+
+
+@pytest.mark.parametrize("per", [False, True])
+def test_direct_ingest_equals_tensor_hand_over(per):
+    """Actor.set_sink: the fused step writing straight into the replay leaves exactly the shard that
+    feeding the same DeviceSamples through History.update leaves (frames, state, scalars, tree)."""
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer, ReplayHistoryBuffer
+    E, calls = 16, 5
+    shards = []
+    for direct in (True, False):
+        actor, pol, env = _make("dqn", E, True)
+        kw = dict(size=E * 40, train_frequency=4, nstep_target=2, nstep_train=4, prefix_steps=2, gamma=0.99,
+                  device_rng=True, keep_policy_outputs=True)
+        hist = PrioritizedReplayHistoryBuffer(alpha=0.9, beta=0.6, **kw) if per else ReplayHistoryBuffer(**kw)
+        if direct:
+            actor.set_sink(hist)
+        for _ in range(calls):
+            s = actor.get_samples(E * 6)
+            assert bool(getattr(s, "ingested", False)) == direct
+            hist.update(s)
+        batch = hist.get_train_data(8, train_progress=0.5)
+        shards.append((batch, hist.stats(), hist.tree_nodes() if per else None))
+        hist.close()
+    (ba, sa, ta), (bb, sb, tb) = shards
+    assert sa == sb
+    flat = lambda tree: [tree] if isinstance(tree, torch.Tensor) else [x for v in (tree.values() if isinstance(tree, dict) else tree) for x in flat(v)] if tree is not None else []   # noqa: E731
+    for x, y in zip(flat(ba), flat(bb)):
+        assert torch.equal(x, y)
+    if per:
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x, y)
+
+
+def test_fused_ingest_kernel_equals_the_separate_kernels():
+    """mirl_replay_ingest as ONE launch against the scatter / scalars / plan / tree-fix launches of
+    rounds 1-2 on a ragged prioritized stream with evictions: identical shards."""
+    from rltime_amd._lib import lib, check
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
+    res = []
+    try:
+        for fused in (1, 0):
+            check(lib.mirl_ingest_fused_set(fused))
+            spec = StreamSpec(seed=12, num_envs=6, frame_shape=(2, 9, 7), lstm_units=4, n_actions=3, done_prob=0.1)
+            buf = PrioritizedReplayHistoryBuffer(size=90, train_frequency=0, nstep_target=2, nstep_train=4, prefix_steps=1,
+                                                 alpha=0.8, beta=0.5, gamma=0.97, device_rng=True)
+            for st in vector_steps(spec, 60):
+                buf.update(as_reference_samples(spec, st))
+            batch = buf.get_train_data(5, train_progress=0.3)
+            res.append((batch, buf.stats(), buf.tree_nodes(), buf.free_slots(), buf.slot_table()))
+            buf.close()
+    finally:
+        check(lib.mirl_ingest_fused_set(1))
+    (ba, sa, ta, fa, la), (bb, sb, tb, fb, lb) = res
+    assert sa == sb and np.array_equal(fa, fb) and all(np.array_equal(x, y) for x, y in zip(la, lb))
+    assert all(np.array_equal(x, y) for x, y in zip(ta, tb))
+    flat = lambda tree: [tree] if isinstance(tree, torch.Tensor) else [x for v in (tree.values() if isinstance(tree, dict) else tree) for x in flat(v)] if tree is not None else []   # noqa: E731
+    for x, y in zip(flat(ba), flat(bb)):
+        assert torch.equal(x, y)

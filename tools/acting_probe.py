@@ -17,7 +17,7 @@ class A:
     train_arg, frame_dedup = [], False
 
 
-cfg = bench.build_config(A, 0, 1)
+cfg = bench.build_config(A, 0, 1, "strong")
 trainer = bench.build_trainer(cfg, torch.device("cuda", 0), use_graph="--eager" not in sys.argv, data_parallel=None)
 actors, hist = trainer.actors, trainer.history_buffer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200

@@ -109,6 +109,22 @@ PY
     ;;
     lstm)    timeout 900 python -m pytest tests/test_lstm_gpu.py -x -q --timeout 300 -k "lstm or persistent" > "$OUT/pytest_lstm.log" 2>&1; echo "pytest lstm rc=$?"; tail -15 "$OUT/pytest_lstm.log"
              timeout 300 python tools/lstm_probe.py > "$OUT/lstm_probe.jsonl" 2> "$OUT/lstm_probe.err"; echo "lstm probe rc=$?"; cat "$OUT/lstm_probe.jsonl"; tail -3 "$OUT/lstm_probe.err";;
+    acttrace) R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$R/$OUT/act_trace" -o act -- python "$R/tools/acting_probe.py" 60 > "$R/$OUT/acting_probe_trace.json" 2> "$R/$OUT/acting_probe_trace.err"); echo "acttrace rc=$?"; cat "$OUT/acting_probe_trace.json"; python - "$OUT" <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/act_trace/**/*kernel_trace.csv", recursive=True)
+rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+# one steady-state vector step = from one k_episode_track to the next, near the end of the acting loop
+idx = [i for i, n in enumerate(names) if "k_episode_track" in n]
+a, b = idx[-12], idx[-11]
+print("kernels in one acting vector step:", b - a)
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
+    print("%8.1f %7.1f  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Kernel_Name"][:120]))
+print("step span us", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3)
+PY
+      find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
+    fast)    timeout 900 python -m pytest tests/test_fast_acting_gpu.py tests/test_train_loop_gpu.py tests/test_ingest_paths_gpu.py tests/test_replay_gpu.py -x -q --timeout 300 > "$OUT/pytest_fast.log" 2>&1; echo "pytest fast rc=$?"; tail -25 "$OUT/pytest_fast.log";;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
