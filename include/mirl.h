@@ -456,6 +456,11 @@ int mirl_relu_bwd_bias_rows(int64_t rows, int32_t C, const float* dy, const floa
 /* IQN cosine embedding (rltime/policies/torch/iqn.py:78-81): phi[r][i] =
  * cos(tau[r] * freq[i]), freq = embedding_range * pi (float32), D % 4 == 0.       */
 int mirl_cos_embed(int64_t rows, int32_t D, const float* tau, const float* freq, float* phi, void* stream);
+/* The same features with the quantile fractions drawn inside the kernel (Philox4x32-10 keyed by
+ * (seed, *step, row), 24-bit uniforms in [0, 1) as torch.rand draws them): the device actor's
+ * IQN forward without a torch.rand launch per vector step.  tau_out (rows floats) may be NULL.  */
+int mirl_cos_embed_rng(int64_t rows, int32_t D, uint64_t seed, const uint64_t* step, const float* freq,
+                       float* phi, float* tau_out, void* stream);
 /* IQN feature product (iqn.py:84,102): out[m*N+n][c] = x[m][c] * emb[m*N+n][c].   */
 int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const float* emb, float* out, void* stream);
 /* its backward fused with the ReLU mask and bias gradient of the embedding layer
@@ -493,8 +498,10 @@ int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv, const flo
                     int32_t* actions, float* qvalues, float* eps_used, void* stream);
 /* The same head with its epsilon-greedy draws made inside the kernel (one Philox4x32-10
  * block per (step, env), keyed by rng_seed and the device word *rng_step that
- * mirl_actor_pre advances): no torch.rand / torch.randint launches per vector step.   */
-int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
+ * mirl_actor_pre advances): no torch.rand / torch.randint launches per vector step.
+ * adv rows are adv_pitch floats apart and val rows Q floats apart, so both may be column
+ * blocks of one (rows, A + q) output GEMM (val = adv + A, Q = adv_pitch).                */
+int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, int32_t adv_pitch, const float* val, int32_t Q,
                         const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
                         const uint64_t* rng_step, int32_t* actions, float* qvalues, float* eps_used, void* stream);
 /* Everything between env.step and the policy forward of the device-resident actor in ONE

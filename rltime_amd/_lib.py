@@ -162,11 +162,12 @@ _SIGNATURES = {
     "mirl_colsum_blocks": [_i64, _i32, _P(_i32)],
     "mirl_relu_bwd_bias_rows": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_cos_embed": [_i64, _i32, _vp, _vp, _vp, _vp],
+    "mirl_cos_embed_rng": [_i64, _i32, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_iqn_mul_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_iqn_mul_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_dueling_tail_bwd": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
+    "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_actor_pre": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                        _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

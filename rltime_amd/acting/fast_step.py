@@ -133,6 +133,13 @@ class FastActingStep:
         self.h1 = h1
         self.fc_w = torch.empty((h1 + hv, self.fc.in_features), **f32)
         self.fc_b = torch.empty(h1 + hv, **f32)
+        # advantage and value outputs as ONE GEMM over the joint hidden activation: block-diagonal weights
+        self.na, self.nq = pol.out_layer.out_features, pol.value_layer.out_features
+        assert self.na == A and self.nq == 1
+        self.out_w = torch.zeros((self.na + self.nq, h1 + hv), **f32)
+        self.out_b = torch.zeros(self.na + self.nq, **f32)
+        self.freq = (pol.embedding_range * np.pi).contiguous() if self.iqn else None
+        self.in_kernel_taus = self.iqn and getattr(pol, "tau_source", None) is None
         expl = actor._exploration
         self.expo = expl._device_exponents(actor._env_ids, dev) if expl is not None else None
         self.eps_min = float(expl.eps_min) if expl is not None else 0.0
@@ -159,6 +166,11 @@ class FastActingStep:
             self.fc_w[self.h1:].copy_(pol.value_hidden_layer.weight)
             self.fc_b[:self.h1].copy_(self.fc.bias)
             self.fc_b[self.h1:].copy_(pol.value_hidden_layer.bias)
+            na = self.na
+            self.out_w[:na, :self.h1].copy_(pol.out_layer.weight)
+            self.out_w[na:, self.h1:].copy_(pol.value_layer.weight)
+            self.out_b[:na].copy_(pol.out_layer.bias)
+            self.out_b[na:].copy_(pol.value_layer.bias)
 
     def set_eps(self, eps):
         self.eps.fill_(eps)
@@ -176,11 +188,13 @@ class FastActingStep:
             _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
             _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), self.step_no, _stream()), "mirl_actor_pre")
 
-    def _conv1(self, obs):
+    def _conv1(self, obs, packed=False):
+        """packed=True: self.wpk still holds the current weights (packed by the call's re-selection)."""
         c1 = self.cnn.layers[0]
         so, sc, sh, sw = c1.weight.stride()
-        check(lib.mirl_conv1_u8_fwd(obs.shape[0], obs.shape[2], obs.shape[3], _p(obs), _p(c1.weight), so, sc, sh, sw, _p(c1.bias),
-                                    float(self.cnn.scale), _p(self.wpk), _p(self.y1), _stream()), "mirl_conv1_u8_fwd")
+        check(lib.mirl_conv1_u8_fwd_ex(obs.shape[0], obs.shape[2], obs.shape[3], _p(obs), _p(c1.weight), so, sc, sh, sw, _p(c1.bias),
+                                       float(self.cnn.scale), _p(self.wpk), _p(self.y1), 8 if packed else 0, _stream()),
+              "mirl_conv1_u8_fwd")
 
     def _body(self):
         """conv 2.. -> LSTM step -> head; reads y1 / xh tail / c_in, writes h, c, actions, qvalues."""
@@ -195,18 +209,22 @@ class FastActingStep:
               "mirl_lstm_cell_fwd")
         feat = self.h
         if self.iqn:
-            taus = pol._draw_taus(E * N)
-            phi = cos_embed(taus, pol.embedding_range * np.pi)
+            if self.in_kernel_taus:
+                phi = torch.empty((E * N, self.freq.shape[0]), dtype=torch.float32, device=self.dev)
+                check(lib.mirl_cos_embed_rng(E * N, self.freq.shape[0], self.rng_seed, _p(self.rng_step), _p(self.freq), _p(phi),
+                                             None, _stream()), "mirl_cos_embed_rng")
+            else:                                            # a test's tau_source replaces the draw
+                phi = cos_embed(pol._draw_taus(E * N), self.freq)
             emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
             prod = torch.empty_like(emb)
             check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(prod), _stream()), "mirl_iqn_mul_fwd")
             feat = prod
         both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
-        adv = torch.addmm(pol.out_layer.bias, both[:, :self.h1], pol.out_layer.weight.t())
-        val = torch.addmm(pol.value_layer.bias, both[:, self.h1:], pol.value_layer.weight.t())
+        outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
+        pitch = self.na + self.nq
         greedy = self.expo is None
         check(lib.mirl_actor_head_rng(
-            E, N, self.A, _p(adv), _p(val), val.shape[1], None if greedy else _p(self.eps), None if greedy else _p(self.expo),
+            E, N, self.A, _p(outs), pitch, C.c_void_p(outs.data_ptr() + 4 * self.na), pitch, None if greedy else _p(self.eps), None if greedy else _p(self.expo),
             self.eps_min, self.rng_seed, None if greedy else _p(self.rng_step), _p(self.actions), _p(self.qvalues), None, _stream()),
             "mirl_actor_head_rng")
 
@@ -249,7 +267,7 @@ class FastActingStep:
             fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
                           policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)
         self.last_obs = obs
-        self._conv1(obs)
+        self._conv1(obs, packed=True)
         self.graph.replay()
         return fields
 

@@ -38,7 +38,7 @@ k_actor_head(int E, int N, int A, const float* __restrict__ adv, const float* __
              const double* __restrict__ eps, const double* __restrict__ expo, double eps_min,
              const float* __restrict__ u, const int64_t* __restrict__ rnd,
              int32_t* __restrict__ actions, float* __restrict__ qvalues, float* __restrict__ eps_used,
-             uint64_t rng_seed, const uint64_t* __restrict__ rng_step) {
+             uint64_t rng_seed, const uint64_t* __restrict__ rng_step, int adv_pitch) {
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= E) return;
@@ -48,7 +48,7 @@ k_actor_head(int E, int N, int A, const float* __restrict__ adv, const float* __
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
     for (int n = lane; n < N; n += 64) {
-      const float* row = adv + ((int64_t)e * N + n) * A;
+      const float* row = adv + ((int64_t)e * N + n) * adv_pitch;
       float off = 0.f;
       if (val) {                                        // dueling: V + A - mean_a A
         float m = 0.f;
@@ -153,14 +153,14 @@ extern "C" int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewa
   return MIRL_OK;
 }
 
-extern "C" int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, const float* val, int32_t Q,
+extern "C" int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, int32_t adv_pitch, const float* val, int32_t Q,
                                    const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
                                    const uint64_t* rng_step, int32_t* actions, float* qvalues, float* eps_used, void* stream) {
-  if (E <= 0 || N <= 0 || A <= 0 || !adv || !actions || !qvalues || (eps && !rng_step) || (val && Q <= 0))
+  if (E <= 0 || N <= 0 || A <= 0 || adv_pitch < A || !adv || !actions || !qvalues || (eps && !rng_step) || (val && Q <= 0))
     return mirl::fail(MIRL_ERR_ARG, "bad actor_head_rng arguments");
   mirl::ProfScope ps("k_actor_head", 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(mirl::k_actor_head, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, (int)E, (int)N, (int)A, adv, val, (int)Q,
-                     eps, expo, eps_min, (const float*)nullptr, (const int64_t*)nullptr, actions, qvalues, eps_used, rng_seed, rng_step);
+                     eps, expo, eps_min, (const float*)nullptr, (const int64_t*)nullptr, actions, qvalues, eps_used, rng_seed, rng_step, (int)adv_pitch);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
@@ -172,7 +172,7 @@ extern "C" int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv
     return mirl::fail(MIRL_ERR_ARG, "bad actor_head arguments");
   mirl::ProfScope ps("k_actor_head", 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(mirl::k_actor_head, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, (int)E, (int)N, (int)A, adv, val, (int)Q,
-                     eps, expo, eps_min, u, rnd, actions, qvalues, eps_used, (uint64_t)0, (const uint64_t*)nullptr);
+                     eps, expo, eps_min, u, rnd, actions, qvalues, eps_used, (uint64_t)0, (const uint64_t*)nullptr, (int)A);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

@@ -349,7 +349,8 @@ extern "C" int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t 
   return C1_PLANES * c1_pitch(H * W) <= 64 * 1024 ? 1 : 0;
 }
 
-// flags: bit 0 = plain (cached) output stores instead of non-temporal ones; bit 2 = byte->float
+// flags: bit 0 = plain (cached) output stores instead of non-temporal ones; bit 3 = skip the weight
+// packing (wpk was packed by an earlier call with the same weights and scale); bit 2 = byte->float
 // conversions interleaved with the MFMA chain instead of hoisted in front of it; bits 8.. =
 // frames per LDS fill override (1 or 2), bits 16.. = split override; bits 24-26 =
 // timing-experiment variants (see the kernel).
@@ -364,7 +365,7 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   hipStream_t st = (hipStream_t)stream;
   const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
   const int tiles = (OH * OW + 15) / 16;
-  {
+  if (!(flags & 8)) {                                     // bit 3: wpk already holds these weights packed (acting steps between updates)
     ProfScope ps("k_conv1_pack_w", 2.0 * C1_WPK * 4, st);
     hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, wpk);
     MIRL_LAUNCH_CHECK();

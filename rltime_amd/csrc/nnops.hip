@@ -18,6 +18,7 @@
 // deterministic (fixed partition, fixed order — no float atomics), so repeated
 // runs give bit-identical gradients.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace mirl {
 
@@ -121,6 +122,25 @@ k_cos_embed(const float* __restrict__ tau, const nn_f4* __restrict__ w, nn_f4* _
   nn_f4 r;
   r.x = cosf(ww.x * t); r.y = cosf(ww.y * t); r.z = cosf(ww.z * t); r.w = cosf(ww.w * t);
   phi[i] = r;
+}
+
+// The same features with tau drawn inside the kernel (Philox4x32-10 keyed by (seed, *step, row);
+// 24-bit uniforms in [0, 1) like torch.rand): the acting path's quantile fractions without a
+// torch.rand launch (and its two graph-RNG bookkeeping fills) per vector step.
+__global__ void __launch_bounds__(256)
+k_cos_embed_rng(uint64_t seed, const uint64_t* __restrict__ step, const nn_f4* __restrict__ w, nn_f4* __restrict__ phi,
+                float* __restrict__ tau_out, int64_t n4, int DQ) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int64_t row = i / DQ;
+  uint32_t r[4];
+  philox_4x32(seed ^ 0x7A5ull, *step, (uint32_t)row, r);
+  const float t = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+  const nn_f4 ww = w[i % DQ];
+  nn_f4 o;
+  o.x = cosf(ww.x * t); o.y = cosf(ww.y * t); o.z = cosf(ww.z * t); o.w = cosf(ww.w * t);
+  phi[i] = o;
+  if (tau_out && i % DQ == 0) tau_out[row] = t;
 }
 
 // out[(m*N+n)][c] = x[m][c] * emb[(m*N+n)][c]   (iqn.py:84,102 without the repeated copy of x).
@@ -356,6 +376,19 @@ extern "C" int mirl_cos_embed(int64_t rows, int32_t D, const float* tau, const f
   if (blocks >= (1LL << 31)) return fail(MIRL_ERR_ARG, "cos_embed: tensor too large for one launch");
   ProfScope ps("k_cos_embed", (double)rows * (D * 4 + 4), st);
   hipLaunchKernelGGL(k_cos_embed, dim3((unsigned)blocks), dim3(256), 0, st, tau, (const nn_f4*)freq, (nn_f4*)phi, n4, D / 4);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_cos_embed_rng(int64_t rows, int32_t D, uint64_t seed, const uint64_t* step, const float* freq, float* phi,
+                                  float* tau_out, void* stream) {
+  if (rows <= 0 || rows >= (1LL << 32) || D <= 0 || (D % 4) || !step || !freq || !phi || !aligned16(freq) || !aligned16(phi))
+    return fail(MIRL_ERR_ARG, "bad cos_embed_rng arguments (embedding_dim must be a multiple of 4)");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n4 = rows * (D / 4), blocks = (n4 + 255) / 256;
+  if (blocks >= (1LL << 31)) return fail(MIRL_ERR_ARG, "cos_embed_rng: tensor too large for one launch");
+  ProfScope ps("k_cos_embed", (double)rows * (D * 4 + 4), st);
+  hipLaunchKernelGGL(k_cos_embed_rng, dim3((unsigned)blocks), dim3(256), 0, st, seed, step, (const nn_f4*)freq, (nn_f4*)phi, tau_out, n4, D / 4);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

@@ -140,3 +140,29 @@ def test_fused_ingest_kernel_equals_the_separate_kernels():
     flat = lambda tree: [tree] if isinstance(tree, torch.Tensor) else [x for v in (tree.values() if isinstance(tree, dict) else tree) for x in flat(v)] if tree is not None else []   # noqa: E731
     for x, y in zip(flat(ba), flat(bb)):
         assert torch.equal(x, y)
+
+
+def test_in_kernel_quantile_fractions():
+    """mirl_cos_embed_rng: tau ~ U[0, 1) drawn in the kernel (Philox keyed by seed, step, row) and the
+    cos features of exactly those taus (iqn.py:76-81); a new step draws new fractions."""
+    from rltime_amd._lib import lib, check
+    rows, D = 8192, 64
+    freq = (torch.arange(1, D + 1, dtype=torch.float32, device="cuda") * np.pi).contiguous()
+    step = torch.tensor([3], dtype=torch.int64, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())                     # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for s in (3, 3, 4):
+        step.fill_(s)
+        phi = torch.empty((rows, D), device="cuda")
+        tau = torch.empty(rows, device="cuda")
+        check(lib.mirl_cos_embed_rng(rows, D, 1234, p(step), p(freq), p(phi), p(tau), st))
+        outs.append((phi, tau))
+    assert torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[0][1], outs[2][1])
+    phi, tau = outs[0]
+    assert 0.0 <= float(tau.min()) and float(tau.max()) < 1.0
+    assert abs(float(tau.mean()) - 0.5) < 0.02 and abs(float(tau.var()) - 1.0 / 12.0) < 0.01
+    hist = torch.histc(tau, bins=16, min=0, max=1)
+    assert float(hist.min()) > rows / 16 * 0.8
+    want = torch.cos(freq * tau.unsqueeze(1))
+    assert torch.allclose(phi, want, rtol=0, atol=2e-6)

@@ -115,7 +115,7 @@ f = glob.glob(sys.argv[1] + "/act_trace/**/*kernel_trace.csv", recursive=True)
 rows = sorted(csv.DictReader(open(f[0])), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # one steady-state vector step = from one k_episode_track to the next, near the end of the acting loop
-idx = [i for i, n in enumerate(names) if "k_episode_track" in n]
+idx = [i for i, n in enumerate(names) if ("k_actor_pre" in n or "k_episode_track" in n)]
 a, b = idx[-12], idx[-11]
 print("kernels in one acting vector step:", b - a)
 t0 = int(rows[a]["Start_Timestamp"])
