@@ -461,7 +461,8 @@ int mirl_cos_embed(int64_t rows, int32_t D, const float* tau, const float* freq,
  * IQN forward without a torch.rand launch per vector step.  tau_out (rows floats) may be NULL.  */
 int mirl_cos_embed_rng(int64_t rows, int32_t D, uint64_t seed, const uint64_t* step, const float* freq,
                        float* phi, float* tau_out, void* stream);
-/* IQN feature product (iqn.py:84,102): out[m*N+n][c] = x[m][c] * emb[m*N+n][c].   */
+/* IQN feature product (iqn.py:84,102): out[m*N+n][c] = x[m][c] * emb[m*N+n][c]; out may be emb
+ * itself (no-grad passes: one read-modify-write stream instead of two streams).          */
 int mirl_iqn_mul_fwd(int64_t M, int32_t N, int32_t C, const float* x, const float* emb, float* out, void* stream);
 /* its backward fused with the ReLU mask and bias gradient of the embedding layer
  * (emb = relu(pre)):  d_pre = emb > 0 ? g * x[m] : 0,  dx[m] = sum_n g * emb,
@@ -523,6 +524,8 @@ int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t
 
 /* ---- device copy micro-benchmark used by bench.py for the measured HBM peak */
 int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream);
+/* nt = 0: grid-stride copy with cached accesses; 1: one 16 B chunk per lane, non-temporal (bench.py reports the better one). */
+int mirl_copy_bytes_ex(void* dst, const void* src, int64_t bytes, int32_t nt, void* stream);
 
 /* ---- host-only hooks (no GPU needed; used by the CPU test-suite) ----------
  * A bookkeeping-only replay (rings, FIFO, free list, activation) that records

@@ -172,6 +172,7 @@ _SIGNATURES = {
                        _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_copy_bytes": [_vp, _vp, _i64, _vp],
+    "mirl_copy_bytes_ex": [_vp, _vp, _i64, _i32, _vp],
     "mirl_book_create": [_P(ReplayConfig), _P(_vp)],
     "mirl_book_destroy": [_vp],
     "mirl_book_ingest": [_vp, _i32, _vp],

@@ -216,9 +216,8 @@ class FastActingStep:
             else:                                            # a test's tau_source replaces the draw
                 phi = cos_embed(pol._draw_taus(E * N), self.freq)
             emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
-            prod = torch.empty_like(emb)
-            check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(prod), _stream()), "mirl_iqn_mul_fwd")
-            feat = prod
+            check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(emb), _stream()), "mirl_iqn_mul_fwd")   # in place
+            feat = emb
         both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
         outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
         pitch = self.na + self.nq

@@ -459,6 +459,6 @@ extern "C" int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8
 extern "C" int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
                                  float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
                                  void* stream) {
-  static const int flags = getenv("MIRL_CONV1_WRW_FLAGS") ? atoi(getenv("MIRL_CONV1_WRW_FLAGS")) : 1;
+  static const int flags = getenv("MIRL_CONV1_WRW_FLAGS") ? atoi(getenv("MIRL_CONV1_WRW_FLAGS")) : 0;   // hoisted conversions: 2.60 vs 2.66 ms per 42 496 frames (profiles/r03)
   return mirl_conv1_u8_wrw_ex(N, H, W, x, g, scale, scratch, dw, ws_o, ws_c, ws_h, ws_w, flags, stream);
 }

@@ -1673,14 +1673,18 @@ extern "C" int mirl_replay_losses_peek(mirl_replay* h, int32_t env_local, int64_
   return MIRL_OK;
 }
 
-extern "C" int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
+extern "C" int mirl_copy_bytes_ex(void* dst, const void* src, int64_t bytes, int32_t nt, void* stream) {
   if (!dst || !src || bytes <= 0 || (bytes % 16) || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return fail(MIRL_ERR_ARG, "copy needs 16-byte aligned pointers and size");
-  static int nt = getenv("MIRL_COPY_NT") ? atoi(getenv("MIRL_COPY_NT")) : 0;
   const int64_t n = bytes / 16;
   if (nt) hipLaunchKernelGGL(k_copy16_nt, dim3((unsigned)((n + 2047) / 2048)), dim3(512), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
   else hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
+}
+
+extern "C" int mirl_copy_bytes(void* dst, const void* src, int64_t bytes, void* stream) {
+  static int nt = getenv("MIRL_COPY_NT") ? atoi(getenv("MIRL_COPY_NT")) : 0;
+  return mirl_copy_bytes_ex(dst, src, bytes, nt, stream);
 }
 
 // ---- host-only hooks ---------------------------------------------------------

@@ -255,7 +255,9 @@ class _QuantileProduct(torch.autograd.Function):
         L = _lib()
         emb = torch._addmm_activation(bias, phi, weight.t(), use_gelu=False)
         M, Cf = x.shape
-        out = torch.empty_like(emb)
+        # no-grad passes (target / selection / acting): the embedding is not needed again, multiply in place
+        need = any(ctx.needs_input_grad)
+        out = torch.empty_like(emb) if need else emb
         L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
         ctx.n = n
         ctx.save_for_backward(x, phi, weight, emb)
