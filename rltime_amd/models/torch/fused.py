@@ -251,12 +251,14 @@ class _QuantileProduct(torch.autograd.Function):
     """out[m*N+n] = x[m] * relu(phi[m*N+n] @ Wq^T + bq)."""
 
     @staticmethod
-    def forward(ctx, x, phi, weight, bias, n):
+    def forward(ctx, x, phi, weight, bias, n, track=True):
         L = _lib()
         emb = torch._addmm_activation(bias, phi, weight.t(), use_gelu=False)
         M, Cf = x.shape
         # no-grad passes (target / selection / acting): the embedding is not needed again, multiply in place
-        need = any(ctx.needs_input_grad)
+        # (`track` comes from the caller's torch.is_grad_enabled(): ctx.needs_input_grad mirrors
+        # requires_grad even under no_grad)
+        need = track and any(ctx.needs_input_grad)
         out = torch.empty_like(emb) if need else emb
         L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
         ctx.n = n
@@ -277,14 +279,14 @@ class _QuantileProduct(torch.autograd.Function):
         L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
                                        blocks, _stream()), "mirl_iqn_mul_bwd")
         dw = d_pre.t().mm(phi) if ctx.needs_input_grad[2] else None
-        return (dx if ctx.needs_input_grad[0] else None), None, dw, (db if ctx.needs_input_grad[3] else None), None
+        return (dx if ctx.needs_input_grad[0] else None), None, dw, (db if ctx.needs_input_grad[3] else None), None, None
 
 
 def quantile_product(x, phi, weight, bias, n):
     """x (M, C), phi (M*n, D) -> (M*n, C): x[m] * relu(linear(phi))[m*n + j]   (iqn.py:82-102)."""
     if (x.dim() == 2 and _fusable(x, phi, weight) and _pow2_quads(x.shape[1]) and x.is_contiguous()
             and phi.is_contiguous() and not phi.requires_grad):
-        return _QuantileProduct.apply(x, phi, weight, bias, n)
+        return _QuantileProduct.apply(x, phi, weight, bias, n, torch.is_grad_enabled())
     emb = linear_relu(phi, weight, bias)
     return (x.unsqueeze(1) * emb.reshape(x.shape[0], n, -1)).reshape(x.shape[0] * n, -1)
 

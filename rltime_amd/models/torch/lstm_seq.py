@@ -106,7 +106,7 @@ def _stream():
 
 class _LSTMSequence(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, bias, h0, c0, keep):
+    def forward(ctx, x, w_ih, w_hh, bias, h0, c0, keep, track=True):
         # x (T*B, I); bias = b_ih + b_hh (4H); keep (T, B).  The input projection of
         # ALL timesteps is one GEMM into `gates`; every step then accumulates the
         # recurrent GEMM onto its slice IN PLACE (no per-step copy of the projection)
@@ -116,7 +116,9 @@ class _LSTMSequence(torch.autograd.Function):
         x = x.float()
         w = w_hh.float().contiguous()
         keep = keep.float().contiguous()
-        need_grad = any(ctx.needs_input_grad[:4])
+        # `track`: decided by the caller from torch.is_grad_enabled() — inside forward() grad mode is
+        # always off and ctx.needs_input_grad mirrors requires_grad even in a no_grad pass
+        need_grad = track and any(ctx.needs_input_grad[:4])
         dev = x.device
         gates = torch.addmm(bias.float(), x, w_ih.float().t()).view(T, B, 4 * H)
         out, hm, cm, c_all, h_last, c_last = _forward_sweep(
@@ -147,7 +149,7 @@ class _LSTMSequence(torch.autograd.Function):
         d_wih = dg.t().mm(x) if ctx.needs_input_grad[1] else None
         d_whh = dg.t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[2] else None
         d_b = dg.sum(0) if ctx.needs_input_grad[3] else None
-        return d_x, d_wih, d_whh, d_b, None, None, None
+        return d_x, d_wih, d_whh, d_b, None, None, None, None
 
 
 class _LSTMSequenceFromProjection(torch.autograd.Function):
@@ -156,14 +158,17 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
     untouched (it may have other consumers), so the gates buffer is a copy of it."""
 
     @staticmethod
-    def forward(ctx, gx, w_hh, h0, c0, keep):
+    def forward(ctx, gx, w_hh, h0, c0, keep, track=True):
         T, B, G = gx.shape
         H = G // 4
         w = w_hh.float().contiguous()
         keep = keep.float().contiguous()
-        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_grad = track and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         dev = gx.device
-        gates = gx.float().clone(memory_format=torch.contiguous_format)
+        if need_grad or not (persistent_supported(T, B, H) and w.data_ptr() % 16 == 0):
+            gates = gx.float().clone(memory_format=torch.contiguous_format)
+        else:
+            gates = gx.float().contiguous()       # the persistent no-grad sweep only READS the projection: no copy
         out, hm, cm, c_all, h_last, c_last = _forward_sweep(
             gates, w, h0.float().contiguous(), c0.float().contiguous(), keep, need_grad)
         if need_grad:
@@ -188,14 +193,14 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
             if t > 0:
                 torch.mm(gates[t], w, out=dh_rec)
         d_whh = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[1] else None
-        return gates, d_whh, None, None, None
+        return gates, d_whh, None, None, None, None
 
 
 def lstm_sequence_from_projection(gx, w_hh, h0, c0, keep):
     """gx (T, B, 4H) -> (out (T,B,H), h_T, c_T)."""
-    return _LSTMSequenceFromProjection.apply(gx, w_hh, h0, c0, keep)
+    return _LSTMSequenceFromProjection.apply(gx, w_hh, h0, c0, keep, torch.is_grad_enabled())
 
 
 def lstm_sequence(x, w_ih, w_hh, bias, h0, c0, keep):
     """x (T*B, I) -> (out (T,B,H), h_T (B,H), c_T (B,H)); keep (T, B) = 1 - initials."""
-    return _LSTMSequence.apply(x, w_ih, w_hh, bias, h0, c0, keep)
+    return _LSTMSequence.apply(x, w_ih, w_hh, bias, h0, c0, keep, torch.is_grad_enabled())
