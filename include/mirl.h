@@ -111,6 +111,16 @@ typedef struct mirl_ingest {
   const float*   policy;    /* [count][policy_f32]    policy_output["qvalues"]   */
   const float*   rewards;   /* [count]                                           */
   const uint8_t* dones;     /* [count]                                           */
+  /* De-duplicated storage (stack_planes = P > 1) only.  newest_plane_only = 1: `frames` holds ONE
+   * plane per transition — the newest plane of its stack, frames_stride bytes apart (0 = packed;
+   * the actor passes the last plane of its (count, P, h, w) observation block with frames_stride
+   * = frame_bytes) — and the number of real planes of a stack follows from the shift contract
+   * itself: 1 for an env's first transition or when the previous transition ended an episode,
+   * else one more than the predecessor's (capped at P).  No plane is compared against the ring.
+   * 0 (default): `frames` holds whole stacks and the contract is VERIFIED against the stored
+   * planes (debug / untrusted producers).                                                        */
+  int32_t newest_plane_only;
+  int64_t frames_stride;
 } mirl_ingest;
 
 /* Output of one get_train_data call (history.py:203-286 _make_train_batch),
@@ -148,6 +158,13 @@ int mirl_replay_destroy(mirl_replay* h);
  * per-env split of Actor.get_samples (actor.py:132-145), as one batched
  * device write per vector step.                                               */
 int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream);
+
+/* De-duplicated storage fed in the newest-plane form (mirl_ingest.newest_plane_only): the stack of an
+ * env's FIRST transition reaches back to the observation its reset returned, which is not a
+ * transition.  This call (once, before the first ingest) stores that observation's newest plane —
+ * newest_planes[e] at `stride` bytes per env — as "transition -1" of every env.  Without it the
+ * first stack of an env is taken to be a reset stack (one real plane).                              */
+int mirl_replay_prime_stack(mirl_replay* h, const uint8_t* newest_planes, int64_t stride, void* stream);
 
 /* mirl_replay_ingest issues ONE fused kernel per call (frame / state / q-value rows, scalars,
  * plan, tree fix) unless the shard de-duplicates frame stacks or initialises priorities at

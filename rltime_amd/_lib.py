@@ -70,6 +70,8 @@ class Ingest(C.Structure):
         ("policy", C.c_void_p),
         ("rewards", C.c_void_p),
         ("dones", C.c_void_p),
+        ("newest_plane_only", C.c_int32),
+        ("frames_stride", C.c_int64),
     ]
 
 
@@ -111,6 +113,7 @@ _SIGNATURES = {
     "mirl_replay_destroy": [_vp],
     "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
     "mirl_ingest_fused_set": [_i32],
+    "mirl_replay_prime_stack": [_vp, _vp, _i64, _vp],
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
     "mirl_replay_sample": [_vp, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_replay_sample_ready": [_vp, _i32, _P(_i32)],

@@ -275,6 +275,8 @@ class Actor(ActingInterface):
             if sink._h is None:
                 pf = self._action_space.n if sink._keep_policy else 0
                 sink.configure(fs.example, self._num_envs, self._base_env_id, policy_f32=pf)
+                if getattr(sink, "_dedup", False) and fs.trusted_stack:
+                    sink.prime_stack(self._reset_obs)
             keep_policy = bool(sink._policy_f32)
         out = None
         for _ in range(iters):

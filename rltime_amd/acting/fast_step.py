@@ -144,6 +144,10 @@ class FastActingStep:
         self.expo = expl._device_exponents(actor._env_ids, dev) if expl is not None else None
         self.eps_min = float(expl.eps_min) if expl is not None else 0.0
         self.last_obs = obs0
+        # a frame-stack env produces its observations by the shift contract itself: de-duplicated
+        # storage can take the newest plane without re-verifying it (MIRL_DEDUP_VERIFY=1: whole stacks)
+        import os
+        self.trusted_stack = bool(getattr(actor._vec_env, "frame_stack", False)) and os.environ.get("MIRL_DEDUP_VERIFY", "0") != "1"
         self.tracker = None
         self.graph = None
         assert cell.weight_ih.shape == (4 * H, F)
@@ -261,7 +265,8 @@ class FastActingStep:
         fields = None
         if sink is not None:
             sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
-                              policy=self.qvalues if keep_policy else None, transient=True)
+                              policy=self.qvalues if keep_policy else None, transient=True,
+                              newest_plane_only=bool(getattr(sink, "_dedup", False)) and self.trusted_stack)
         else:
             fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
                           policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)

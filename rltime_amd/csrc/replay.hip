@@ -217,6 +217,8 @@ struct IngestSrc {
   const uint8_t* frames; const float* extra; const float* state; const float* policy;
   const float* initials; const int32_t* actions; const float* rewards; const uint8_t* dones;
   int vec_frames, vec_extra, vec_state, vec_policy;
+  int64_t frames_stride;      // bytes between the frame rows of consecutive transitions in `frames`
+  int32_t row_bytes, slot_bytes;   // bytes copied per transition / ring slot pitch (de-dup: one plane)
 };
 
 __device__ __forceinline__ void copy_row(const uint8_t* s, uint8_t* t, int row_bytes, int vec, int part, int parts) {
@@ -239,7 +241,7 @@ k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, co
   if (k < K) {
     const int64_t slot = (int64_t)s_env[k] * d.C + s_off[k] % d.C;
     const int part = blockIdx.x, parts = gridDim.x;
-    copy_row(in.frames + (int64_t)k * d.F, d.frames + slot * (int64_t)d.Fp, d.F, in.vec_frames, part, parts);
+    copy_row(in.frames + (int64_t)k * in.frames_stride, d.frames + slot * (int64_t)in.slot_bytes, in.row_bytes, in.vec_frames, part, parts);
     if (d.X) copy_row((const uint8_t*)(in.extra + (int64_t)k * d.X), (uint8_t*)(d.extra + slot * (int64_t)d.X), d.X * 4, in.vec_extra, part, parts);
     if (d.S) copy_row((const uint8_t*)(in.state + (int64_t)k * d.S), (uint8_t*)(d.state + slot * (int64_t)d.S), d.S * 4, in.vec_state, part, parts);
     if (d.A) copy_row((const uint8_t*)(in.policy + (int64_t)k * d.A), (uint8_t*)(d.policy + slot * (int64_t)d.A), d.A * 4, in.vec_policy, part, parts);
@@ -253,6 +255,18 @@ k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, co
     d.rewards[sl] = in.rewards[i];
     d.dones[sl] = in.dones[i] ? 1 : 0;
     if (d.per) { d.loss[sl] = MIRL_LOSS_FRESH; d.prio_index[sl] = -1; d.stamp[sl] = 0ull; }
+    if (d.planes) {
+      // newest-plane form of de-duplicated storage: the stack of transition `off` has one real
+      // plane after a reset (the env's first transition, or the previous one ended an episode:
+      // env_wrappers/common.py:175-178 zero-fills the rest), else one more than its predecessor's
+      const int64_t off = s_off[i];
+      int dep = 1;
+      // off == 0: the predecessor is the reset observation mirl_replay_prime_stack put into ring
+      // slot -1 (depth 0 there = nothing primed: the first stack is taken as a reset stack)
+      const int64_t prev = (int64_t)s_env[i] * d.C + ((off - 1) % d.C + d.C) % d.C;
+      if (!d.dones[prev] && (off > 0 || d.depth[prev] > 0)) { dep = (int)d.depth[prev] + 1; if (dep > d.planes) dep = d.planes; }
+      d.depth[sl] = (uint8_t)dep;
+    }
   }
   __threadfence_block();
   __syncthreads();
@@ -628,7 +642,7 @@ k_gather_rows_dedup(Dev d, uint8_t* __restrict__ out, const int32_t* __restrict_
 // and writes RC stacks: (RC + P - 1) / RC read amplification instead of P.  Chunks
 // whose source transitions are not one short run (layout seams, truncated n-step
 // targets at the ring end) take the direct path of k_gather_rows_dedup.
-#define MIRL_DD_MAX_PLANES 16
+#define MIRL_DD_MAX_PLANES 22
 __global__ void __launch_bounds__(512)
 k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restrict__ env,
                         const int64_t* __restrict__ start, int B, int R, int overlapped, int RC, int lds_planes) {
@@ -642,15 +656,16 @@ k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restr
   const int64_t st = start[b];
   int64_t lo = INT64_MAX, hi = INT64_MIN;
   for (int r = r0; r < r1; ++r) { int64_t o = row_src_off(d, overlapped, r, e, st); lo = o < lo ? o : lo; hi = o > hi ? o : hi; }
-  const int nq = d.plane_bytes >> 4, n = nq * d.planes;
+  const int nq = d.plane_bytes >> 4;
   const uint8_t* ring0 = d.frames + (int64_t)e * d.C * d.plane_bytes;
   const int64_t first = lo - (d.planes - 1);
   const int span = (int)(hi - first + 1);
   const bool staged = span <= lds_planes;
   if (staged) {
-    for (int c = threadIdx.x; c < span * nq; c += 512) {
-      const int p = c / nq, q = c - p * nq;
-      s_planes[c] = __builtin_nontemporal_load((const u32x4*)(ring0 + (((first + p) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+    // plane by plane, lane = 16-byte chunk inside the plane: no index division per vector
+    for (int p = 0; p < span; ++p) {
+      const u32x4* src = (const u32x4*)(ring0 + (((first + p) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
+      for (int q = threadIdx.x; q < nq; q += 512) s_planes[p * nq + q] = __builtin_nontemporal_load(src + q);
     }
     __syncthreads();
   }
@@ -658,14 +673,16 @@ k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restr
     const int64_t o = row_src_off(d, overlapped, r, e, st);
     const int dep = d.depth[slot_of(d, e, o)];
     u32x4* t4 = (u32x4*)(out + ((int64_t)r * B + b) * (int64_t)d.F);
-    for (int c = threadIdx.x; c < n; c += 512) {
-      const int p = c / nq, q = c - p * nq, back = d.planes - 1 - p;
-      u32x4 v = u32x4{0u, 0u, 0u, 0u};
-      if (back < dep) {
-        if (staged) v = s_planes[(int)(o - back - first) * nq + q];
-        else v = __builtin_nontemporal_load((const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
+    for (int p = 0; p < d.planes; ++p) {
+      const int back = d.planes - 1 - p;
+      const bool real = back < dep;
+      const u32x4* src = staged ? s_planes + (int)(o - back - first) * nq
+                                : (const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
+      for (int q = threadIdx.x; q < nq; q += 512) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (real) v = staged ? src[q] : __builtin_nontemporal_load(src + q);
+        __builtin_nontemporal_store(v, t4 + p * nq + q);
       }
-      __builtin_nontemporal_store(v, t4 + c);
     }
   }
 }
@@ -1070,6 +1087,29 @@ static int scatter(mirl_replay* h, const void* src, void* ring, const int32_t* s
 
 static int update_losses_impl(mirl_replay* h, int64_t count, const int64_t* indices, const float* losses, hipStream_t st);
 
+// Reset observation of every env as "transition -1" of a de-duplicated shard (newest-plane ingest).
+__global__ void __launch_bounds__(256)
+k_prime_stack(Dev d, const uint8_t* __restrict__ planes, int64_t stride) {
+  const int e = blockIdx.x;
+  const int64_t slot = (int64_t)e * d.C + (d.C - 1);
+  const u32x4* s4 = (const u32x4*)(planes + (int64_t)e * stride);
+  u32x4* t4 = (u32x4*)(d.frames + slot * (int64_t)d.plane_bytes);
+  for (int q = threadIdx.x; q < (d.plane_bytes >> 4); q += 256) t4[q] = s4[q];
+  if (threadIdx.x == 0) { d.depth[slot] = 1; d.dones[slot] = 0; }
+}
+
+extern "C" int mirl_replay_prime_stack(mirl_replay* h, const uint8_t* newest_planes, int64_t stride, void* stream) {
+  if (!h || !newest_planes) return fail(MIRL_ERR_ARG, "bad prime_stack arguments");
+  Dev& d = h->d;
+  if (!d.planes) return fail(MIRL_ERR_ARG, "prime_stack: the shard does not de-duplicate frame stacks");
+  if (h->book.total_items() != 0) return fail(MIRL_ERR_STATE, "prime_stack: only before the first transition");
+  if (stride <= 0) stride = d.plane_bytes;
+  if (((uintptr_t)newest_planes % 16) || (stride % 16)) return fail(MIRL_ERR_ARG, "prime_stack: 16-byte aligned planes");
+  hipLaunchKernelGGL(k_prime_stack, dim3(d.E), dim3(256), 0, (hipStream_t)stream, d, newest_planes, stride);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
 static int g_ingest_fused = -1;     // -1: take MIRL_INGEST_FUSED (default on) at the first ingest
 extern "C" int mirl_ingest_fused_set(int32_t on) { g_ingest_fused = on ? 1 : 0; return MIRL_OK; }
 
@@ -1101,19 +1141,25 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   const int32_t* s_env = (const int32_t*)(db + o_env);
   const int64_t* s_off = (const int64_t*)(db + o_off);
   if (g_ingest_fused < 0) g_ingest_fused = (getenv("MIRL_INGEST_FUSED") && atoi(getenv("MIRL_INGEST_FUSED")) == 0) ? 0 : 1;
-  if (g_ingest_fused && !d.planes && !(h->book.cfg.acting_priority_init && d.per)) {
+  if (d.planes && in->newest_plane_only && (h->book.cfg.acting_priority_init && d.per))
+    return fail(MIRL_ERR_ARG, "newest_plane_only ingest cannot be combined with acting_priority_init");
+  if ((g_ingest_fused && !d.planes && !(h->book.cfg.acting_priority_init && d.per)) || (d.planes && in->newest_plane_only)) {
+    const bool planes = d.planes != 0;
+    const int64_t f_stride = in->frames_stride > 0 ? in->frames_stride : (planes ? d.plane_bytes : d.F);
+    const int32_t f_row = planes ? d.plane_bytes : d.F, f_slot = planes ? d.plane_bytes : d.Fp;
     auto vec_ok = [](const void* src, const void* dst, int64_t row_bytes, int64_t src_stride, int64_t dst_stride) {
       return (int)(row_bytes && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0 &&
                    ((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0);
     };
     IngestSrc src{in->frames, in->extra, in->state, in->policy, in->initials, in->actions, in->rewards, in->dones,
-                  vec_ok(in->frames, d.frames, d.F, d.F, d.Fp), vec_ok(in->extra, d.extra, d.X * 4, d.X * 4, d.X * 4),
-                  vec_ok(in->state, d.state, d.S * 4, d.S * 4, d.S * 4), vec_ok(in->policy, d.policy, d.A * 4, d.A * 4, d.A * 4)};
+                  vec_ok(in->frames, d.frames, f_row, f_stride, f_slot), vec_ok(in->extra, d.extra, d.X * 4, d.X * 4, d.X * 4),
+                  vec_ok(in->state, d.state, d.S * 4, d.S * 4, d.S * 4), vec_ok(in->policy, d.policy, d.A * 4, d.A * 4, d.A * 4),
+                  f_stride, f_row, f_slot};
     const int nt = d.per ? (int)p.table_ops.size() : 0, ne = (int)p.env_ops.size(), nl = d.per ? (int)p.leaf_ops.size() : 0;
     // 16 KB per copy workgroup: a (4, 84, 84) frame row takes 2
-    int parts = (int)((d.F + 16383) / 16384); if (parts < 1) parts = 1; if (parts > 8) parts = 8;
+    int parts = (int)((f_row + 16383) / 16384); if (parts < 1) parts = 1; if (parts > 8) parts = 8;
     {
-      ProfScope ps("k_ingest_fused", 2.0 * K * ((double)d.F + 4.0 * (d.X + d.S + d.A) + 13 + (d.per ? 16 : 0)), st);
+      ProfScope ps("k_ingest_fused", 2.0 * K * ((double)f_row + 4.0 * (d.X + d.S + d.A) + 13 + (d.per ? 16 : 0)), st);
       hipLaunchKernelGGL(k_ingest_fused, dim3(parts, K + 1), dim3(1024), 0, st, d, K, src, s_env, s_off, nt, (const TableOp*)(db + o_tab),
                          ne, (const EnvOp*)(db + o_eop), nl, (const LeafOp*)(db + o_lop));
     }
@@ -1528,8 +1574,14 @@ extern "C" int mirl_replay_gather(mirl_replay* h, int32_t B, const int32_t* env,
       // window read once (rows + P - 1 planes per sequence and state block)
       ProfScope ps("k_gather_rows_dedup(frames)", (double)blocks * d.F + (double)B * (h->rows + d.planes - 1) * d.plane_bytes, st);
       // LDS-staged variant: as many planes as fit in 64 KB; RC rows per workgroup
-      int lds_planes = (int)(65536 / d.plane_bytes); if (lds_planes > MIRL_DD_MAX_PLANES) lds_planes = MIRL_DD_MAX_PLANES;
+      static const int lds_kb = getenv("MIRL_DEDUP_LDS_KB") ? atoi(getenv("MIRL_DEDUP_LDS_KB")) : 64;
+      int lds_planes = (int)((size_t)lds_kb * 1024 / d.plane_bytes); if (lds_planes > MIRL_DD_MAX_PLANES) lds_planes = MIRL_DD_MAX_PLANES;
       const int RC = lds_planes - (d.planes - 1);
+      static bool lds_attr = false;
+      if (!lds_attr && (size_t)lds_planes * d.plane_bytes > 65536) {
+        MIRL_HIP(hipFuncSetAttribute((const void*)k_gather_rows_dedup_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr = true;
+      }
       if (h->dedup_lds && RC >= 2) {
         const int chunks = (h->rows + RC - 1) / RC;
         hipLaunchKernelGGL(k_gather_rows_dedup_lds, dim3((unsigned)(chunks * B)), dim3(512), (size_t)lds_planes * d.plane_bytes, st, d,

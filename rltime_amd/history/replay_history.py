@@ -279,7 +279,7 @@ class ReplayHistoryBuffer(History):
         self.update_batch(env_ids=env_ids, **dev)
 
     def update_batch(self, frames, actions, rewards, dones, extra=None, state=None,
-                     initials=None, policy=None, env_ids=None, transient=False):
+                     initials=None, policy=None, env_ids=None, transient=False, newest_plane_only=False):
         """Fast path: one vector step of device tensors with leading dim K
         (frames u8 [K, ...], actions i32 [K], rewards f32 [K], dones u8 [K],
         extra/state/policy f32 [K, n], initials f32 [K]).  ``env_ids`` (host
@@ -289,6 +289,14 @@ class ReplayHistoryBuffer(History):
                 "update_batch before the shard exists: call configure() first")
         K = int(frames.shape[0])
         keep = [frames, actions, rewards, dones, extra, state, initials, policy]
+        plane_ptr, plane_stride = None, 0
+        if newest_plane_only:
+            # de-duplicated storage fed by a producer that honours the stack-shift contract (the device
+            # actor): only the newest plane of every (K, P, h, w) stack is read, nothing is verified
+            assert self._dedup and frames.dim() >= 3 and frames.is_contiguous()
+            per_plane = frames[0, 0].numel()
+            plane_ptr = frames.data_ptr() + (frames.shape[1] - 1) * per_plane
+            plane_stride = frames.shape[1] * per_plane
         for t in keep:
             if t is not None:
                 assert t.is_cuda and t.is_contiguous()
@@ -299,9 +307,10 @@ class ReplayHistoryBuffer(History):
             ids = np.ascontiguousarray(env_ids, dtype=np.int32)
         arg = _lib.Ingest(
             count=K, env_ids_host=_lib.np_ptr(ids) if ids is not None else None,
-            frames=_ptr(frames), extra=_ptr(extra), state=_ptr(state),
+            frames=_ptr(frames) if plane_ptr is None else C.c_void_p(plane_ptr), extra=_ptr(extra), state=_ptr(state),
             initials=_ptr(initials), actions=_ptr(actions), policy=_ptr(policy),
-            rewards=_ptr(rewards), dones=_ptr(dones))
+            rewards=_ptr(rewards), dones=_ptr(dones), newest_plane_only=1 if newest_plane_only else 0,
+            frames_stride=plane_stride)
         check(lib.mirl_replay_ingest(self._h, C.byref(arg), _stream()), "mirl_replay_ingest")
         # the kernels read the payload asynchronously: tie its lifetime to the stream
         # (transient=True: the caller owns long-lived buffers it only rewrites in stream order)
@@ -310,6 +319,14 @@ class ReplayHistoryBuffer(History):
             for t in keep:
                 if t is not None:
                     t.record_stream(s)
+
+    def prime_stack(self, obs):
+        """De-duplicated storage + newest-plane ingest: hand over the observation block the env's
+        reset returned ((E, P, h, w) uint8) so that the first transitions' stacks can reach back to it."""
+        assert self._dedup and self._h is not None and obs.is_contiguous()
+        per_plane = obs[0, 0].numel()
+        check(lib.mirl_replay_prime_stack(self._h, C.c_void_p(obs.data_ptr() + (obs.shape[1] - 1) * per_plane),
+                                          obs.shape[1] * per_plane, _stream()), "mirl_replay_prime_stack")
 
     def configure(self, example_state, num_envs, env_base=0, policy_f32=0):
         """Create the shard up-front from one example ``next_state`` pytree

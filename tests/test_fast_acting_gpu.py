@@ -166,3 +166,41 @@ def test_in_kernel_quantile_fractions():
     assert float(hist.min()) > rows / 16 * 0.8
     want = torch.cos(freq * tau.unsqueeze(1))
     assert torch.allclose(phi, want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("done_prob", [0.02, 0.4])
+def test_dedup_newest_plane_ingest_equals_verified_whole_stacks(done_prob):
+    """De-duplicated storage fed (a) whole stacks, verified against the ring (k_dedup_depth), (b) only the
+    newest plane of every stack + the primed reset observation (mirl_ingest.newest_plane_only), (c) whole
+    stacks into a plain shard: the same gathered batches, bit for bit — episodes that end inside an env's
+    first steps (done_prob 0.4) included."""
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    from rltime_amd.history import ReplayHistoryBuffer
+    E, steps = 6, 70
+    env = SyntheticAtariVecEnv(E, frame_shape=(4, 84, 84), n_actions=4, seed=11, done_prob=done_prob, frame_stack=True)
+    obs0 = env.reset()
+    kw = dict(size=E * 50, train_frequency=0, nstep_target=2, nstep_train=3, prefix_steps=1, gamma=0.99, device_rng=True,
+              keep_policy_outputs=False)
+    bufs = [ReplayHistoryBuffer(frame_stack_dedup=True, **kw), ReplayHistoryBuffer(frame_stack_dedup=True, **kw), ReplayHistoryBuffer(**kw)]
+    example = {"x": obs0[0].cpu().numpy()}
+    for b in bufs:
+        b.configure(example, E, 0)
+    bufs[1].prime_stack(obs0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for t in range(steps):
+        actions = torch.randint(0, 4, (E,), dtype=torch.int32, device="cuda", generator=g)
+        obs, rewards, dones, _ = env.step_device(actions)
+        obs = obs.contiguous()
+        d8 = dones.to(torch.uint8)
+        for i, b in enumerate(bufs):
+            b.update_batch(obs, actions, rewards.float(), d8, newest_plane_only=(i == 1))
+    batches = []
+    for b in bufs:
+        b._seed = 77
+        batches.append(b.get_train_data(16))
+        b.close()
+    for k in ("returns", "nsteps", "target_masks"):
+        assert torch.equal(batches[0][k], batches[2][k]) and torch.equal(batches[1][k], batches[2][k])
+    for key in ("states", "target_states"):
+        assert torch.equal(batches[0][key]["x"], batches[2][key]["x"]), "verified whole-stack form"
+        assert torch.equal(batches[1][key]["x"], batches[2][key]["x"]), "newest-plane form"
