@@ -115,8 +115,9 @@ typedef struct mirl_ingest {
    * plane per transition — the newest plane of its stack, frames_stride bytes apart (0 = packed;
    * the actor passes the last plane of its (count, P, h, w) observation block with frames_stride
    * = frame_bytes) — and the number of real planes of a stack follows from the shift contract
-   * itself: 1 for an env's first transition or when the previous transition ended an episode,
-   * else one more than the predecessor's (capped at P).  No plane is compared against the ring.
+   * itself: 1 when this transition ended an episode (the auto-resetting env returned the new
+   * episode's first stack with it) or for an unprimed env's first transition, else one more than the
+   * predecessor's (capped at P).  No plane is compared against the ring.
    * 0 (default): `frames` holds whole stacks and the contract is VERIFIED against the stored
    * planes (debug / untrusted producers).                                                        */
   int32_t newest_plane_only;
@@ -522,6 +523,11 @@ int mirl_actor_head(int32_t E, int32_t N, int32_t A, const float* adv, const flo
 int mirl_actor_head_rng(int32_t E, int32_t N, int32_t A, const float* adv, int32_t adv_pitch, const float* val, int32_t Q,
                         const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
                         const uint64_t* rng_step, int32_t* actions, float* qvalues, float* eps_used, void* stream);
+/* The frame-stack wrapper's shift for a device-resident vector env (env_wrappers/common.py:141-178
+ * with auto-reset): out[e] = [in[e] planes 1..P-1 — or zeros where dones[e] —, newest[e]].  One launch
+ * (the synthetic env's torch expression of it is four).                                              */
+int mirl_stack_shift(int32_t E, int32_t P, int32_t plane_bytes, const uint8_t* in, uint8_t* out,
+                     const uint8_t* newest, const uint8_t* dones, void* stream);
 /* Everything between env.step and the policy forward of the device-resident actor in ONE
  * launch (acting/actor.py:124-131 -> modules/lstm.py:131-161 state reset on `done`;
  * policy_trainer.py:93-131 episode statistics; :252-254 reward sign clipping): h_in = h *

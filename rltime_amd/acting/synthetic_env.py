@@ -57,10 +57,20 @@ class SyntheticAtariVecEnv:
         rewards, dones = self._sched[0][self._sched_at], self._sched[1][self._sched_at]
         self._sched_at += 1
         if self.frame_stack:
-            keep = (~dones).to(torch.uint8).view(-1, 1, 1, 1)
             nxt = torch.empty_like(self._stack)
-            torch.mul(self._stack[:, 1:], keep, out=nxt[:, :-1])      # roll by one plane; a reset zero-fills
-            nxt[:, -1] = obs
+            plane = obs[0].numel()
+            if self._stack.is_cuda and plane % 16 == 0:
+                # roll by one plane, zero-fill on reset, append the new plane: one launch (csrc/acting.hip)
+                import ctypes as C
+                from rltime_amd._lib import lib, check
+                p = lambda t: C.c_void_p(t.data_ptr())                      # noqa: E731
+                check(lib.mirl_stack_shift(self.num_envs, self._stack.shape[1], plane, p(self._stack), p(nxt), p(obs),
+                                           p(dones.view(torch.uint8)), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                      "mirl_stack_shift")
+            else:
+                keep = (~dones).to(torch.uint8).view(-1, 1, 1, 1)
+                torch.mul(self._stack[:, 1:], keep, out=nxt[:, :-1])      # roll by one plane; a reset zero-fills
+                nxt[:, -1] = obs
             self._stack = nxt
             obs = nxt
         return obs, rewards, dones, None

@@ -135,7 +135,38 @@ k_actor_pre(int E, int H, int A, const float* __restrict__ rewards_raw, const ui
   }
 }
 
+// The frame-stack wrapper's shift on the device (env_wrappers/common.py:141-178 under an
+// auto-resetting vector env): out[e] = [in[e][1..P-1] or zeros when done[e], newest[e]].
+__global__ void __launch_bounds__(256)
+k_stack_shift(int P, int plane_q, const uint4* __restrict__ in, uint4* __restrict__ out, const uint4* __restrict__ newest,
+              const uint8_t* __restrict__ dones) {
+  const int e = blockIdx.y;
+  const bool reset = dones[e] != 0;
+  const int64_t base = (int64_t)e * P * plane_q;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < P * plane_q; c += gridDim.x * 256) {
+    const int p = c / plane_q;
+    uint4 v;
+    if (p == P - 1) v = newest[(int64_t)e * plane_q + (c - p * plane_q)];
+    else if (reset) v = uint4{0u, 0u, 0u, 0u};
+    else v = in[base + c + plane_q];
+    out[base + c] = v;
+  }
+}
+
 }  // namespace mirl
+
+extern "C" int mirl_stack_shift(int32_t E, int32_t P, int32_t plane_bytes, const uint8_t* in, uint8_t* out, const uint8_t* newest,
+                                const uint8_t* dones, void* stream) {
+  if (E <= 0 || P <= 1 || plane_bytes <= 0 || (plane_bytes % 16) || !in || !out || !newest || !dones || in == out ||
+      ((uintptr_t)in % 16) || ((uintptr_t)out % 16) || ((uintptr_t)newest % 16))
+    return mirl::fail(MIRL_ERR_ARG, "bad stack_shift arguments (16-byte aligned planes, out != in)");
+  const int pq = plane_bytes / 16;
+  int gx = (P * pq + 255) / 256; if (gx > 8) gx = 8;
+  hipLaunchKernelGGL(mirl::k_stack_shift, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, (int)P, pq, (const uint4*)in, (uint4*)out,
+                     (const uint4*)newest, dones);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
 
 extern "C" int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, const uint8_t* dones,
                               const int32_t* actions, const float* h, const float* c, float* xh_tail, int64_t xh_pitch,

@@ -257,14 +257,15 @@ k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, co
     if (d.per) { d.loss[sl] = MIRL_LOSS_FRESH; d.prio_index[sl] = -1; d.stamp[sl] = 0ull; }
     if (d.planes) {
       // newest-plane form of de-duplicated storage: the stack of transition `off` has one real
-      // plane after a reset (the env's first transition, or the previous one ended an episode:
-      // env_wrappers/common.py:175-178 zero-fills the rest), else one more than its predecessor's
+      // plane after a reset (an unprimed env's first transition, or this transition ended an
+      // episode: env_wrappers/common.py:175-178 zero-fills the rest), else one more than its predecessor's
       const int64_t off = s_off[i];
       int dep = 1;
       // off == 0: the predecessor is the reset observation mirl_replay_prime_stack put into ring
       // slot -1 (depth 0 there = nothing primed: the first stack is taken as a reset stack)
       const int64_t prev = (int64_t)s_env[i] * d.C + ((off - 1) % d.C + d.C) % d.C;
-      if (!d.dones[prev] && (off > 0 || d.depth[prev] > 0)) { dep = (int)d.depth[prev] + 1; if (dep > d.planes) dep = d.planes; }
+      // (an auto-resetting env returns the NEW episode's first stack with the transition that has done = 1)
+      if (!in.dones[i] && (off > 0 || d.depth[prev] > 0)) { dep = (int)d.depth[prev] + 1; if (dep > d.planes) dep = d.planes; }
       d.depth[sl] = (uint8_t)dep;
     }
   }
@@ -656,16 +657,15 @@ k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restr
   const int64_t st = start[b];
   int64_t lo = INT64_MAX, hi = INT64_MIN;
   for (int r = r0; r < r1; ++r) { int64_t o = row_src_off(d, overlapped, r, e, st); lo = o < lo ? o : lo; hi = o > hi ? o : hi; }
-  const int nq = d.plane_bytes >> 4;
+  const int nq = d.plane_bytes >> 4, n = nq * d.planes;
   const uint8_t* ring0 = d.frames + (int64_t)e * d.C * d.plane_bytes;
   const int64_t first = lo - (d.planes - 1);
   const int span = (int)(hi - first + 1);
   const bool staged = span <= lds_planes;
   if (staged) {
-    // plane by plane, lane = 16-byte chunk inside the plane: no index division per vector
-    for (int p = 0; p < span; ++p) {
-      const u32x4* src = (const u32x4*)(ring0 + (((first + p) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
-      for (int q = threadIdx.x; q < nq; q += 512) s_planes[p * nq + q] = __builtin_nontemporal_load(src + q);
+    for (int c = threadIdx.x; c < span * nq; c += 512) {
+      const int p = c / nq, q = c - p * nq;
+      s_planes[c] = __builtin_nontemporal_load((const u32x4*)(ring0 + (((first + p) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
     }
     __syncthreads();
   }
@@ -673,16 +673,14 @@ k_gather_rows_dedup_lds(Dev d, uint8_t* __restrict__ out, const int32_t* __restr
     const int64_t o = row_src_off(d, overlapped, r, e, st);
     const int dep = d.depth[slot_of(d, e, o)];
     u32x4* t4 = (u32x4*)(out + ((int64_t)r * B + b) * (int64_t)d.F);
-    for (int p = 0; p < d.planes; ++p) {
-      const int back = d.planes - 1 - p;
-      const bool real = back < dep;
-      const u32x4* src = staged ? s_planes + (int)(o - back - first) * nq
-                                : (const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes);
-      for (int q = threadIdx.x; q < nq; q += 512) {
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (real) v = staged ? src[q] : __builtin_nontemporal_load(src + q);
-        __builtin_nontemporal_store(v, t4 + p * nq + q);
+    for (int c = threadIdx.x; c < n; c += 512) {
+      const int p = c / nq, q = c - p * nq, back = d.planes - 1 - p;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (back < dep) {
+        if (staged) v = s_planes[(int)(o - back - first) * nq + q];
+        else v = __builtin_nontemporal_load((const u32x4*)(ring0 + (((o - back) % d.C + d.C) % d.C) * (int64_t)d.plane_bytes) + q);
       }
+      __builtin_nontemporal_store(v, t4 + c);
     }
   }
 }
