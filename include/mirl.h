@@ -367,6 +367,16 @@ int mirl_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, float* gx, const float* w
                       const float* c0, const float* keep, float* out, float* c_all, float* hm, float* cm,
                       float* h_last, float* c_last, int32_t save_gates, void* workspace, void* stream);
 int mirl_lstm_seq_status(int32_t* status);
+/* The backward sweep of the same layer in ONE persistent launch (replaces the T-step loop of
+ * mirl_lstm_cell_bwd + one recurrent GEMM per step): gates [T][B][4H] holds the activated gates
+ * on entry and d loss / d pre-activation on exit; c_all / cm as mirl_lstm_seq_fwd wrote them,
+ * d_out [T][B][H] = gradient w.r.t. the layer's outputs (NULL = zero).  The recurrent contraction
+ * is split by column owner and its 16 x 16 partial blocks are summed in a fixed order, so reruns
+ * are bit-identical.  Shapes: mirl_lstm_seq_bwd_supported (H = 512, B multiple of 16).          */
+int mirl_lstm_seq_bwd_supported(int32_t T, int32_t B, int32_t H);
+int mirl_lstm_seq_bwd_workspace_bytes(int32_t B, int32_t H, int64_t* bytes);
+int mirl_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, float* gates, const float* w_hh, const float* c_all,
+                      const float* cm, const float* d_out, const float* keep, void* workspace, void* stream);
 /* Backward of one step: gates holds the activated gates on entry and
  * d loss / d pre-activation on exit; d_out [B][H] = grad of this step's output h
  * (NULL = 0); dh_rec / dc_rec = grads w.r.t. the next step's masked inputs

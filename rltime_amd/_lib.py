@@ -150,6 +150,9 @@ _SIGNATURES = {
     "mirl_lstm_seq_workspace_bytes": [_i32, _i32, _P(_i64)],
     "mirl_lstm_seq_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mirl_lstm_seq_status": [_P(_i32)],
+    "mirl_lstm_seq_bwd_supported": [_i32, _i32, _i32],
+    "mirl_lstm_seq_bwd_workspace_bytes": [_i32, _i32, _P(_i64)],
+    "mirl_lstm_seq_bwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_lstm_cell_bwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_frames_to_f32_nhwc": [_i64, _i32, _i32, _vp, C.c_float, _vp, _vp],
     "mirl_frames_to_f32_nhwc_ex": [_i64, _i32, _i32, _vp, C.c_float, _vp, _i32, _i32, _vp],

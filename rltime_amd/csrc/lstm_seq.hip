@@ -289,6 +289,177 @@ k_lstm_seq_fwd(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t 
   }
 }
 
+// ---------------------------------------------------------------------------
+// The backward sweep as one persistent launch (same ownership as the forward: wave =
+// 16-row tile x 16 hidden units x 4 gates, W_hh slice resident in LDS for all T steps).
+//
+//   dh(t)[r][j] = d_out[t][r][j] + keep(t+1)[r] * sum_c dgates(t+1)[r][c] W_hh[c][j]
+//
+// The contraction over the 4H gate columns is split by OWNER: a wave multiplies ITS 64
+// columns of dgates(t+1) — which it has just produced, no exchange on the operand side —
+// with its 64 x H slice of W_hh into a partial dh for ALL H hidden units (K = 64, N = H:
+// 512 MFMAs, 32 independent accumulator tiles), and hands the 16 x 16 block of hidden
+// units 16 jt .. 16 jt + 15 to the wave that owns them.  Blocks travel in the accumulator
+// layout itself (lane l holds rows 4 (l >> 4) + v of column l & 15): one 16 B write-through
+// store per lane and block, no transposition on either side, and the receiving lane adds
+// its 32 incoming float4 in source order — a fixed summation order, bit-identical reruns.
+// Half the exchange traffic of gathering whole dgates rows (32 KB read + 32 KB written per
+// wave and step instead of 128 KB read), and the dgates operand never leaves the CU.
+// Gradients are unbounded, so there is no free tag bit: the classic form R1 of the guide —
+// sc1 stores, `s_waitcnt vmcnt(0)`, one relaxed agent-scope arrival per wave and step on
+// the tile's counter, one polling lane, ONE agent-scope acquire, then the loads.
+struct SeqBwdArgs {
+  int T, B;
+  float* gates;          // [T][B][4H] activated gates in, d loss / d pre-activation out
+  const float* w;        // [4H][H]
+  const float* c_all;    // [T][B][H]
+  const float* cm;       // [T+1][B][H] masked cell inputs (row t = c_in of step t)
+  const float* d_out;    // [T][B][H]
+  const float* keep;     // [T][B]
+};
+
+#define SQB_LP 36          // floats per (column, lane-column) row of the LDS weight slice: 32 + 4 (conflict-free b128 reads)
+
+template <int H>
+__global__ void __launch_bounds__(256, 1)
+k_lstm_seq_bwd(SeqBwdArgs a, unsigned* __restrict__ counters, float* P, int64_t p_half_floats, int nclusters, int* status) {
+  constexpr int NCG = H / 16;       // column groups = hidden-unit owners = 16-column blocks of a partial
+  static_assert(NCG == 32, "the partial-block layout below is written for H = 512");
+  extern __shared__ __attribute__((aligned(16))) char sq_smem[];
+  float* Wl = (float*)sq_smem;                      // [c = gate * 16 + hid (64)][li (16)][SQB_LP]: W_hh[gate H + 16 cg + hid][16 jt + li] at jt
+  float* Tl = Wl + 64 * 16 * SQB_LP;                // 4 x [gate][row][hid] transposition tiles
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cluster = blockIdx.x % nclusters, cg = blockIdx.x / nclusters;
+  const int li = lane & 15, lk = lane >> 4;
+  const int B = a.B, T = a.T;
+  for (int idx = tid; idx < 64 * H; idx += 256) {
+    const int c = idx / H, j = idx - c * H;
+    Wl[(c * 16 + (j & 15)) * SQB_LP + (j >> 4)] = a.w[((int64_t)((c >> 4) * H + 16 * cg + (c & 15))) * H + j];
+  }
+  __syncthreads();
+  float* Tw = Tl + wave * 1024;
+  const int tiles = B / 16;
+  const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(P, 0, (int)(2 * p_half_floats * 4), 0x00020000);
+  const int nrb = (B + 63) >> 6;
+  for (int rb = cluster; rb < nrb; rb += nclusters) {
+    const int tile = rb * 4 + wave;
+    const int row0 = tile * 16;
+    if (row0 >= B) continue;
+    unsigned* cnt = counters + tile * 32;
+    const int r0 = row0 + 4 * lk;
+    const int hcol = 16 * cg + li;
+    // partial blocks: [parity][tile][dst column group][src column group][lane][4]
+    const int64_t p_tile = (int64_t)tile * NCG * NCG * 256;
+    float dcr[4] = {0.f, 0.f, 0.f, 0.f};
+    bool failed = false;
+    for (int t = T - 1; t >= 0; --t) {
+      const bool first = t == T - 1;
+      // ---- this step's saved forward values, requested before the wait
+      float gi[4], gf[4], gg[4], go[4], ct[4], cin[4], dout[4], kn[4];
+      {
+        const float* gt = a.gates + ((int64_t)t * B + r0) * 4 * H + hcol;
+        const int64_t e0 = ((int64_t)t * B + r0) * H + hcol;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          gi[v] = gt[(int64_t)v * 4 * H]; gf[v] = gt[(int64_t)v * 4 * H + H];
+          gg[v] = gt[(int64_t)v * 4 * H + 2 * H]; go[v] = gt[(int64_t)v * 4 * H + 3 * H];
+          ct[v] = a.c_all[e0 + (int64_t)v * H];
+          cin[v] = a.cm[e0 + (int64_t)v * H];
+          dout[v] = a.d_out ? a.d_out[e0 + (int64_t)v * H] : 0.f;
+          kn[v] = first ? 1.0f : a.keep[(int64_t)(t + 1) * B + r0 + v];
+        }
+      }
+      // ---- dh_rec: the 32 partial blocks of this wave's (rows, hidden units) from step t + 1
+      float dhr[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!first) {
+        const unsigned want = (unsigned)NCG * (unsigned)(T - 1 - t);
+        int bad = 0;
+        if (lane == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SQ_SPIN_CAP) { bad = 1; break; }
+          }
+        }
+        bad = __builtin_amdgcn_readfirstlane(bad);
+        if (bad) { failed = true; break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const int pb = (int)(((((t + 1) & 1) * p_half_floats) + p_tile + (int64_t)cg * NCG * 256) * 4) + lane * 16;
+        sq_f4 part[NCG];
+#pragma unroll
+        for (int s = 0; s < NCG; ++s) part[s] = __builtin_bit_cast(sq_f4, __builtin_amdgcn_raw_buffer_load_b128(pr, pb + s * 1024, 0, 16));
+#pragma unroll
+        for (int s = 0; s < NCG; ++s) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) dhr[v] = dhr[v] + part[s][v];
+        }
+      }
+      // ---- the cell's backward (csrc/lstm.hip k_lstm_cell_bwd), in registers
+      float dgv[4][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float dh = dout[v] + (first ? 0.0f : dhr[v] * kn[v]);
+        const float tc = tanhf(ct[v]);
+        const float dc = (first ? 0.0f : dcr[v] * kn[v]) + dh * go[v] * (1.0f - tc * tc);
+        dgv[0][v] = dc * gg[v] * gi[v] * (1.0f - gi[v]);
+        dgv[1][v] = dc * cin[v] * gf[v] * (1.0f - gf[v]);
+        dgv[2][v] = dc * gi[v] * (1.0f - gg[v] * gg[v]);
+        dgv[3][v] = dh * tc * go[v] * (1.0f - go[v]);
+        dcr[v] = dc * gf[v];
+      }
+      if (t > 0) {
+        // ---- partial dh(t-1 side) = dgates(t)[own 64 columns] x W slice: A operand via one LDS transposition
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Tw[(g * 16 + 4 * lk + v) * 16 + li] = dgv[g][v];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        sq_f4 av[4];                                  // A[row = li][k slot = lk] for k-steps s = 0..15: gate lk, hidden s
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = *(const sq_f4*)(Tw + (lk * 16 + li) * 16 + 4 * q);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        sq_f4 acc[NCG];
+#pragma unroll
+        for (int jt = 0; jt < NCG; ++jt) acc[jt] = sq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          sq_f4 bq[8];
+          const float* brow = Wl + ((16 * lk + s) * 16 + li) * SQB_LP;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bq[k] = *(const sq_f4*)(brow + 4 * k);
+#pragma unroll
+          for (int jt = 0; jt < NCG; ++jt)
+            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s >> 2][s & 3], bq[jt >> 2][jt & 3], acc[jt], 0, 0, 0);
+        }
+        // ---- hand block jt to the owner of hidden units 16 jt ..: accumulator layout, 16 B per lane
+        const int ob = (int)((((t & 1) * p_half_floats) + p_tile + (int64_t)cg * 256) * 4) + lane * 16;
+#pragma unroll
+        for (int jt = 0; jt < NCG; ++jt)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sq_u4, acc[jt]), pr, ob + jt * (NCG * 1024), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- d loss / d pre-activation of this step, in place of the activated gates
+      {
+        float* gt = a.gates + ((int64_t)t * B + r0) * 4 * H + hcol;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          gt[(int64_t)v * 4 * H] = dgv[0][v]; gt[(int64_t)v * 4 * H + H] = dgv[1][v];
+          gt[(int64_t)v * 4 * H + 2 * H] = dgv[2][v]; gt[(int64_t)v * 4 * H + 3 * H] = dgv[3][v];
+        }
+      }
+    }
+    if (failed) {
+      if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+  (void)tiles;
+}
+
 static int* g_seq_status = nullptr;       // pinned host word the kernels write on a spin timeout
 static int g_seq_cus = 0;
 
@@ -333,9 +504,62 @@ static int seq_launch(const SeqFwdArgs& a, void* workspace, hipStream_t st) {
   return MIRL_OK;
 }
 
+template <int H>
+static int seq_bwd_launch(const SeqBwdArgs& a, void* workspace, hipStream_t st) {
+  constexpr int NCG = H / 16;
+  const int tiles = a.B / 16, nrb = (a.B + 63) / 64;
+  int ncl = g_seq_cus / NCG;
+  if (ncl < 1) return fail(MIRL_ERR_ARG, "lstm_seq_bwd: fewer compute units than column groups");
+  if (ncl > nrb) ncl = nrb;
+  const size_t cnt_bytes = align_up((size_t)tiles * 32 * sizeof(unsigned), 256);
+  const int64_t p_half = (int64_t)tiles * NCG * NCG * 256;
+  MIRL_HIP(hipMemsetAsync(workspace, 0, cnt_bytes, st));
+  const size_t lds = (size_t)(64 * 16 * SQB_LP + 4 * 1024) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MIRL_HIP(hipFuncSetAttribute((const void*)k_lstm_seq_bwd<H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int* status_dev = nullptr;
+  MIRL_HIP(hipHostGetDevicePointer((void**)&status_dev, g_seq_status, 0));
+  hipLaunchKernelGGL(k_lstm_seq_bwd<H>, dim3((unsigned)(ncl * NCG)), dim3(256), lds, st, a, (unsigned*)workspace,
+                     (float*)((char*)workspace + cnt_bytes), p_half, ncl, status_dev);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
 }  // namespace mirl
 
 using namespace mirl;
+
+extern "C" int mirl_lstm_seq_bwd_supported(int32_t T, int32_t B, int32_t H) {
+  // the partial blocks of a sweep must fit 32-bit buffer offsets: 2 x (B / 16) x 1 MiB
+  return (T >= 1 && B >= 16 && B % 16 == 0 && H == 512 && (int64_t)(B / 16) * 2 * 1048576 < 2147483648LL) ? 1 : 0;
+}
+
+extern "C" int mirl_lstm_seq_bwd_workspace_bytes(int32_t B, int32_t H, int64_t* bytes) {
+  if (!bytes || B <= 0 || H != 512 || B % 16) return fail(MIRL_ERR_ARG, "bad lstm_seq_bwd_workspace_bytes arguments");
+  const int64_t tiles = B / 16, ncg = H / 16;
+  *bytes = (int64_t)align_up((size_t)tiles * 32 * sizeof(unsigned), 256) + 2 * tiles * ncg * ncg * 256 * (int64_t)sizeof(float);
+  return MIRL_OK;
+}
+
+extern "C" int mirl_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, float* gates, const float* w_hh, const float* c_all,
+                                 const float* cm, const float* d_out, const float* keep, void* workspace, void* stream) {
+  if (!mirl_lstm_seq_bwd_supported(T, B, H)) return fail(MIRL_ERR_ARG, "lstm_seq_bwd: unsupported shape (B multiple of 16, H = 512)");
+  if (!gates || !w_hh || !c_all || !cm || !keep || !workspace || ((uintptr_t)workspace % 256))
+    return fail(MIRL_ERR_ARG, "bad lstm_seq_bwd arguments");
+  int rc = seq_init();
+  if (rc) return rc;
+  if (*(volatile int*)g_seq_status) {
+    *g_seq_status = 0;
+    return fail(MIRL_ERR_STATE, "an earlier lstm_seq launch gave up waiting for a peer workgroup (results of that sweep are invalid)");
+  }
+  SeqBwdArgs a{T, B, gates, w_hh, c_all, cm, d_out, keep};
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("k_lstm_seq_bwd", 4.0 * B * H * T * (8.0 + 3.0) + 4.0 * 4.0 * H * H, st);
+  return seq_bwd_launch<512>(a, workspace, st);
+}
 
 extern "C" int mirl_lstm_seq_supported(int32_t T, int32_t B, int32_t H) {
   return (T >= 1 && B >= 16 && B % 16 == 0 && (H == 128 || H == 256 || H == 512)) ? 1 : 0;

@@ -38,6 +38,12 @@ _FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "0") == "1"
 # LDS, h exchanged between workgroups through write-through stores + arrival counters) is
 # the default wherever it supports the shape; MIRL_LSTM_PERSISTENT=0 keeps the per-step path.
 _PERSISTENT = os.environ.get("MIRL_LSTM_PERSISTENT", "1") != "0"
+# The persistent BACKWARD sweep exchanges 32 KB of partial sums per wave and step (write-through);
+# measured 13.3 us per step at B = 64 and 17.9 at B = 256, but 28 at B = 512 where the chip-wide
+# 64 MB per step saturate the fabric — no better than the cell kernel + rocBLAS GEMM per step
+# (20.6 us inside the learner step; profiles/r03_lstm_probe_with_persistent_backward.jsonl).  It is
+# therefore the default for small per-GPU batches only (strong scaling: B = 64 per rank at 8 GPUs).
+_BWD_PERSISTENT_MAX_B = int(os.environ.get("MIRL_LSTM_BWD_PERSISTENT_MAX_B", "128"))
 
 
 def _p(t):
@@ -104,6 +110,33 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _backward_sweep(gates, c_all, cm, d_out, keep, w):
+    """The backward time loop: `gates` (T, B, 4H) activated gates -> d loss / d pre-activation, in place.
+    One persistent launch (csrc/lstm_seq.hip k_lstm_seq_bwd) where the shape is covered, else one
+    cell kernel + one recurrent GEMM per step."""
+    T, B, G = gates.shape
+    H = G // 4
+    st = _stream()
+    if _PERSISTENT and T >= 2 and B <= _BWD_PERSISTENT_MAX_B and lib.mirl_lstm_seq_bwd_supported(T, B, H) \
+            and w.data_ptr() % 16 == 0:
+        nbytes = C.c_int64()
+        check(lib.mirl_lstm_seq_bwd_workspace_bytes(B, H, C.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=gates.device)
+        check(lib.mirl_lstm_seq_bwd(T, B, H, _p(gates), _p(w), _p(c_all), _p(cm), _p(d_out), _p(keep), _p(ws), st),
+              "mirl_lstm_seq_bwd")
+        ws.record_stream(torch.cuda.current_stream())
+        return
+    dh_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+    dc_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
+    for t in range(T - 1, -1, -1):
+        check(lib.mirl_lstm_cell_bwd(
+            B, H, _p(gates[t]), _p(c_all[t]), _p(cm[t]), _p(d_out[t]), _p(dh_rec), _p(dc_rec),
+            _p(keep[t + 1]) if t + 1 < T else None, 1 if t == T - 1 else 0, st),
+            "mirl_lstm_cell_bwd")
+        if t > 0:
+            torch.mm(gates[t], w, out=dh_rec)
+
+
 class _LSTMSequence(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, bias, h0, c0, keep, track=True):
@@ -134,16 +167,7 @@ class _LSTMSequence(torch.autograd.Function):
         T, B, G = gates.shape
         H = G // 4
         d_out = d_out.float().contiguous()
-        dh_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
-        dc_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
-        st = _stream()
-        for t in range(T - 1, -1, -1):
-            check(lib.mirl_lstm_cell_bwd(
-                B, H, _p(gates[t]), _p(c_all[t]), _p(cm[t]), _p(d_out[t]), _p(dh_rec), _p(dc_rec),
-                _p(keep[t + 1]) if t + 1 < T else None, 1 if t == T - 1 else 0, st),
-                "mirl_lstm_cell_bwd")
-            if t > 0:
-                torch.mm(gates[t], w, out=dh_rec)
+        _backward_sweep(gates, c_all, cm, d_out, keep, w)
         dg = gates.reshape(T * B, G)                      # now d loss / d pre-activation
         d_x = dg.mm(w_ih.float()) if ctx.needs_input_grad[0] else None
         d_wih = dg.t().mm(x) if ctx.needs_input_grad[1] else None
@@ -182,16 +206,7 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
         T, B, G = gates.shape
         H = G // 4
         d_out = d_out.float().contiguous()
-        dh_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
-        dc_rec = torch.empty((B, H), dtype=torch.float32, device=gates.device)
-        st = _stream()
-        for t in range(T - 1, -1, -1):
-            check(lib.mirl_lstm_cell_bwd(
-                B, H, _p(gates[t]), _p(c_all[t]), _p(cm[t]), _p(d_out[t]), _p(dh_rec), _p(dc_rec),
-                _p(keep[t + 1]) if t + 1 < T else None, 1 if t == T - 1 else 0, st),
-                "mirl_lstm_cell_bwd")
-            if t > 0:
-                torch.mm(gates[t], w, out=dh_rec)
+        _backward_sweep(gates, c_all, cm, d_out, keep, w)
         d_whh = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[1] else None
         return gates, d_whh, None, None, None, None
 

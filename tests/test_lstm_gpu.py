@@ -244,3 +244,33 @@ def test_persistent_sweep_under_uneven_load_and_back_to_back(T, B, H):
     st = C.c_int32(-1)
     check(lib.mirl_lstm_seq_status(C.byref(st)))
     assert st.value == 0
+
+
+@pytest.mark.parametrize("T,B", [(80, 512), (9, 256), (5, 48), (33, 1024)])
+def test_persistent_backward_sweep_equals_the_per_step_path(T, B, monkeypatch):
+    """mirl_lstm_seq_bwd (one launch: cell backward in registers, the recurrent contraction split by
+    column owner, 16 x 16 partial blocks summed in a fixed order) against mirl_lstm_cell_bwd + one
+    recurrent GEMM per step on the same saved forward state: d loss / d pre-activation of every step.
+    B = 1024: clusters loop over row blocks; B = 48: a ragged row block."""
+    from rltime_amd.models.torch import lstm_seq
+    H = 512
+    gx, w, h0, c0, keep = _sweep_inputs(T, B, H, 3 * T + B)
+    monkeypatch.setattr(lstm_seq, "_PERSISTENT", False)
+    gates = gx.clone()
+    out, hm, cm, c_all, _, _ = lstm_seq._forward_sweep(gates, w, h0, c0, keep, True)
+    g = torch.Generator(device="cuda").manual_seed(T)
+    d_out = torch.randn(T, B, H, device="cuda", generator=g)
+    res = []
+    monkeypatch.setattr(lstm_seq, "_BWD_PERSISTENT_MAX_B", 1 << 20)       # every batch size through the persistent kernel
+    for persistent in (True, False):
+        monkeypatch.setattr(lstm_seq, "_PERSISTENT", persistent)
+        dg = gates.clone()
+        lstm_seq._backward_sweep(dg, c_all, cm, d_out, keep, w)
+        res.append(dg)
+    scale = float(res[1].abs().max())
+    np.testing.assert_allclose(res[0].cpu().numpy() / scale, res[1].cpu().numpy() / scale, rtol=1e-4, atol=2e-6)
+    # fixed summation order: a second persistent run is bit-identical
+    monkeypatch.setattr(lstm_seq, "_PERSISTENT", True)
+    dg = gates.clone()
+    lstm_seq._backward_sweep(dg, c_all, cm, d_out, keep, w)
+    assert torch.equal(dg, res[0])

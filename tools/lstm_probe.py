@@ -22,6 +22,7 @@ def main():
         w = (torch.randn(4 * H, H, device="cuda", generator=g) / H ** 0.5).contiguous()
         h0, c0 = torch.randn(B, H, device="cuda", generator=g), torch.randn(B, H, device="cuda", generator=g)
         keep = (torch.rand(T, B, device="cuda", generator=g) > 0.01).float()
+        lstm_seq._BWD_PERSISTENT_MAX_B = 1 << 20
         for name, pers, step in (("persistent", True, False), ("gemm+cell", False, False), ("step_kernel", False, True)):
             for need_grad in (False, True):
                 lstm_seq._PERSISTENT, lstm_seq._FUSED_STEP = pers, step
@@ -44,6 +45,20 @@ def main():
                     torch.cuda.synchronize()
                     total += e0.elapsed_time(e1)
                 ms = total / reps
+                if need_grad and not step and lstm_seq.lib.mirl_lstm_seq_bwd_supported(T, B, H):
+                    out, hm, cm, c_all, _, _ = lstm_seq._forward_sweep(gates, w, h0, c0, keep, True)
+                    d_out = torch.randn_like(out)
+                    saved = gates.clone()
+                    tot = 0.0
+                    for _ in range(reps + 2):
+                        dg = saved.clone()
+                        e0.record()
+                        lstm_seq._backward_sweep(dg, c_all, cm, d_out, keep, w)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        tot += e0.elapsed_time(e1) if _ >= 2 else 0.0
+                    print(json.dumps({"variant": name + " BACKWARD", "T": T, "B": B, "H": H, "ms_per_sweep": round(tot / reps, 4),
+                                      "us_per_step": round(tot / reps * 1e3 / T, 2)}), flush=True)
                 print(json.dumps({"variant": name, "need_grad": need_grad, "T": T, "B": B, "H": H,
                                   "ms_per_sweep": round(ms, 4), "us_per_step": round(ms * 1e3 / T, 2),
                                   "f32_mfma_floor_us_per_step": round(2.0 * B * H * 4 * H / 157.3e12 * 1e6, 2)}), flush=True)
