@@ -94,6 +94,12 @@ def parse():
     ap.add_argument("--envs", type=int, default=None, help="envs (per GPU when weak, whole job when strong)")
     ap.add_argument("--replay-size", type=int, default=1000000, help="transitions (per GPU when weak, whole job when strong)")
     ap.add_argument("--no-acting", action="store_true", help="feed pre-generated actor output instead of running the device actor's policy forward inside the step")
+    ap.add_argument("--overlap-acting", default="auto", choices=["auto", "on", "off"],
+                    help="run the acting + ingest of iteration k+1 on a second HIP stream against iteration k's training "
+                         "(MultiStepTrainer overlap_acting: the actor's weights are one learner step old, like the reference's async "
+                         "actors).  auto: on when a rank trains at most 8192 rows per step (strong scaling at >= 8 GPUs: the learner's "
+                         "kernels no longer fill the chip; measured 23.9 vs 27.4 ms per step at B=64, T=80) — a tie at B=256 and a loss "
+                         "at B=512 (138.9 vs 136.1), where it stays off")
     ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,7 +133,12 @@ def build_config(args, rank, world, scaling):
         targs["history_mode"]["args"]["frame_stack_dedup"] = True
         config.setdefault("env_args", {})["frame_stack"] = True
     deep_dictionary_update(config, {"acting": {"actor_envs": args.envs or spec["envs"]}, "training": {"args": targs}})
-    return shard_config(config, rank, world, scaling)
+    config = shard_config(config, rank, world, scaling)
+    ta = config["training"]["args"]
+    if "overlap_acting" not in targs and not args.no_acting:
+        rows = int(ta.get("mbatch_size") or 0) * int(ta.get("nstep_train") or 1)
+        ta["overlap_acting"] = args.overlap_acting == "on" or (args.overlap_acting == "auto" and 0 < rows <= 8192 and ta.get("nstep_train", 1) > 1)
+    return config
 
 
 def build_trainer(config, device, use_graph, data_parallel):
@@ -536,7 +547,7 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
     n = targs.get("nstep_target") or targs["nstep_train"]
     res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
                table=table, prof_step_ms=prof_step_ms, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
-               hist_stats=hist_stats, fill_s=fill_s, rccl=rccl)
+               hist_stats=hist_stats, fill_s=fill_s, rccl=rccl, overlap=bool(targs.get("overlap_acting")) and not args.no_acting)
     trainer.actors = real_actors
     hist.close()
     if hasattr(real_actors, "_graphed"):
@@ -671,6 +682,7 @@ def main():
                 "envs_per_gpu": envs, "acted_transitions_per_step_per_gpu": res["acted"] / args.steps,
                 "acting_policy_forward_in_step": not args.no_acting,
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
+                "acting_overlapped_on_second_stream": res["overlap"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2)},
             "roofline": {

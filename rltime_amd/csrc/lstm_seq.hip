@@ -290,6 +290,214 @@ k_lstm_seq_fwd(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t 
 }
 
 // ---------------------------------------------------------------------------
+// The same sweep for SMALL per-GPU batches (strong scaling: B = 64 per rank at 8 GPUs).  With
+// 16 hidden units per wave a batch of 64 sequences is 4 row tiles x 32 column groups = 128
+// waves: one eighth of the chip works and every step still costs a full 512-MFMA chain
+// (8.7 us per step measured at B = 64).  Here a wave owns 4 hidden units x 4 gates = ONE
+// 16-column MFMA tile: 128 MFMAs per step on four k-interleaved accumulators (1.7 us), four
+// times as many waves.  Lane n of a 16-lane row holds gate n / 4 of hidden n % 4, so the four
+// gates of a hidden unit sit in lanes n % 4 + {0, 4, 8, 12}: pre-activations are gathered with
+// three cross-lane reads (ds_bpermute) per row.  Exchange layout, tags and the acquire-before-
+// re-sweep rule are those of k_lstm_seq_fwd; a tile now has H / 4 producers.
+template <int H>
+__global__ void __launch_bounds__(256, 1)
+k_lstm_seq_fwd_narrow(SeqFwdArgs a, unsigned* __restrict__ counters, float* X, int64_t x_half_floats, int nclusters, int* status) {
+  constexpr int KQ = H / 16, KG = H / 4, PW = H + 4;
+  constexpr int NP = H / 4;         // producers per row tile
+  extern __shared__ __attribute__((aligned(16))) char sq_smem[];
+  float* Wl = (float*)sq_smem;                      // [16 columns = gate * 4 + hid][PW]
+  float* Tl = Wl + 16 * PW;                         // 4 x [16 rows][4]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cluster = blockIdx.x % nclusters, cgn = blockIdx.x / nclusters;
+  const int li = lane & 15, lk = lane >> 4;
+  const int g0 = li >> 2, hid = li & 3;             // this lane's gate and hidden unit (4 cgn + hid)
+  const int B = a.B, T = a.T;
+  for (int idx = tid; idx < 16 * (H / 4); idx += 256) {
+    const int c = idx / (H / 4), k4 = idx - c * (H / 4);
+    const sq_f4 v = *(const sq_f4*)(a.w + ((int64_t)((c >> 2) * H + 4 * cgn + (c & 3))) * H + 4 * k4);
+    *(sq_f4*)(Wl + c * PW + 4 * k4) = v;
+  }
+  __syncthreads();
+  float* Tw = Tl + wave * 64;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(X, 0, (int)(3 * x_half_floats * 4), 0x00020000);
+  const int pk0 = 4 * cgn;                           // this wave publishes hidden units pk0 .. pk0 + 3: lanes 0..15 = rows
+  const int p_slot = (((pk0 % KG) >> 2) * 64 + ((lane & 15) + 16 * (pk0 / KG))) * 4;
+  const int nrb = (B + 63) >> 6;
+  const int b_off = (li * PW + KG * lk);
+  const int src1 = (lane & 48) | ((li + 4) & 15), src2 = (lane & 48) | ((li + 8) & 15), src3 = (lane & 48) | ((li + 12) & 15);
+  for (int rb = cluster; rb < nrb; rb += nclusters) {
+    const int tile = rb * 4 + wave;
+    const int row0 = tile * 16;
+    if (row0 >= B) continue;
+    unsigned* cnt = counters + tile * 32;
+    const int64_t x_tile = (int64_t)tile * KQ * 256;
+    const int r0 = row0 + 4 * lk;
+    const int hcol = 4 * cgn + hid;
+    float c_in[4], hmv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float k0 = a.keep[r0 + v];
+      c_in[v] = a.c0[(int64_t)(r0 + v) * H + hcol] * k0;
+      hmv[v] = a.h0[(int64_t)(r0 + v) * H + hcol] * k0;
+    }
+    bool failed = false;
+    for (int t = -1; t < T; ++t) {
+      float hv[4], cv[4], act[4];
+      if (t >= 0) {
+        float gxv[4], kn[4];
+        const float* gxt = a.gx + ((int64_t)t * B + r0) * 4 * H + g0 * H + hcol;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          gxv[v] = gxt[(int64_t)v * 4 * H];
+          kn[v] = (t + 1 < T) ? a.keep[(int64_t)(t + 1) * B + r0 + v] : 1.0f;
+        }
+        sq_f4 av[KQ];
+        if (t == 0) {
+          const unsigned want = (unsigned)NP;
+          int bad = 0;
+          if (lane == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > SQ_SPIN_CAP) { bad = 1; break; }
+            }
+          }
+          bad = __builtin_amdgcn_readfirstlane(bad);
+          if (bad) { failed = true; break; }
+          asm volatile("" ::: "memory");
+        }
+        {
+          const unsigned tmask = t >= 1 ? sq_tag(t - 1) : 0u;
+          const int xb = (int)(((t == 0 ? 2 * x_half_floats : (t & 1) * x_half_floats) + x_tile) * 4) + lane * 16;
+          unsigned spins = 0;
+          if (t >= 1) {
+            // pre-poll: one word of every producer's block (row 15 of its 4 hidden units), two loads per lane
+            const unsigned* base = (const unsigned*)(X + (t & 1) * x_half_floats + x_tile);
+            for (;;) {
+              unsigned ok = 1u;
+#pragma unroll
+              for (int half = 0; half < (NP + 63) / 64; ++half) {
+                const int pcg = lane + 64 * half;
+                if (pcg < NP) {
+                  const int k0 = 4 * pcg;
+                  const unsigned wv = __hip_atomic_load(base + (((k0 % KG) >> 2) * 64 + (15 + 16 * (k0 / KG))) * 4, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                  ok &= (((wv ^ tmask) & 0x40000000u) == 0u) ? 1u : 0u;
+                }
+              }
+              if (__all(ok != 0u)) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > SQ_SPIN_CAP) { failed = true; break; }
+            }
+            if (failed) break;
+            asm volatile("" ::: "memory");
+          }
+          for (;;) {
+            sq_u4 rv[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) rv[q] = __builtin_amdgcn_raw_buffer_load_b128(xr, xb + q * 1024, 0, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned seen = 0;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+              const sq_u4 y = rv[q] ^ tmask;
+              seen |= (y[0] | y[1]) | (y[2] | y[3]);
+              av[q] = __builtin_bit_cast(sq_f4, y);
+            }
+            if (t == 0 || __all((seen & 0x40000000u) == 0u)) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // see k_lstm_seq_fwd: stale tagged lines can sit in L1
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SQ_SPIN_CAP) { failed = true; break; }
+          }
+          if (failed) break;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sq_f4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = sq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+          const sq_f4 bv = *(const sq_f4*)(Wl + b_off + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][j], bv[j], acc[j], 0, 0, 0);
+        }
+        // ---- pre-activation of (row, own gate, own hidden), then the other three gates of that hidden unit
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float pre = ((acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v])) + gxv[v];
+          const float mine = g0 == 2 ? sq_tanh(pre) : sq_sigmoid(pre);
+          act[v] = mine;
+          const float o1 = __shfl(mine, src1), o2 = __shfl(mine, src2), o3 = __shfl(mine, src3);   // gates g0+1, g0+2, g0+3 (mod 4)
+          float gate[4];
+          gate[g0] = mine; gate[(g0 + 1) & 3] = o1; gate[(g0 + 2) & 3] = o2; gate[(g0 + 3) & 3] = o3;
+          cv[v] = gate[1] * c_in[v] + gate[0] * gate[2];
+          hv[v] = gate[3] * sq_tanh(cv[v]);
+          c_in[v] = cv[v] * kn[v];
+          hmv[v] = hv[v] * kn[v];
+        }
+      }
+      if (t + 1 < T) {
+        if (g0 == 0) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Tw[(4 * lk + v) * 4 + hid] = hmv[v];
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const sq_f4 chunk = *(const sq_f4*)(Tw + (lane & 15) * 4);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (t < 0) {
+          const int off = (int)((2 * x_half_floats + x_tile + p_slot) * 4);
+          if (lane < 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sq_u4, chunk), xr, off, 0, 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const int off = (int)(((((t + 1) & 1) * x_half_floats) + x_tile + p_slot) * 4);
+          if (lane < 16) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sq_u4, chunk) | sq_tag(t), xr, off, 0, 16);
+        }
+      }
+      const bool owner = g0 == 0;                    // one of the four lanes of a hidden unit writes its h / c
+      if (t < 0) {
+        if (a.hm && owner) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            a.hm[(int64_t)(r0 + v) * H + hcol] = hmv[v];
+            a.cm[(int64_t)(r0 + v) * H + hcol] = c_in[v];
+          }
+        }
+        continue;
+      }
+      const int64_t e0 = ((int64_t)t * B + r0) * H + hcol;
+      if (owner) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int64_t e = e0 + (int64_t)v * H;
+          if (a.out) a.out[e] = hv[v];
+          if (a.c_all) a.c_all[e] = cv[v];
+          if (a.hm) { a.hm[e + (int64_t)B * H] = hmv[v]; a.cm[e + (int64_t)B * H] = c_in[v]; }
+        }
+        if (t == T - 1 && a.h_last) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            a.h_last[(int64_t)(r0 + v) * H + hcol] = hmv[v];
+            a.c_last[(int64_t)(r0 + v) * H + hcol] = c_in[v];
+          }
+        }
+      }
+      if (a.save) {
+        float* gxs = a.gx + ((int64_t)t * B + r0) * 4 * H + g0 * H + hcol;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gxs[(int64_t)v * 4 * H] = act[v];
+      }
+    }
+    if (failed) {
+      if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The backward sweep as one persistent launch (same ownership as the forward: wave =
 // 16-row tile x 16 hidden units x 4 gates, W_hh slice resident in LDS for all T steps).
 //
@@ -481,6 +689,23 @@ template <int H>
 static int seq_launch(const SeqFwdArgs& a, void* workspace, hipStream_t st) {
   constexpr int NCG = H / 16, KQ = H / 16;
   const int tiles = a.B / 16, nrb = (a.B + 63) / 64;
+  // small batches: four times as many, four times narrower waves (k_lstm_seq_fwd_narrow) while they all
+  // fit the chip at once (every wave a step waits for must be resident)
+  static const int narrow_env = getenv("MIRL_LSTM_SEQ_NARROW") ? atoi(getenv("MIRL_LSTM_SEQ_NARROW")) : -1;
+  const bool narrow = narrow_env >= 0 ? (narrow_env != 0 && nrb * (H / 4) <= g_seq_cus) : (nrb * (H / 4) <= g_seq_cus);
+  if (narrow) {
+    const size_t cnt_b = (size_t)tiles * 32 * sizeof(unsigned);
+    const int64_t x_half_n = (int64_t)tiles * KQ * 256;
+    unsigned* counters_n = (unsigned*)workspace;
+    float* Xn = (float*)((char*)workspace + align_up(cnt_b, 256));
+    MIRL_HIP(hipMemsetAsync(workspace, 0, align_up(cnt_b, 256) + (size_t)(2 * x_half_n) * sizeof(float), st));
+    const size_t lds_n = (size_t)(16 * (H + 4) + 4 * 64) * sizeof(float);
+    int* status_n = nullptr;
+    MIRL_HIP(hipHostGetDevicePointer((void**)&status_n, g_seq_status, 0));
+    hipLaunchKernelGGL(k_lstm_seq_fwd_narrow<H>, dim3((unsigned)(nrb * (H / 4))), dim3(256), lds_n, st, a, counters_n, Xn, x_half_n, nrb, status_n);
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
   int ncl = g_seq_cus / NCG;
   if (ncl < 1) return fail(MIRL_ERR_ARG, "lstm_seq_fwd: fewer compute units than column groups");
   if (ncl > nrb) ncl = nrb;
