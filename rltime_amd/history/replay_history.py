@@ -51,6 +51,17 @@ def _host_example(state):
     return leaf(state)
 
 
+def global_sampling_rows(mbatch, world, share, quantum=None):
+    """Rows of ONE rank's padded batch under exact global sampling (mirl_replay_sample_global) for a
+    shard holding `share` = P_r / P_g of the global priority mass: the B_g = mbatch * world strata
+    have width P_g / B_g, so a range of mass P_r contains at most ceil(B_g * share) + 1 stratum
+    points; + 1 for the rounding of the cumulative sums, rounded up to a multiple of `quantum`
+    (default max(4, mbatch // 8): few distinct batch shapes).  Returns (rows, bound)."""
+    q = int(quantum) if quantum else max(4, mbatch // 8)
+    bound = int(np.ceil(mbatch * world * float(share))) + 2
+    return ((bound + q - 1) // q) * q, bound
+
+
 class _Layout:
     """Shape of one stored ``next_state`` pytree (sequential.py:128-146:
     {"x": obs | tuple(obs, extra...), "layer{i}_state": {} | {hx, cx, initials}})."""
@@ -560,9 +571,7 @@ class PrioritizedReplayHistoryBuffer(ReplayHistoryBuffer):
         """Rows of this rank's padded batch for a shard holding `share` = P_r / P_g of
         the global priority mass (see enable_global_sampling)."""
         dp, quantum = self._global
-        q = int(quantum) if quantum else max(4, B // 8)
-        bound = int(np.ceil(B * dp.world * float(share))) + 2
-        return ((bound + q - 1) // q) * q, bound
+        return global_sampling_rows(B, dp.world, share, quantum)
 
     def check_dropped_strata(self):
         """Strata that did not fit a padded batch since the last check (one host read;

@@ -184,3 +184,53 @@ def test_sequence_priority_matches_numpy(T):
         assert k.value == scalar_kind(want), (T, trial)
         rtol = 1.3e-7 if k.value == 1 else 4.5e-16
         assert abs(v.value - float(want)) <= rtol * float(want), (T, trial, v.value, float(want))
+
+
+def test_global_sampling_rows_bound_every_stratum_fits():
+    """Exact global sampling sizes a rank's padded batch from the exchanged shard totals
+    (history/replay_history.py:global_sampling_rows): for ANY table of shard masses and ANY
+    uniforms, the strata whose mass point falls into a shard's cumulative range number at most
+    `bound` — so no stratum can be dropped, whatever the imbalance."""
+    from rltime_amd.history.replay_history import global_sampling_rows
+    rs = np.random.RandomState(0)
+    for trial in range(400):
+        R = int(rs.choice([2, 3, 4, 8]))
+        B = int(rs.choice([4, 8, 64, 512]))
+        P = np.abs(rs.randn(R)) ** rs.choice([1, 3]) + 1e-9
+        if trial % 5 == 0:
+            P[rs.randint(R)] *= 1000.0                      # one shard owns almost all the mass
+        Bg, Pg = B * R, P.sum()
+        seg = Pg / Bg
+        u = rs.rand(Bg)
+        if trial % 7 == 0:
+            u[:] = rs.choice([0.0, 1.0 - 1e-12])            # all points at a stratum edge
+        mass = (u + np.arange(Bg)) * seg
+        edges = np.concatenate([[0.0], np.cumsum(P)])
+        edges[-1] = np.inf
+        total = 0
+        for r in range(R):
+            mine = int(((mass >= edges[r]) & (mass < edges[r + 1])).sum())
+            rows, bound = global_sampling_rows(B, R, P[r] / Pg)
+            assert mine <= bound <= rows, (trial, r, mine, bound, rows)
+            assert rows % max(4, B // 8) == 0
+            total += mine
+        assert total == Bg
+
+
+def test_bench_overlap_rule_and_strong_shares():
+    """bench.py: the per-rank config of the strong-scaling line (global B = 512, 256 envs, 1M transitions
+    split over the ranks) and the acting-overlap rule (on when a rank trains <= 8192 rows per step)."""
+    import argparse
+    import bench
+    base = dict(config="iqn_lstm", mbatch=None, nstep_train=None, burn_in=None, nstep_target=None, envs=None,
+                replay_size=1000000, train_arg=[], frame_dedup=False, no_acting=False, overlap_acting="auto")
+    for world, want_b, want_e, want_overlap in ((1, 512, 256, False), (2, 256, 128, False), (4, 128, 64, False), (8, 64, 32, True)):
+        cfg = bench.build_config(argparse.Namespace(**base), world - 1, world, "strong")
+        ta = cfg["training"]["args"]
+        assert ta["mbatch_size"] == want_b and cfg["acting"]["actor_envs"] == want_e
+        assert ta["history_mode"]["args"]["size"] == 1000000 // world
+        assert cfg["acting"]["env_base"] == (world - 1) * want_e and bool(ta["overlap_acting"]) == want_overlap
+    weak = bench.build_config(argparse.Namespace(**base), 3, 8, "weak")
+    assert weak["training"]["args"]["mbatch_size"] == 512 and not weak["training"]["args"]["overlap_acting"]
+    forced = bench.build_config(argparse.Namespace(**dict(base, overlap_acting="on")), 0, 1, "strong")
+    assert forced["training"]["args"]["overlap_acting"]
