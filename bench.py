@@ -57,6 +57,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF headline is 2:1 sparse)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32)
 
 CONFIGS = {
@@ -543,6 +544,22 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
         _lib.check(_lib.lib.mirl_profile_set(0))
         table = _lib.profile_table()
 
+    if want_tables and os.environ.get("BENCH_GEMM_SHAPES"):
+        # one extra step under the torch profiler: every library GEMM call with its operand shapes
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            one_step()
+            torch.cuda.synchronize()
+        rows = []
+        for ev in prof.key_averages(group_by_input_shape=True):
+            if ev.key in ("aten::mm", "aten::addmm", "aten::_addmm_activation", "aten::bmm", "aten::addmm_"):
+                rows.append({"op": ev.key, "shapes": str(ev.input_shapes), "calls": ev.count,
+                             "device_ms": round(getattr(ev, "device_time_total", getattr(ev, "cuda_time_total", 0)) / 1e3, 3)})
+        rows.sort(key=lambda r: -r["device_ms"])
+        with open(os.environ["BENCH_GEMM_SHAPES"], "w") as f:
+            for r in rows:
+                f.write(json.dumps(r) + "\n")
+
     T, P, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs["mbatch_size"]
     n = targs.get("nstep_target") or targs["nstep_train"]
     res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
@@ -658,6 +675,15 @@ def main():
                 entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
                               "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn") and by > 0:
+                # the split-bf16 GEMMs record their f32 flop (2 M N K) in the bytes slot; they issue six bf16 MFMAs
+                # per f32 product block, so the f32 product is priced against 2.5 PFLOP/s / 6
+                tf = by / (avg_us * 1e-6) / 1e12
+                entry.update({"bound": "mfma", "algorithmic_bytes_per_launch": None, "achieved_GBps": None, "frac_of_hbm_peak": None,
+                              "flop_per_launch": by, "achieved_TFLOPs": round(tf, 1), "issued_bf16_TFLOPs": round(6 * tf, 1),
+                              "peak_TFLOPs": round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "peak_is": "dense bf16 MFMA peak / 6 part products",
+                              "frac_of_bf16x6_peak": round(6 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                              "x_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 3)})
             kernels.append(entry)
         head = summary(res, world, args.steps)
         mode_text = {"strong": "strong scaling: the configured batch (global B=%d), envs and replay size are whole-job values "

@@ -466,6 +466,29 @@ int mirl_conv2_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const
                         int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx,
                         void* stream);
 
+/* ---- f32 GEMMs of the wide layers on the bf16 matrix pipe (csrc/gemm3.hip).  Replaces the
+ * library f32 GEMMs behind the nn.Linear layers of the reference's recurrent IQN model
+ * (rltime/policies/torch/dqn.py:50-112 dueling head, rltime/policies/torch/iqn.py:82-102
+ * quantile layer, rltime/models/torch/modules/lstm.py:60-81 input projection) and the data /
+ * weight gradients autograd derives for them.  Each f32 operand element is split exactly into
+ * three bf16 parts (hi + mid + lo = x) while its tile is staged; six of the nine part products
+ * are accumulated in f32 (the three dropped ones are < 2^-23 |a||b| per term), so the result
+ * is an f32 GEMM: tests/test_gemm3_gpu.py holds it to the float64 product at least as tightly
+ * as the library's f32 GEMM.  Non-finite inputs give NaN.  Row-major, strides in floats:
+ *   layout 0 "NT": C[M][N] = A[M][K] . B[N][K]^T (+ bias[N], ReLU if relu)      nn.Linear forward
+ *   layout 1 "NN": C[M][N] = A[M][K] . B[K][N]                                   data gradient
+ *   layout 2 "TN": C[M][N] = A[K][M]^T . B[K][N]                                 weight gradient
+ * K % 16 == 0.  k-contiguous operands (A in NT/NN, B in NT): 16-byte aligned, ld % 4 == 0.
+ * TN splits K over workgroups into partial tiles in `workspace`
+ * (mirl_gemm3_workspace_bytes) that a second kernel sums in a fixed order (deterministic);
+ * no bias / ReLU there, C 16-byte aligned, ldc % 4 == 0, N % 4 == 0.
+ * mirl_gemm3_supported() gates layout and shape; otherwise MIRL_ERR_ARG.                  */
+int mirl_gemm3_supported(int32_t layout, int64_t M, int64_t N, int64_t K);
+int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, int64_t K, int64_t* bytes);
+int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+               const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

@@ -1,0 +1,355 @@
+// gemm3.hip — the network's wide f32 GEMMs on the bf16 matrix pipe without giving up f32 results.
+//
+// What it replaces: the hipBLASLt f32 GEMMs behind the reference's nn.Linear layers of the recurrent IQN
+// model (policies/torch/dqn.py:50-112 dueling head, iqn.py:82-102 quantile layer, modules/lstm.py:60-81
+// input projection) and their data / weight gradients — 86 of the 136 ms learner step at BASELINE
+// configs[3], already at 0.8-0.9 of the f32 MFMA peak (157 TFLOP/s = 1/16 of the bf16 rate).
+//
+// How: every f32 operand element is split EXACTLY into three bf16 parts while its tile is staged into LDS,
+//     x = hi + mid + lo,   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// (three 8-bit significands cover f32's 24 bits; both subtractions are exact), and six of the nine part
+// products are accumulated in f32 by v_mfma_f32_32x32x16_bf16, smallest first:
+//     a.b ~= lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi
+// The three dropped products (mid.lo, lo.mid, lo.lo) are below 2^-23 |a||b| per term — the size of the
+// rounding a plain f32 fma chain commits per product; tests/test_gemm3_gpu.py holds the result to the
+// float64 product at least as tightly as the library's f32 GEMM on the same inputs.  Six bf16 MFMAs per
+// 32x32x16 block of f32 work price the f32 product at 2.5 PFLOP/s / 6 = 417 TFLOP/s peak, 2.65x the f32 pipe.
+// Non-finite inputs are not preserved (inf - inf in the split gives NaN); the callers' activations are finite.
+//
+// Tiling: one workgroup = 256 x 256 outputs, 8 waves (2 along M x 4 along N, 128 x 64 each = 4 x 2 MFMA tiles,
+// 128 accumulator registers), K in steps of 16 floats.  LDS holds two stages of six bf16 planes
+// [operand A|B][part][256 rows][16 k], 48-byte row pitch (ds_read_b128 of a 32-row fragment is conflict free),
+// 147 456 bytes: one workgroup per CU, two waves per SIMD.  Per K-step a wave issues 48 MFMAs (1 536 cycles on its
+// SIMD's matrix pipe, 3 072 for the pair) against 18 fragment reads, 2 x 16-byte global loads, ~90 VALU split ops
+// and 12 LDS writes; the two waves of a SIMD run the stage/compute halves of the step in opposite order so one
+// splits while the other multiplies.  Global loads for tile k+2 are in flight across the (raw) barrier.
+//
+// Operand forms (row-major, strides in floats): element (row, k) of an operand is either k-contiguous
+// (base[row*ld + k]: activations / weights as stored) or k-strided (base[k*ld + row]: the transposed use in
+// a weight gradient or an un-transposed weight in a data gradient).  layout 0 "NT": C = A[M][K] . B[N][K]^T (+bias,
+// ReLU); 1 "NN": C = A[M][K] . B[K][N]; 2 "TN": C = A[K][M]^T . B[K][N], K split over workgroups into
+// partial tiles that a second deterministic kernel sums.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace mirl {
+
+typedef __bf16 g3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float g3_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G3_PITCH = 48;                 // bytes per LDS row: 16 bf16 + 16 B pad
+constexpr int G3_PLANE = 256 * G3_PITCH;     // one part of one operand
+constexpr int G3_STAGE = 6 * G3_PLANE;
+constexpr int G3_LDS = 2 * G3_STAGE;
+
+struct G3Args {
+  const float* A; const float* B; float* C; const float* bias;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;
+  int relu;
+  int mt, nt;            // output tiles along M / N
+  int splits;            // K chunks (1 = none); with splits > 1, C is [splits][M][N] partials (ldc = N)
+  int steps_per_split;   // K-steps of 16 per chunk
+  int order;             // 0: the two waves of a SIMD take opposite stage/compute orders; 1: all stage first; 2: all compute first
+};
+
+__device__ __forceinline__ unsigned g3_pk(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// x[0..3] (four consecutive k of one row) -> three 8-byte groups of bf16 parts
+__device__ __forceinline__ void g3_split4(const float (&x)[4], uint2& h, uint2& m, uint2& l) {
+  unsigned ph[2], pm[2], pl[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = x[2 * e], x1 = x[2 * e + 1];
+    ph[e] = g3_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(ph[e] << 16), r1 = x1 - __uint_as_float(ph[e] & 0xffff0000u);
+    pm[e] = g3_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(pm[e] << 16), s1 = r1 - __uint_as_float(pm[e] & 0xffff0000u);
+    pl[e] = g3_pk(s0, s1);
+  }
+  h = make_uint2(ph[0], ph[1]); m = make_uint2(pm[0], pm[1]); l = make_uint2(pl[0], pl[1]);
+}
+
+// One operand's loader state: two rows per thread (r and r + 128 of the 256-row tile), four consecutive k each.
+template <bool KC>
+struct G3Loader {
+  const float* p[2];
+  int64_t step;          // pointer advance per K-step
+  int64_t ld;
+  int lds_off;           // byte offset of this thread's first row inside a plane
+  __device__ __forceinline__ void init(const float* base, int64_t ld_, int64_t row0, int64_t rows, int64_t k0, int t) {
+    ld = ld_;
+    if (KC) {
+      const int r = t >> 2, kq = t & 3;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t row = row0 + r + 128 * h; if (row > rows - 1) row = rows - 1;
+        p[h] = base + row * ld + k0 + kq * 4;
+      }
+      step = 16;
+      lds_off = r * G3_PITCH + kq * 8;
+    } else {
+      const int kq = t >> 7, r = t & 127;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t row = row0 + r + 128 * h; if (row > rows - 1) row = rows - 1;
+        p[h] = base + (k0 + kq * 4) * ld + row;
+      }
+      step = 16 * ld;
+      lds_off = r * G3_PITCH + kq * 8;
+    }
+  }
+  __device__ __forceinline__ void load(float (&v)[2][4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (KC) {
+        const float4 q = *reinterpret_cast<const float4*>(p[h]);
+        v[h][0] = q.x; v[h][1] = q.y; v[h][2] = q.z; v[h][3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[h][e] = p[h][e * ld];
+      }
+      p[h] += step;
+    }
+  }
+  // split + write both rows into the three planes of this operand at `planes`
+  __device__ __forceinline__ void store(char* planes, const float (&v)[2][4]) const {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint2 a, b, c;
+      g3_split4(v[h], a, b, c);
+      char* d = planes + lds_off + h * 128 * G3_PITCH;
+      *reinterpret_cast<uint2*>(d) = a;
+      *reinterpret_cast<uint2*>(d + G3_PLANE) = b;
+      *reinterpret_cast<uint2*>(d + 2 * G3_PLANE) = c;
+    }
+  }
+};
+
+__device__ __forceinline__ g3_f32x16 g3_mfma(g3_bf16x8 a, g3_bf16x8 b, g3_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
+// of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.
+__device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4][2], int a_off, int b_off) {
+  const char* pa = stage + a_off;
+  const char* pb = stage + 3 * G3_PLANE + b_off;
+  g3_bf16x8 b[3][2];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const g3_bf16x8*>(pb + p * G3_PLANE + j * 32 * G3_PITCH);
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    g3_bf16x8 a[3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
+    // smallest products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
+  }
+}
+
+__device__ __forceinline__ void g3_barrier() {
+  // LDS writes of this wave done, then the workgroup barrier; global loads stay in flight (no vmcnt wait)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(512)
+k_gemm3(G3Args g) {
+  extern __shared__ __attribute__((aligned(16))) char g3_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // workgroup -> (row tile, column tile, K chunk).  Workgroup b runs on XCD b % 8: the column tiles of one row
+  // tile (and, with split K, the output tiles of one K chunk) are consecutive on ONE XCD and share its L2.
+  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+  int it, jt, split = 0;
+  if (g.splits > 1) {
+    const int tiles = g.mt * g.nt, tile = q % tiles;
+    split = xcd + 8 * (q / tiles);
+    it = tile / g.nt; jt = tile % g.nt;
+  } else {
+    jt = q % g.nt; it = (q / g.nt) * 8 + xcd;
+    if (it >= g.mt) return;
+  }
+  const int64_t m0 = (int64_t)it * 256, n0 = (int64_t)jt * 256;
+  const int64_t nk_all = g.K / 16;
+  int64_t ks0 = 0, nk = nk_all;
+  if (g.splits > 1) {
+    ks0 = (int64_t)split * g.steps_per_split;
+    nk = nk_all - ks0; if (nk > g.steps_per_split) nk = g.steps_per_split;
+    if (nk < 0) nk = 0;
+  }
+
+  G3Loader<AKC> la; G3Loader<BKC> lb;
+  la.init(g.A, g.lda, m0, g.M, ks0 * 16, t);
+  lb.init(g.B, g.ldb, n0, g.N, ks0 * 16, t);
+
+  g3_f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wu & 1, wn = wu >> 1;
+  const int a_off = (wm * 128 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
+  const int b_off = (wn * 64 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
+  const bool stage_first = g.order == 0 ? ((wu >> 2) & 1) : g.order == 1;      // waves w and w + 4 share a SIMD and take opposite orders
+
+  float va[2][4], vb[2][4];
+  if (nk > 0) {
+    la.load(va); lb.load(vb);
+    la.store(g3_lds, va); lb.store(g3_lds + 3 * G3_PLANE, vb);
+    if (nk > 1) { la.load(va); lb.load(vb); }
+  }
+  g3_barrier();
+  for (int64_t k = 0; k < nk; ++k) {
+    const char* cur = g3_lds + (k & 1) * G3_STAGE;
+    char* nxt = g3_lds + ((k + 1) & 1) * G3_STAGE;
+    // ONE copy of the MFMA block (two copies get two accumulator register assignments and the compiler
+    // reconciles them with 128 moves per step); the small staging block sits before or after it
+    if (stage_first) {
+      if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
+      if (k + 2 < nk) { la.load(va); lb.load(vb); }
+    }
+    g3_compute(cur, acc, a_off, b_off);
+    if (!stage_first) {
+      if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
+      if (k + 2 < nk) { la.load(va); lb.load(vb); }
+    }
+    g3_barrier();
+  }
+
+  // epilogue: C/D register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+  float* C = g.C + (g.splits > 1 ? (int64_t)split * g.M * g.N : 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+    const bool col_ok = col < g.N;
+    const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = rb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (g.relu) v = v > 0.0f ? v : 0.0f;
+        if (col_ok && row < g.M) __builtin_nontemporal_store(v, C + row * g.ldc + col);
+      }
+    }
+  }
+}
+
+// out[i] = sum over splits of partial[s][i] (fixed order: deterministic), i over M*N, rows re-pitched to ldc
+__global__ void __launch_bounds__(256)
+k_gemm3_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N, float* __restrict__ out, int64_t ldc) {
+  const int64_t n4 = N >> 2;
+  const int64_t total = M * n4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / n4, c4 = i - row * n4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + ((int64_t)k * M + row) * N + c4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + row * ldc + c4 * 4) = s;
+  }
+}
+
+static int g3_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+  int64_t s = 8 * ((256 + 8 * tiles - 1) / (8 * tiles));      // tiles * splits >= 256 workgroups, splits % 8 == 0
+  const int64_t nk = K / 16;
+  while (s > 8 && nk / s < 64) s -= 8;                        // keep >= 64 K-steps per workgroup
+  return (int)s;
+}
+
+}  // namespace mirl
+
+extern "C" int mirl_gemm3_supported(int32_t layout, int64_t M, int64_t N, int64_t K) {
+  if (layout < 0 || layout > 2) return 0;
+  if (M < 1 || N < 1 || K < 16 || (K % 16)) return 0;
+  if (M >= (1LL << 31) || N >= (1LL << 31)) return 0;
+  if (layout == 2) {
+    if (N % 4) return 0;                                      // the reduction works on float4 columns
+    if (K / 16 < 8) return 0;
+  }
+  return 1;
+}
+
+extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, int64_t K, int64_t* bytes) {
+  using namespace mirl;
+  if (!bytes) return fail(MIRL_ERR_ARG, "gemm3_workspace_bytes: null out");
+  if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
+  *bytes = layout == 2 ? (int64_t)g3_splits(M, N, K) * M * N * (int64_t)sizeof(float) : 0;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  using namespace mirl;
+  if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
+  if (!A || !B || !C) return fail(MIRL_ERR_ARG, "gemm3: null operand");
+  const bool akc = layout != 2, bkc = layout == 0;
+  if (akc && ((lda % 4) || ((uintptr_t)A % 16) || lda < K)) return fail(MIRL_ERR_ARG, "gemm3: A must be 16-byte aligned with lda % 4 == 0");
+  if (bkc && ((ldb % 4) || ((uintptr_t)B % 16) || ldb < K)) return fail(MIRL_ERR_ARG, "gemm3: B must be 16-byte aligned with ldb % 4 == 0");
+  if (!akc && lda < M) return fail(MIRL_ERR_ARG, "gemm3: lda < M");
+  if (!bkc && ldb < N) return fail(MIRL_ERR_ARG, "gemm3: ldb < N");
+  if (ldc < N) return fail(MIRL_ERR_ARG, "gemm3: ldc < N");
+  if (layout == 2 && (bias || relu)) return fail(MIRL_ERR_ARG, "gemm3: no epilogue with split K");
+  hipStream_t st = (hipStream_t)stream;
+  G3Args g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.relu = relu ? 1 : 0;
+  g.mt = (int)((M + 255) / 256); g.nt = (int)((N + 255) / 256);
+  g.splits = 1; g.steps_per_split = (int)(K / 16);
+  static const int order_env = getenv("MIRL_GEMM3_ORDER") ? atoi(getenv("MIRL_GEMM3_ORDER")) : 0;
+  g.order = order_env;
+  unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);
+  if (layout == 2) {
+    g.splits = g3_splits(M, N, K);
+    const int64_t need = (int64_t)g.splits * M * N * (int64_t)sizeof(float);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 16) || (ldc % 4) || ((uintptr_t)C % 16))
+      return fail(MIRL_ERR_ARG, "gemm3: split-K workspace too small / misaligned");
+    g.steps_per_split = (int)((K / 16 + g.splits - 1) / g.splits);
+    g.C = (float*)workspace; g.ldc = N;
+    grid = (unsigned)(g.mt * g.nt * g.splits);
+  }
+  static bool attr[3] = {false, false, false};
+  const void* fn = layout == 0 ? (const void*)k_gemm3<true, true> : layout == 1 ? (const void*)k_gemm3<true, false> : (const void*)k_gemm3<false, false>;
+  if (!attr[layout]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[layout] = true; }
+  {
+    const double flop = 2.0 * (double)M * (double)N * (double)K;
+    ProfScope ps(layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", flop, st);   // "bytes" slot carries flop here
+    if (layout == 0) hipLaunchKernelGGL((k_gemm3<true, true>), dim3(grid), dim3(512), G3_LDS, st, g);
+    else if (layout == 1) hipLaunchKernelGGL((k_gemm3<true, false>), dim3(grid), dim3(512), G3_LDS, st, g);
+    else hipLaunchKernelGGL((k_gemm3<false, false>), dim3(grid), dim3(512), G3_LDS, st, g);
+    MIRL_LAUNCH_CHECK();
+  }
+  if (layout == 2) {
+    ProfScope ps("k_gemm3_reduce", (double)(g.splits + 1) * (double)M * (double)N * 4.0, st);
+    const int64_t total = M * (N / 4);
+    unsigned rg = (unsigned)((total + 255) / 256); if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(k_gemm3_reduce, dim3(rg), dim3(256), 0, st, (const float*)workspace, g.splits, M, N, C, ldc);
+    MIRL_LAUNCH_CHECK();
+  }
+  return MIRL_OK;
+}

@@ -27,6 +27,9 @@ import torch
 import torch.nn.functional as F
 
 
+from . import gemm3
+
+
 def _lib():
     from rltime_amd import _lib as L
     return L
@@ -73,7 +76,7 @@ def relu_bwd_bias_rows(dy, y, channels):
 class _LinearReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        out = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        out = gemm3.linear_fwd(x, weight, bias, relu=True)
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -86,8 +89,8 @@ class _LinearReLU(torch.autograd.Function):
         else:
             g = torch.ops.aten.threshold_backward(grad.contiguous(), out, 0.0)
             db = g.sum(0) if ctx.needs_input_grad[2] else None
-        dx = g.mm(weight) if ctx.needs_input_grad[0] else None
-        dw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        dx = gemm3.grad_input(g, weight) if ctx.needs_input_grad[0] else None
+        dw = gemm3.grad_weight(g, x) if ctx.needs_input_grad[1] else None
         return dx, dw, (db if ctx.needs_input_grad[2] else None)
 
 
@@ -307,7 +310,7 @@ class _DuelingTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, wo, bo, wv, bv, wq, bq):
         h1 = w1.shape[0]
-        both = torch._addmm_activation(torch.cat([b1, bv]), x, torch.cat([w1, wv], 0).t(), use_gelu=False)
+        both = gemm3.linear_fwd(x, torch.cat([w1, wv], 0), torch.cat([b1, bv]), relu=True)
         a = torch.addmm(bo, both[:, :h1], wo.t())
         v = torch.addmm(bq, both[:, h1:], wq.t())
         ctx.h1 = h1
@@ -347,10 +350,19 @@ class _DuelingTail(torch.autograd.Function):
         # (10.3 + 11.5 ms merged vs 4 x 3.55 ms, profiles/r02b)
         g1, g2 = g[:, :h1], g[:, h1:]
         dx = None
-        if ctx.needs_input_grad[0]:
-            dx = g1.mm(w1)
-            dx.addmm_(g2, wv)
-        dw1, dwv = g1.t().mm(x), g2.t().mm(x)
+        wj = torch.cat([w1, wv], 0) if gemm3.enabled() else None
+        if wj is not None and gemm3.supported(gemm3.NN, g, wj) and gemm3.supported(gemm3.TN, g, x):
+            # the split-bf16 kernel takes the joint (rows, H1 + Hv) gradient as ONE K = H1 + Hv data gradient
+            # and ONE weight gradient whose row blocks are dW1 | dWv
+            if ctx.needs_input_grad[0]:
+                dx = gemm3.gemm(gemm3.NN, g, wj)
+            dwj = gemm3.gemm(gemm3.TN, g, x)
+            dw1, dwv = dwj[:h1], dwj[h1:]
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = g1.mm(w1)
+                dx.addmm_(g2, wv)
+            dw1, dwv = g1.t().mm(x), g2.t().mm(x)
         dwo = ga.t().mm(both[:, :h1])
         dwq = gv.t().mm(both[:, h1:])
         return dx, dw1, db[:h1], dwo, ga.sum(0), dwv, db[h1:], dwq, gv.sum(0)

@@ -20,6 +20,7 @@ import ctypes as C
 import torch
 
 from rltime_amd._lib import lib, check
+from . import gemm3
 
 
 import os
@@ -153,7 +154,7 @@ class _LSTMSequence(torch.autograd.Function):
         # always off and ctx.needs_input_grad mirrors requires_grad even in a no_grad pass
         need_grad = track and any(ctx.needs_input_grad[:4])
         dev = x.device
-        gates = torch.addmm(bias.float(), x, w_ih.float().t()).view(T, B, 4 * H)
+        gates = gemm3.linear_fwd(x, w_ih.float(), bias.float().contiguous()).view(T, B, 4 * H)
         out, hm, cm, c_all, h_last, c_last = _forward_sweep(
             gates, w, h0.float().contiguous(), c0.float().contiguous(), keep, need_grad)
         if need_grad:
@@ -169,9 +170,9 @@ class _LSTMSequence(torch.autograd.Function):
         d_out = d_out.float().contiguous()
         _backward_sweep(gates, c_all, cm, d_out, keep, w)
         dg = gates.reshape(T * B, G)                      # now d loss / d pre-activation
-        d_x = dg.mm(w_ih.float()) if ctx.needs_input_grad[0] else None
-        d_wih = dg.t().mm(x) if ctx.needs_input_grad[1] else None
-        d_whh = dg.t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[2] else None
+        d_x = gemm3.grad_input(dg, w_ih.float()) if ctx.needs_input_grad[0] else None
+        d_wih = gemm3.grad_weight(dg, x) if ctx.needs_input_grad[1] else None
+        d_whh = gemm3.grad_weight(dg, hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[2] else None
         d_b = dg.sum(0) if ctx.needs_input_grad[3] else None
         return d_x, d_wih, d_whh, d_b, None, None, None, None
 
@@ -207,7 +208,7 @@ class _LSTMSequenceFromProjection(torch.autograd.Function):
         H = G // 4
         d_out = d_out.float().contiguous()
         _backward_sweep(gates, c_all, cm, d_out, keep, w)
-        d_whh = gates.reshape(T * B, G).t().mm(hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[1] else None
+        d_whh = gemm3.grad_weight(gates.reshape(T * B, G), hm[:T].reshape(T * B, H)) if ctx.needs_input_grad[1] else None
         return gates, d_whh, None, None, None, None
 
 

@@ -163,7 +163,8 @@ class LSTM(BaseModule):
         its double-Q selection pass, MultiStepTrainer._share_online_features) computes
         it once and hands each pass its rows through forward(projected=...)."""
         cell = self.lstm_cell
-        return F.linear(x.reshape(-1, self.inp_size), cell.weight_ih, cell.bias_ih + cell.bias_hh)
+        from .gemm3 import linear as linear3
+        return linear3(x.reshape(-1, self.inp_size), cell.weight_ih, cell.bias_ih + cell.bias_hh)
 
     def forward(self, x, hx, cx, initials, timesteps, projected=None):
         if projected is not None and projected.is_cuda and self.fused and projected.shape[0] == hx.shape[0]:

@@ -1,0 +1,167 @@
+"""GPU: the wide layers' f32 GEMMs on the bf16 matrix pipe (csrc/gemm3.hip, mirl_gemm3) against the
+float64 product and the library's f32 GEMM on the same inputs — the three products of the reference's
+nn.Linear layers (rltime/policies/torch/dqn.py:50-112, iqn.py:82-102, models/torch/modules/lstm.py:60-81):
+forward x W^T + b, data gradient g W, weight gradient g^T x.
+
+Small-integer operands are exactly representable in one bf16 part and every partial sum is exact in
+f32: indexing / tile mapping / split-K order are checked BIT-exactly.  Real operands: the result must be
+an f32 GEMM — no further from the float64 product than twice the library f32 GEMM's own error, and
+within 1e-5 of the largest output (the north-star tolerance is 1e-4)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = {"nt": 0, "nn": 1, "tn": 2}
+
+
+def _operands(lay, M, N, K, gen, integer=False, pad_a=0, pad_b=0):
+    def make(r, c, pad):
+        full = (torch.randint(-8, 9, (r, c + pad), device="cuda", generator=gen).float() if integer
+                else torch.randn(r, c + pad, device="cuda", generator=gen))
+        return full[:, :c] if pad else full
+    if lay == "nt":
+        return make(M, K, pad_a), make(N, K, pad_b)
+    if lay == "nn":
+        return make(M, K, pad_a), make(K, N, pad_b)
+    return make(K, M, pad_a), make(K, N, pad_b)
+
+
+def _product(lay, a, b):
+    if lay == "nt":
+        return a @ b.t()
+    if lay == "nn":
+        return a @ b
+    return a.t() @ b
+
+
+SHAPES = [("nt", 256, 256, 16), ("nt", 1000, 300, 64), ("nt", 513, 1024, 512), ("nt", 4096, 2048, 3136),
+          ("nn", 256, 256, 16), ("nn", 777, 260, 48), ("nn", 2048, 3136, 2048), ("nn", 5000, 512, 1024),
+          ("tn", 256, 256, 128), ("tn", 300, 260, 4112), ("tn", 1024, 512, 40960), ("tn", 2048, 3136, 2064),
+          ("nt", 1, 1, 16), ("tn", 4, 4, 128)]
+
+
+@pytest.mark.parametrize("lay,M,N,K", SHAPES)
+def test_integer_operands_are_bit_exact(lay, M, N, K):
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    a, b = _operands(lay, M, N, K, gen, integer=True)
+    assert gemm3.supported(LAYOUTS[lay], a, b, min_work=0)
+    want = _product(lay, a.double(), b.double())
+    assert float(want.abs().max()) < 2 ** 24
+    got = gemm3.gemm(LAYOUTS[lay], a, b)
+    assert got.shape == (M, N)
+    assert torch.equal(got.double(), want)
+
+
+@pytest.mark.parametrize("lay,M,N,K", SHAPES[:12])
+def test_real_operands_are_an_f32_gemm(lay, M, N, K):
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a, b = _operands(lay, M, N, K, gen)
+    a[::7] *= 37.0                     # rows of very different magnitude inside one tile
+    b[::5] *= 0.013
+    want = _product(lay, a.double(), b.double())
+    scale = float(want.abs().max())
+    got = gemm3.gemm(LAYOUTS[lay], a, b)
+    lib = _product(lay, a, b)
+    err3 = float((got.double() - want).abs().max()) / scale
+    errl = float((lib.double() - want).abs().max()) / scale
+    assert err3 <= 2.0 * errl + 1e-7, (err3, errl)
+    assert err3 <= 1e-5
+
+
+def test_strided_operands_bias_and_relu():
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    # column-slice views: row pitch larger than the row length (the dueling head's two halves)
+    a, b = _operands("nt", 1500, 520, 256, gen, pad_a=256, pad_b=64)
+    assert a.stride(0) == 512 and b.stride(0) == 320
+    bias = torch.randn(520, device="cuda", generator=gen)
+    want = torch.relu(a.double() @ b.double().t() + bias.double())
+    got = gemm3.gemm(0, a, b, bias=bias, relu=True)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(got.min()) >= 0.0 and float((got == 0).float().mean()) > 0.3
+    # into a column block of a wider output (ldc > N)
+    wide = torch.full((1500, 1040), float("nan"), device="cuda")
+    gemm3.gemm(0, a, b, bias=bias, relu=True, out=wide[:, 520:])
+    assert torch.equal(wide[:, 520:], got) and bool(torch.isnan(wide[:, :520]).all())
+    # k-strided operands with a pitch: weight gradient of a column block
+    g, x = _operands("tn", 384, 512, 8192, gen, pad_a=128, pad_b=0)
+    want = g.double().t() @ x.double()
+    got = gemm3.gemm(2, g, x)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_split_k_reduction_is_deterministic():
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    g, x = _operands("tn", 1024, 512, 65536, gen)
+    first = gemm3.gemm(2, g, x).clone()
+    for _ in range(3):
+        assert torch.equal(gemm3.gemm(2, g, x), first)
+
+
+def test_rejects_what_it_cannot_take():
+    from rltime_amd.models.torch import gemm3
+    from rltime_amd import _lib
+    a = torch.randn(64, 24, device="cuda")                     # K % 16 != 0
+    assert not gemm3.supported(0, a, torch.randn(32, 24, device="cuda"), min_work=0)
+    assert not gemm3.supported(0, torch.randn(64, 32, device="cuda").double(), torch.randn(32, 32, device="cuda").double(), min_work=0)
+    assert not gemm3.supported(0, torch.randn(64, 32, device="cuda")[:, ::2], torch.randn(32, 16, device="cuda"), min_work=0)
+    assert _lib.lib.mirl_gemm3_supported(3, 64, 64, 64) == 0
+    with pytest.raises(_lib.MirlError):
+        gemm3.gemm(0, a, torch.randn(32, 24, device="cuda"))
+
+
+def test_linear_autograd_matches_the_library(monkeypatch):
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    M, K, N = 8192, 3136, 512                                   # M*N*K above the library threshold
+    x = torch.randn(M, K, device="cuda", generator=gen)
+    w = (torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5)
+    b = torch.randn(N, device="cuda", generator=gen)
+    go = torch.randn(M, N, device="cuda", generator=gen)
+    res = {}
+    for mode in ("gemm3", "library"):
+        monkeypatch.setenv("MIRL_GEMM3", "1" if mode == "gemm3" else "0")
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = gemm3.linear(xx, ww, bb)
+        y.backward(go)
+        res[mode] = (y.detach(), xx.grad, ww.grad, bb.grad)
+    want = F.linear(x.double(), w.double(), b.double())
+    assert float((res["gemm3"][0].double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    for got, lib in zip(res["gemm3"], res["library"]):
+        assert float((got - lib).abs().max()) <= 2e-5 * float(lib.abs().max())
+
+
+def test_dueling_tail_and_linear_relu_match_the_library_path(monkeypatch):
+    from rltime_amd.models.torch import fused
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    M, Fd, H, A = 16384, 512, 512, 6
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=gen)
+    x = mk(M, Fd)
+    params = [mk(H, Fd) / Fd ** 0.5, mk(H), mk(A, H) / H ** 0.5, mk(A), mk(H, Fd) / Fd ** 0.5, mk(H), mk(1, H) / H ** 0.5, mk(1)]
+    ga, gv = mk(M, A), mk(M, 1)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MIRL_GEMM3", mode)
+        xx = x.clone().requires_grad_(True)
+        pp = [p.clone().requires_grad_(True) for p in params]
+        a, v = fused._DuelingTail.apply(xx, *pp)
+        torch.autograd.backward([a, v], [ga, gv])
+        y = fused.linear_relu(xx.detach().requires_grad_(True), pp[0].detach().requires_grad_(True), pp[1].detach().requires_grad_(True))
+        out[mode] = [a.detach(), v.detach(), xx.grad] + [p.grad for p in pp] + [y.detach()]
+    names = ["a", "v", "dx", "dw1", "db1", "dwo", "dbo", "dwv", "dbv", "dwq", "dbq", "linear_relu"]
+    for name, got, lib in zip(names, out["1"], out["0"]):
+        assert got.shape == lib.shape
+        tol = 2e-5 * max(float(lib.abs().max()), 1e-6)
+        off = (got - lib).abs() > tol
+        if name in ("a", "v", "linear_relu"):
+            assert not bool(off.any()), name
+        else:
+            # a hidden unit whose pre-activation is within an ulp of zero can land on the other side of the ReLU
+            # in the two paths: its row of the gradient then differs legitimately — a handful of rows at most
+            assert float(off.float().mean()) <= 1e-3, (name, float(off.float().mean()))
+            assert float((got - lib).norm()) <= 1e-3 * float(lib.norm()), name

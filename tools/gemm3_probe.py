@@ -1,0 +1,74 @@
+"""Correctness + time of csrc/gemm3.hip against the float64 product and the library f32 GEMM.
+usage: python tools/gemm3_probe.py [layout:MxNxK ...]   (layout in nt, nn, tn)"""
+import json
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rltime_amd.models.torch import gemm3
+
+DEFAULT = ["nt:655360x1024x512", "nn:655360x512x1024", "tn:1024x512x655360", "nt:40960x2048x3136",
+           "nn:20480x3136x2048", "tn:2048x3136x20480", "nt:1000x300x64", "nn:777x260x48", "tn:300x260x4112"]
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    specs = sys.argv[1:] or DEFAULT
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for spec in specs:
+        lay, dims = spec.split(":")
+        M, N, K = (int(v) for v in dims.split("x"))
+        layout = {"nt": gemm3.NT, "nn": gemm3.NN, "tn": gemm3.TN}[lay]
+        if layout == gemm3.NT:
+            a, b = torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g)
+            lib = lambda: torch.mm(a, b.t())
+        elif layout == gemm3.NN:
+            a, b = torch.randn(M, K, device="cuda", generator=g), torch.randn(K, N, device="cuda", generator=g)
+            lib = lambda: torch.mm(a, b)
+        else:
+            a, b = torch.randn(K, M, device="cuda", generator=g), torch.randn(K, N, device="cuda", generator=g)
+            lib = lambda: torch.mm(a.t(), b)
+        # a few scaled rows / columns so magnitudes differ across the tile
+        a[:: 7] *= 37.0
+        b[:: 5] *= 0.013
+        ok = gemm3.supported(layout, a, b, min_work=0)
+        rec = {"layout": lay, "M": M, "N": N, "K": K, "supported": ok}
+        if ok:
+            out = gemm3.gemm(layout, a, b)
+            ref32 = lib()
+            # float64 check on a slice of rows (all columns): rows across the whole range incl. the tail
+            rows = torch.unique(torch.cat([torch.arange(0, min(M, 64)), torch.randint(0, M, (192,)), torch.arange(max(M - 64, 0), M)])).cuda()
+            if layout == gemm3.TN:
+                ref64 = a[:, rows].double().t() @ b.double()
+            elif layout == gemm3.NN:
+                ref64 = a[rows].double() @ b.double()
+            else:
+                ref64 = a[rows].double() @ b.double().t()
+            scale = float(ref64.abs().max())
+            rec["max_err_gemm3"] = float((out[rows].double() - ref64).abs().max()) / scale
+            rec["max_err_lib_f32"] = float((ref32[rows].double() - ref64).abs().max()) / scale
+            rec["max_diff_vs_lib"] = float((out - ref32).abs().max()) / scale
+            flop = 2.0 * M * N * K
+            reps = 5 if flop > 1e11 else 20
+            t3 = timed(lambda: gemm3.gemm(layout, a, b, out=out), reps)
+            tl = timed(lib, reps)
+            rec.update(ms_gemm3=round(t3, 4), ms_lib_f32=round(tl, 4), tflops_gemm3=round(flop / t3 / 1e9, 1),
+                       tflops_lib=round(flop / tl / 1e9, 1), frac_of_bf16x6_peak=round(flop / t3 / 1e9 / 416.7, 3))
+        print(json.dumps(rec), flush=True)
+        del a, b
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

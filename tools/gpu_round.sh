@@ -125,6 +125,31 @@ print("step span us", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3)
 PY
       find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     fast)    timeout 900 python -m pytest tests/test_fast_acting_gpu.py tests/test_train_loop_gpu.py tests/test_ingest_paths_gpu.py tests/test_replay_gpu.py -x -q --timeout 300 > "$OUT/pytest_fast.log" 2>&1; echo "pytest fast rc=$?"; tail -25 "$OUT/pytest_fast.log";;
+    gemm3)   timeout 600 python tools/gemm3_probe.py ${GEMM3_SPECS:-} > "$OUT/gemm3_probe.jsonl" 2> "$OUT/gemm3_probe.err"; echo "gemm3 probe rc=$?"; cat "$OUT/gemm3_probe.jsonl"; tail -5 "$OUT/gemm3_probe.err";;
+    g3pmc)   R="$(pwd)"; export TMPDIR=/tmp; i=0
+             for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC"; do
+               i=$((i+1)); (cd /tmp && timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$R/$OUT/g3pmc$i" -o c -- python "$R/tools/gemm3_probe.py" ${GEMM3_SPECS:-nt:655360x1024x512} > "$R/$OUT/g3pmc$i.jsonl" 2> "$R/$OUT/g3pmc$i.err"); echo "g3pmc pass $i rc=$?"
+             done
+             python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections, json
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(out, "g3pmc*", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n_disp = collections.Counter(); seen = set(); dur = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "k_gemm3<" not in n and "Cijk" not in n: continue
+        n = n.split("(")[0][:60]
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n_disp[n] += 1; dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for n, c in acc.items():
+        for k, v in c.items(): res[n][k] = v / n_disp[n]
+        res[n]["avg_ms_under_counters"] = round(dur[n] / n_disp[n], 4); res[n]["dispatches"] = n_disp[n]
+print(json.dumps(res, indent=1)); json.dump(res, open(os.path.join(out, "gemm3_pmc.json"), "w"), indent=1)
+PY
+             find "$OUT" -path "*g3pmc*" -name "*.csv" -size +1M -delete; find "$OUT" -path "*g3pmc*" -name "*.db" -delete; tail -3 "$OUT"/g3pmc*.err | tail -20;;
+    gemmshapes) BENCH_GEMM_SHAPES="$OUT/gemm_shapes.jsonl" timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 1 > "$OUT/bench_gemmshapes.json" 2> "$OUT/bench_gemmshapes.err"; echo "gemmshapes rc=$?"; tail -3 "$OUT/bench_gemmshapes.err"; cat "$OUT/gemm_shapes.jsonl";;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
