@@ -136,30 +136,48 @@ __device__ __forceinline__ g3_f32x16 g3_mfma(g3_bf16x8 a, g3_bf16x8 b, g3_f32x16
 
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
 // of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.
+template <int FRAGS_UP_FRONT>
 __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4][2], int a_off, int b_off) {
   const char* pa = stage + a_off;
   const char* pb = stage + 3 * G3_PLANE + b_off;
+  // smallest products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   g3_bf16x8 b[3][2];
 #pragma unroll
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const g3_bf16x8*>(pb + p * G3_PLANE + j * 32 * G3_PITCH);
-#pragma unroll
-  for (int ih = 0; ih < 2; ++ih) {
-    g3_bf16x8 a[3][2];
+  if (FRAGS_UP_FRONT) {
+    // all 18 fragment reads in flight before the first MFMA: one exposed LDS latency per K-step instead of one
+    // per A half (72 fragment registers)
+    g3_bf16x8 a[3][4];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
-    // smallest products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+      for (int i = 0; i < 4; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + i * 32 * G3_PITCH);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[i][j]);
+  } else {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      g3_bf16x8 a[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
+    }
   }
 }
 
@@ -168,7 +186,7 @@ __device__ __forceinline__ void g3_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int UF>
 __global__ void __launch_bounds__(512)
 k_gemm3(G3Args g) {
   extern __shared__ __attribute__((aligned(16))) char g3_lds[];
@@ -228,7 +246,7 @@ k_gemm3(G3Args g) {
       if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
       if (k + 2 < nk) { la.load(va); lb.load(vb); }
     }
-    g3_compute(cur, acc, a_off, b_off);
+    g3_compute<UF>(cur, acc, a_off, b_off);
     if (!stage_first) {
       if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
       if (k + 2 < nk) { la.load(va); lb.load(vb); }
@@ -333,16 +351,18 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
     g.C = (float*)workspace; g.ldc = N;
     grid = (unsigned)(g.mt * g.nt * g.splits);
   }
-  static bool attr[3] = {false, false, false};
-  const void* fn = layout == 0 ? (const void*)k_gemm3<true, true> : layout == 1 ? (const void*)k_gemm3<true, false> : (const void*)k_gemm3<false, false>;
-  if (!attr[layout]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[layout] = true; }
+  static const int uf_env = getenv("MIRL_GEMM3_UF") ? atoi(getenv("MIRL_GEMM3_UF")) : 0;
+  static bool attr[3][2] = {{false, false}, {false, false}, {false, false}};
+  const int uf = uf_env ? 1 : 0;
+  const void* fns[3][2] = {{(const void*)k_gemm3<true, true, 0>, (const void*)k_gemm3<true, true, 1>},
+                           {(const void*)k_gemm3<true, false, 0>, (const void*)k_gemm3<true, false, 1>},
+                           {(const void*)k_gemm3<false, false, 0>, (const void*)k_gemm3<false, false, 1>}};
+  if (!attr[layout][uf]) { MIRL_HIP(hipFuncSetAttribute(fns[layout][uf], hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[layout][uf] = true; }
   {
     const double flop = 2.0 * (double)M * (double)N * (double)K;
     ProfScope ps(layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", flop, st);   // "bytes" slot carries flop here
-    if (layout == 0) hipLaunchKernelGGL((k_gemm3<true, true>), dim3(grid), dim3(512), G3_LDS, st, g);
-    else if (layout == 1) hipLaunchKernelGGL((k_gemm3<true, false>), dim3(grid), dim3(512), G3_LDS, st, g);
-    else hipLaunchKernelGGL((k_gemm3<false, false>), dim3(grid), dim3(512), G3_LDS, st, g);
-    MIRL_LAUNCH_CHECK();
+    void* kargs[] = {(void*)&g};
+    MIRL_HIP(hipLaunchKernel(fns[layout][uf], dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
   if (layout == 2) {
     ProfScope ps("k_gemm3_reduce", (double)(g.splits + 1) * (double)M * (double)N * 4.0, st);

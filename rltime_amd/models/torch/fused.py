@@ -281,7 +281,7 @@ class _QuantileProduct(torch.autograd.Function):
         partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
         L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
                                        blocks, _stream()), "mirl_iqn_mul_bwd")
-        dw = d_pre.t().mm(phi) if ctx.needs_input_grad[2] else None
+        dw = gemm3.grad_weight(d_pre, phi) if ctx.needs_input_grad[2] else None
         return (dx if ctx.needs_input_grad[0] else None), None, dw, (db if ctx.needs_input_grad[3] else None), None, None
 
 

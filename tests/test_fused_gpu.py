@@ -20,7 +20,7 @@ def _close(a, b, what, rtol=1e-4):
 
 
 @pytest.mark.parametrize("n,cin,hw,cout,k,s,need_x", [
-    (64, 4, 84, 32, 8, 4, False), (33, 32, 20, 64, 4, 2, True), (17, 64, 9, 64, 3, 1, True), (5, 2, 20, 8, 4, 2, True)])
+    (64, 4, 84, 32, 8, 4, False), (33, 32, 20, 64, 4, 2, True), (17, 64, 9, 64, 3, 1, True), (5, 32, 20, 16, 4, 2, True)])
 def test_conv_bias_relu_matches_relu_conv(n, cin, hw, cout, k, s, need_x):
     from rltime_amd.models.torch.fused import conv_bias_relu
     torch.manual_seed(n)

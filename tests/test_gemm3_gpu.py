@@ -156,12 +156,15 @@ def test_dueling_tail_and_linear_relu_match_the_library_path(monkeypatch):
     names = ["a", "v", "dx", "dw1", "db1", "dwo", "dbo", "dwv", "dbv", "dwq", "dbq", "linear_relu"]
     for name, got, lib in zip(names, out["1"], out["0"]):
         assert got.shape == lib.shape
-        tol = 2e-5 * max(float(lib.abs().max()), 1e-6)
+        fwd = name in ("a", "v", "linear_relu")
+        # forward outputs: K = 512 products; gradients sum over 16 384 rows in different orders in the two paths
+        tol = (2e-5 if fwd else 1e-4) * max(float(lib.abs().max()), 1e-6)
         off = (got - lib).abs() > tol
-        if name in ("a", "v", "linear_relu"):
+        if fwd:
             assert not bool(off.any()), name
         else:
             # a hidden unit whose pre-activation is within an ulp of zero can land on the other side of the ReLU
-            # in the two paths: its row of the gradient then differs legitimately — a handful of rows at most
-            assert float(off.float().mean()) <= 1e-3, (name, float(off.float().mean()))
-            assert float((got - lib).norm()) <= 1e-3 * float(lib.norm()), name
+            # in the two paths (expected: a few of the 16.8 M): the sample's row of dx and the unit's row of
+            # dW1 / dWv / element of db then differ legitimately — a handful of rows at most
+            bad = int(off.any(dim=-1).sum()) if off.dim() == 2 else int(off.sum())
+            assert bad <= 8, (name, bad)
