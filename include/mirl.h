@@ -530,6 +530,15 @@ int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g, const floa
 int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga,
                           const float* gv, const float* wo, const float* wq, const float* both,
                           float* g, float* db, float* partial, int32_t blocks, void* stream);
+/* the same pass with the two output layers' weight gradients riding along (`both` is in registers anyway):
+ *   dwj[k][c] = sum_r ga[r][k] * both[r][c]        (c <  H1, k < A):  d loss / d out_layer.weight[k][c]
+ *             = sum_r gv[r][k] * both[r][c]        (c >= H1, k < Q):  d loss / d value_layer.weight[k][c - H1]
+ * dwj is KW x (H1+Hv) floats with KW = max(A, Q) <= 8 (rows k >= A resp. k >= Q of a branch are zero);
+ * partial_w is scratch of blocks * KW * (H1+Hv) floats; fixed-order (deterministic) block sums.       */
+int mirl_dueling_tail_bwd_w(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga,
+                            const float* gv, const float* wo, const float* wq, const float* both, float* g,
+                            float* db, float* partial, int32_t blocks, float* dwj, float* partial_w,
+                            void* stream);
 
 /* ---- device-resident actor bookkeeping (csrc/acting.hip) -----------------------
  * Episode statistics on the RAW rewards and the action histogram

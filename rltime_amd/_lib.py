@@ -175,6 +175,7 @@ _SIGNATURES = {
     "mirl_iqn_mul_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_iqn_mul_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_dueling_tail_bwd": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
+    "mirl_dueling_tail_bwd_w": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_stack_shift": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

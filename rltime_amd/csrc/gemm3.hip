@@ -193,36 +193,14 @@ k_gemm3(G3Args g) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // workgroup -> (row tile, column tile, K chunk).  Workgroup b runs on XCD b % 8: the column tiles of one row
   // tile (and, with split K, the output tiles of one K chunk) are consecutive on ONE XCD and share its L2.
-  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-  int it, jt, split = 0;
-  if (g.splits > 1) {
-    const int tiles = g.mt * g.nt, tile = q % tiles;
-    split = xcd + 8 * (q / tiles);
-    it = tile / g.nt; jt = tile % g.nt;
-  } else {
-    jt = q % g.nt; it = (q / g.nt) * 8 + xcd;
-    if (it >= g.mt) return;
-  }
-  const int64_t m0 = (int64_t)it * 256, n0 = (int64_t)jt * 256;
+  // Without split K a workgroup walks the XCD's tile list e = l, l + L, ... (l = b / 8, L = workgroups per XCD;
+  // element e = column tile e % nt of row tile 8 (e / nt) + xcd): L = list length is one tile per workgroup,
+  // L = CUs per XCD is a persistent workgroup whose next tile's first loads fly during this tile's stores.
+  const int b = blockIdx.x, xcd = b & 7, l = b >> 3, L = gridDim.x >> 3;
   const int64_t nk_all = g.K / 16;
+  const int E = g.splits > 1 ? l + 1 : ((g.mt + 7) / 8) * g.nt;        // split K: exactly one pass
+  int split = 0;
   int64_t ks0 = 0, nk = nk_all;
-  if (g.splits > 1) {
-    ks0 = (int64_t)split * g.steps_per_split;
-    nk = nk_all - ks0; if (nk > g.steps_per_split) nk = g.steps_per_split;
-    if (nk < 0) nk = 0;
-  }
-
-  G3Loader<AKC> la; G3Loader<BKC> lb;
-  la.init(g.A, g.lda, m0, g.M, ks0 * 16, t);
-  lb.init(g.B, g.ldb, n0, g.N, ks0 * 16, t);
-
-  g3_f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int wu = __builtin_amdgcn_readfirstlane(wave);
   const int wm = wu & 1, wn = wu >> 1;
@@ -230,48 +208,90 @@ k_gemm3(G3Args g) {
   const int b_off = (wn * 64 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
   const bool stage_first = g.order == 0 ? ((wu >> 2) & 1) : g.order == 1;      // waves w and w + 4 share a SIMD and take opposite orders
 
-  float va[2][4], vb[2][4];
-  if (nk > 0) {
-    la.load(va); lb.load(vb);
-    la.store(g3_lds, va); lb.store(g3_lds + 3 * G3_PLANE, vb);
-    if (nk > 1) { la.load(va); lb.load(vb); }
-  }
-  g3_barrier();
-  for (int64_t k = 0; k < nk; ++k) {
-    const char* cur = g3_lds + (k & 1) * G3_STAGE;
-    char* nxt = g3_lds + ((k + 1) & 1) * G3_STAGE;
-    // ONE copy of the MFMA block (two copies get two accumulator register assignments and the compiler
-    // reconciles them with 128 moves per step); the small staging block sits before or after it
-    if (stage_first) {
-      if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
-      if (k + 2 < nk) { la.load(va); lb.load(vb); }
-    }
-    g3_compute<UF>(cur, acc, a_off, b_off);
-    if (!stage_first) {
-      if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
-      if (k + 2 < nk) { la.load(va); lb.load(vb); }
-    }
-    g3_barrier();
+  // first tile of this workgroup
+  int e = l, it = 0, jt = 0;
+  if (g.splits > 1) {
+    const int tiles = g.mt * g.nt, tile = l % tiles;
+    split = xcd + 8 * (l / tiles);
+    it = tile / g.nt; jt = tile % g.nt;
+    ks0 = (int64_t)split * g.steps_per_split;
+    nk = nk_all - ks0; if (nk > g.steps_per_split) nk = g.steps_per_split;
+    if (nk < 0) nk = 0;
+  } else {
+    for (; e < E; e += L) { jt = e % g.nt; it = (e / g.nt) * 8 + xcd; if (it < g.mt) break; }
+    if (e >= E) return;
   }
 
-  // epilogue: C/D register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-  float* C = g.C + (g.splits > 1 ? (int64_t)split * g.M * g.N : 0);
+  G3Loader<AKC> la; G3Loader<BKC> lb;
+  float va[2][4], vb[2][4];
+  la.init(g.A, g.lda, (int64_t)it * 256, g.M, ks0 * 16, t);
+  lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
+  if (nk > 0) { la.load(va); lb.load(vb); }
+
+  g3_f32x16 acc[4][2];
+  while (true) {
+    const int64_t m0 = (int64_t)it * 256, n0 = (int64_t)jt * 256;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
-    const bool col_ok = col < g.N;
-    const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = rb + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
-        if (g.relu) v = v > 0.0f ? v : 0.0f;
-        if (col_ok && row < g.M) __builtin_nontemporal_store(v, C + row * g.ldc + col);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (nk > 0) {
+      la.store(g3_lds, va); lb.store(g3_lds + 3 * G3_PLANE, vb);
+      if (nk > 1) { la.load(va); lb.load(vb); }
+    }
+    g3_barrier();
+    for (int64_t k = 0; k < nk; ++k) {
+      const char* cur = g3_lds + (k & 1) * G3_STAGE;
+      char* nxt = g3_lds + ((k + 1) & 1) * G3_STAGE;
+      // ONE copy of the MFMA block (two copies get two accumulator register assignments and the compiler
+      // reconciles them with 128 moves per step); the small staging block sits before or after it
+      if (stage_first) {
+        if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
+        if (k + 2 < nk) { la.load(va); lb.load(vb); }
+      }
+      g3_compute<UF>(cur, acc, a_off, b_off);
+      if (!stage_first) {
+        if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
+        if (k + 2 < nk) { la.load(va); lb.load(vb); }
+      }
+      g3_barrier();
+    }
+
+    // next tile of this workgroup: its first K-step is requested before this tile's stores go out
+    bool more = false;
+    if (g.splits <= 1) {
+      for (e += L; e < E; e += L) { jt = e % g.nt; it = (e / g.nt) * 8 + xcd; if (it < g.mt) break; }
+      more = e < E;
+      if (more) {
+        la.init(g.A, g.lda, (int64_t)it * 256, g.M, 0, t);
+        lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, 0, t);
+        la.load(va); lb.load(vb);
       }
     }
+
+    // epilogue: C/D register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+    float* C = g.C + (g.splits > 1 ? (int64_t)split * g.M * g.N : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+      const bool col_ok = col < g.N;
+      const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = rb + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bv;
+          if (g.relu) v = v > 0.0f ? v : 0.0f;
+          if (col_ok && row < g.M) __builtin_nontemporal_store(v, C + row * g.ldc + col);
+        }
+      }
+    }
+    if (!more) break;
   }
 }
 
@@ -341,7 +361,15 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
   g.splits = 1; g.steps_per_split = (int)(K / 16);
   static const int order_env = getenv("MIRL_GEMM3_ORDER") ? atoi(getenv("MIRL_GEMM3_ORDER")) : 0;
   g.order = order_env;
-  unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);
+  static const int persist_env = getenv("MIRL_GEMM3_PERSIST") ? atoi(getenv("MIRL_GEMM3_PERSIST")) : 0;   // measured: no gain (7.36 vs 7.32 ms), opt-in
+  unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);                 // one tile per workgroup
+  if (persist_env) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned resident = (unsigned)(cus / 8 * 8);                        // one workgroup per CU (147 KB of LDS each)
+    if (grid > resident) grid = resident;
+  }
   if (layout == 2) {
     g.splits = g3_splits(M, N, K);
     const int64_t need = (int64_t)g.splits * M * N * (int64_t)sizeof(float);

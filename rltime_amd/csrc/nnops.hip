@@ -325,6 +325,95 @@ k_tail_bwd(const float* __restrict__ ga, const float* __restrict__ gv, const flo
   }
 }
 
+// The same pass with the output layers' weight gradients riding along:
+//   dwo[a][c] = sum_r ga[r][a] * both[r][c] (c < H1),  dwq[q][c - H1] = sum_r gv[r][q] * both[r][c] (c >= H1)
+// `both` is in registers anyway, so the two (A | Q) x rows x H library GEMMs that re-read it (3.2 ms per step at the
+// benchmark shape, 3x their HBM floor) become K more FMAs per element here.  K is padded to 8 with zero weights and
+// zero output-gradient columns so every inner loop is unconditional; per-block partials [block][k][C], k < KW =
+// max(A, Q) <= 8, are summed in a fixed order afterwards.
+#define MIRL_TAIL_WGK 8
+__global__ void __launch_bounds__(256)
+k_tail_bwd_w(const float* __restrict__ ga, const float* __restrict__ gv, const float* __restrict__ wo,
+             const float* __restrict__ wq, const nn_f4* __restrict__ both, nn_f4* __restrict__ g,
+             nn_f4* __restrict__ partial, nn_f4* __restrict__ partial_w, int64_t rows, int H1, int Hv, int A, int Q,
+             int KW, int64_t rpb) {
+  __shared__ nn_f4 s_acc[256];
+  __shared__ __attribute__((aligned(16))) float s_ga[MIRL_TAIL_ROWS * MIRL_TAIL_WGK];
+  __shared__ __attribute__((aligned(16))) float s_gv[MIRL_TAIL_ROWS * MIRL_TAIL_WGK];
+  const int C = H1 + Hv, CQ = C / 4, tid = threadIdx.x, cq = tid % CQ, rl = tid / CQ, RL = 256 / CQ;
+  const int c0 = cq * 4;
+  const bool adv = c0 < H1;
+  const int K = adv ? A : Q;
+  const float* w = adv ? wo + c0 : wq + (c0 - H1);
+  const int ldw = adv ? H1 : Hv;
+  const float* sg = adv ? s_ga : s_gv;
+  nn_f4 wk[MIRL_TAIL_WGK], aw[MIRL_TAIL_WGK];
+#pragma unroll
+  for (int k = 0; k < MIRL_TAIL_WGK; ++k) {
+    wk[k] = k < K ? nn_f4{w[(int64_t)k * ldw], w[(int64_t)k * ldw + 1], w[(int64_t)k * ldw + 2], w[(int64_t)k * ldw + 3]}
+                  : nn_f4{0.f, 0.f, 0.f, 0.f};
+    aw[k] = nn_f4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (tid < MIRL_TAIL_ROWS * MIRL_TAIL_WGK) { s_ga[tid] = 0.f; s_gv[tid] = 0.f; }     // pad columns stay zero
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  int64_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  nn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t base = r0; base < r1; base += MIRL_TAIL_ROWS) {
+    const int nr = r1 - base < MIRL_TAIL_ROWS ? (int)(r1 - base) : MIRL_TAIL_ROWS;
+    __syncthreads();
+    for (int i = tid; i < nr * A; i += 256) s_ga[(i / A) * MIRL_TAIL_WGK + i % A] = ga[base * A + i];
+    for (int i = tid; i < nr * Q; i += 256) s_gv[(i / Q) * MIRL_TAIL_WGK + i % Q] = gv[base * Q + i];
+    __syncthreads();
+    for (int u = rl; u < nr; u += 2 * RL) {               // two rows in flight per lane
+      const bool two = u + RL < nr;
+      const nn_f4 b0 = both[(base + u) * CQ + cq];
+      const nn_f4 b1 = two ? both[(base + u + RL) * CQ + cq] : nn_f4{0.f, 0.f, 0.f, 0.f};
+      const nn_f4* g0 = reinterpret_cast<const nn_f4*>(sg + u * MIRL_TAIL_WGK);
+      const nn_f4* g1 = reinterpret_cast<const nn_f4*>(sg + (two ? u + RL : u) * MIRL_TAIL_WGK);
+      const nn_f4 ga0 = g0[0], gb0 = g0[1], ga1 = g1[0], gb1 = g1[1];
+      const float gr0[8] = {ga0.x, ga0.y, ga0.z, ga0.w, gb0.x, gb0.y, gb0.z, gb0.w};
+      const float gr1[8] = {ga1.x, ga1.y, ga1.z, ga1.w, gb1.x, gb1.y, gb1.z, gb1.w};
+      nn_f4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < MIRL_TAIL_WGK; ++k) {
+        d0 = d0 + wk[k] * gr0[k];
+        d1 = d1 + wk[k] * gr1[k];
+        aw[k] = aw[k] + b0 * gr0[k];
+        aw[k] = aw[k] + b1 * gr1[k];                       // b1 is zero when there is no second row
+      }
+      MIRL_MASK(d0, b0)
+      __builtin_nontemporal_store(d0, g + (base + u) * CQ + cq);
+      acc = acc + d0;
+      if (two) {
+        MIRL_MASK(d1, b1)
+        __builtin_nontemporal_store(d1, g + (base + u + RL) * CQ + cq);
+        acc = acc + d1;
+      }
+    }
+  }
+  __syncthreads();
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (rl == 0) {
+    nn_f4 t = s_acc[cq];
+    for (int k = 1; k < RL; ++k) t = t + s_acc[k * CQ + cq];
+    partial[(int64_t)blockIdx.x * CQ + cq] = t;
+  }
+#pragma unroll
+  for (int k = 0; k < MIRL_TAIL_WGK; ++k) {
+    if (k < KW) {                                          // block-uniform
+      __syncthreads();
+      s_acc[tid] = aw[k];                                  // lanes of the other branch hold zeros for k >= their K
+      __syncthreads();
+      if (rl == 0) {
+        nn_f4 t = s_acc[cq];
+        for (int j2 = 1; j2 < RL; ++j2) t = t + s_acc[j2 * CQ + cq];
+        partial_w[((int64_t)blockIdx.x * KW + k) * CQ + cq] = t;
+      }
+    }
+  }
+}
+
 static inline bool pow2_quads(int C) { int cq = C / 4; return (C % 4) == 0 && cq >= 1 && cq <= 256 && (256 % cq) == 0; }
 static inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
 
@@ -445,20 +534,29 @@ extern "C" int mirl_iqn_mul_bwd(int64_t M, int32_t N, int32_t C, const float* g,
   return MIRL_OK;
 }
 
-extern "C" int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga, const float* gv,
-                                     const float* wo, const float* wq, const float* both, float* g, float* db, float* partial,
-                                     int32_t blocks, void* stream) {
+static int tail_bwd_launch(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga, const float* gv,
+                           const float* wo, const float* wq, const float* both, float* g, float* db, float* partial,
+                           int32_t blocks, float* dwj, float* partial_w, void* stream) {
+  using namespace mirl;
   if (M <= 0 || H1 <= 0 || Hv <= 0 || A <= 0 || Q <= 0 || !ga || !gv || !wo || !wq || !both || !g || !db || !partial || blocks <= 0)
     return fail(MIRL_ERR_ARG, "bad dueling_tail_bwd arguments");
   if (A > MIRL_TAIL_MAXK || Q > MIRL_TAIL_MAXK || (H1 % 4) || !pow2_quads(H1 + Hv) || !aligned16(both) || !aligned16(g) || !aligned16(partial))
     return fail(MIRL_ERR_ARG, "dueling_tail_bwd: outputs per branch <= 16, H1 % 4 == 0, H1 + Hv = 4 * 2^k <= 1024, 16-byte aligned pointers");
+  const bool wgrad = dwj != nullptr;
+  const int KW = A > Q ? A : Q;
+  if (wgrad && (KW > MIRL_TAIL_WGK || !partial_w || !aligned16(partial_w) || !aligned16(dwj)))
+    return fail(MIRL_ERR_ARG, "dueling_tail_bwd_w: outputs per branch <= 8, 16-byte aligned buffers");
   hipStream_t st = (hipStream_t)stream;
   const int C = H1 + Hv;
   const int64_t rpb = (M + blocks - 1) / blocks;
   {
     ProfScope ps("k_tail_bwd", 2.0 * M * C * 4 + (double)M * (A + Q) * 4, st);
-    hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)blocks), dim3(256), 0, st, ga, gv, wo, wq, (const nn_f4*)both, (nn_f4*)g, (nn_f4*)partial,
-                       M, (int)H1, (int)Hv, (int)A, (int)Q, rpb);
+    if (wgrad)
+      hipLaunchKernelGGL(k_tail_bwd_w, dim3((unsigned)blocks), dim3(256), 0, st, ga, gv, wo, wq, (const nn_f4*)both, (nn_f4*)g, (nn_f4*)partial,
+                         (nn_f4*)partial_w, M, (int)H1, (int)Hv, (int)A, (int)Q, KW, rpb);
+    else
+      hipLaunchKernelGGL(k_tail_bwd, dim3((unsigned)blocks), dim3(256), 0, st, ga, gv, wo, wq, (const nn_f4*)both, (nn_f4*)g, (nn_f4*)partial,
+                         M, (int)H1, (int)Hv, (int)A, (int)Q, rpb);
   }
   MIRL_LAUNCH_CHECK();
   {
@@ -466,5 +564,23 @@ extern "C" int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t 
     hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, st, partial, db, (int)blocks, (int)C);
   }
   MIRL_LAUNCH_CHECK();
+  if (wgrad) {
+    ProfScope ps("k_colsum_partials", (double)blocks * KW * C * 4, st);
+    hipLaunchKernelGGL(k_colsum_partials, dim3((unsigned)((KW * C + 63) / 64)), dim3(1024), 0, st, partial_w, dwj, (int)blocks, (int)(KW * C));
+    MIRL_LAUNCH_CHECK();
+  }
   return MIRL_OK;
+}
+
+extern "C" int mirl_dueling_tail_bwd(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga, const float* gv,
+                                     const float* wo, const float* wq, const float* both, float* g, float* db, float* partial,
+                                     int32_t blocks, void* stream) {
+  return tail_bwd_launch(M, H1, Hv, A, Q, ga, gv, wo, wq, both, g, db, partial, blocks, nullptr, nullptr, stream);
+}
+
+extern "C" int mirl_dueling_tail_bwd_w(int64_t M, int32_t H1, int32_t Hv, int32_t A, int32_t Q, const float* ga, const float* gv,
+                                       const float* wo, const float* wq, const float* both, float* g, float* db, float* partial,
+                                       int32_t blocks, float* dwj, float* partial_w, void* stream) {
+  if (!dwj) return mirl::fail(MIRL_ERR_ARG, "dueling_tail_bwd_w: null dwj");
+  return tail_bwd_launch(M, H1, Hv, A, Q, ga, gv, wo, wq, both, g, db, partial, blocks, dwj, partial_w, stream);
 }

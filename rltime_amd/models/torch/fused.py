@@ -29,6 +29,8 @@ import torch.nn.functional as F
 
 from . import gemm3
 
+_TAIL_WGRAD = os.environ.get("MIRL_TAIL_WGRAD", "1") != "0"
+
 
 def _lib():
     from rltime_amd import _lib as L
@@ -323,6 +325,7 @@ class _DuelingTail(torch.autograd.Function):
         h1 = ctx.h1
         ga, gv = ga.contiguous(), gv.contiguous()
         width = both.shape[1]
+        dwo_dwq = None
         if (_pow2_quads(width) and h1 % 4 == 0 and ga.shape[1] <= 16 and gv.shape[1] <= 16
                 and wo.is_contiguous() and wq.is_contiguous()):
             # [ga @ wo | gv @ wq], ReLU mask and bias gradient in ONE pass over `both`
@@ -333,9 +336,19 @@ class _DuelingTail(torch.autograd.Function):
             g = torch.empty_like(both)
             db = torch.empty(width, dtype=torch.float32, device=both.device)
             partial = torch.empty((blocks.value, width), dtype=torch.float32, device=both.device)
-            L.check(L.lib.mirl_dueling_tail_bwd(M, h1, width - h1, ga.shape[1], gv.shape[1], _p(ga), _p(gv), _p(wo), _p(wq),
-                                                _p(both), _p(g), _p(db), _p(partial), blocks.value, _stream()),
-                    "mirl_dueling_tail_bwd")
+            kw = max(ga.shape[1], gv.shape[1])
+            if kw <= 8 and _TAIL_WGRAD:
+                # the output layers' weight gradients from the same pass over `both` (no (A | Q) x rows x H GEMMs)
+                dwj = torch.empty((kw, width), dtype=torch.float32, device=both.device)
+                partial_w = torch.empty((blocks.value, kw, width), dtype=torch.float32, device=both.device)
+                L.check(L.lib.mirl_dueling_tail_bwd_w(M, h1, width - h1, ga.shape[1], gv.shape[1], _p(ga), _p(gv), _p(wo), _p(wq),
+                                                      _p(both), _p(g), _p(db), _p(partial), blocks.value, _p(dwj), _p(partial_w),
+                                                      _stream()), "mirl_dueling_tail_bwd_w")
+                dwo_dwq = (dwj[:ga.shape[1], :h1], dwj[:gv.shape[1], h1:])
+            else:
+                L.check(L.lib.mirl_dueling_tail_bwd(M, h1, width - h1, ga.shape[1], gv.shape[1], _p(ga), _p(gv), _p(wo), _p(wq),
+                                                    _p(both), _p(g), _p(db), _p(partial), blocks.value, _stream()),
+                        "mirl_dueling_tail_bwd")
         else:
             d_both = torch.empty_like(both)
             torch.mm(ga, wo, out=d_both[:, :h1])
@@ -363,8 +376,11 @@ class _DuelingTail(torch.autograd.Function):
                 dx = g1.mm(w1)
                 dx.addmm_(g2, wv)
             dw1, dwv = g1.t().mm(x), g2.t().mm(x)
-        dwo = ga.t().mm(both[:, :h1])
-        dwq = gv.t().mm(both[:, h1:])
+        if dwo_dwq is not None:
+            dwo, dwq = dwo_dwq
+        else:
+            dwo = ga.t().mm(both[:, :h1])
+            dwq = gv.t().mm(both[:, h1:])
         return dx, dw1, db[:h1], dwo, ga.sum(0), dwv, db[h1:], dwq, gv.sum(0)
 
 
