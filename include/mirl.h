@@ -401,12 +401,15 @@ int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* 
  * Replaces, for the first conv layer of the reference's Atari models
  * (rltime/models/torch/modules/cnn.py:44-49 with configs/models/cnn_*.json:
  * Conv2d(4 -> 32, kernel 8, stride 4)), the chain `x.float() * scale` ->
- * conv -> + bias -> ReLU by ONE kernel on the f32 MFMA pipe:
+ * conv -> + bias -> ReLU by ONE kernel (default: on the bf16 matrix pipe with an f32 result —
+ * a uint8 pixel is exact in bf16 and weight * scale is split exactly into three bf16 parts, so
+ * every product is exact and only the f32 summation order differs; flags bit 5 of the _ex form
+ * or MIRL_CONV1_BF16=0 selects the f32-MFMA kernel):
  *   x       uint8 [N][4][H][W] (the replay's gathered rows, as stored)
  *   weight  float, logical [32][4][8][8] with element strides ws_o, ws_c, ws_h, ws_w
  *   y       float [N][OH][OW][32] = relu(conv(x * scale, weight) + bias), the NHWC
  *           memory of the logical (N, 32, OH, OW) tensor; OH = (H-8)/4+1, OW likewise
- *   wpk     scratch, 8192 floats (the weights re-ordered into MFMA operand order,
+ *   wpk     scratch, 12288 floats (the weights re-ordered into MFMA operand order,
  *           rewritten by every call)
  * Products are float(x)*scale times weight as in the reference; only the order of
  * the 256-term sum differs (fp32 tolerance 1e-4, tests/test_conv_in_gpu.py).
@@ -421,7 +424,8 @@ int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const f
 /* the same with explicit launch shape (tuning probe): flags bit 0 = cached output
  * stores (default non-temporal), bit 2 = conversions interleaved with the MFMA chain (default:
  * hoisted in front of it), bits 8-15 = frames per LDS fill (1 | 2, 0 = heuristic),
- * bits 16-23 = workgroups sharing one frame's tiles (0 = heuristic).               */
+ * bits 16-23 = workgroups sharing one frame's tiles (0 = heuristic), bit 3 = wpk already holds
+ * these weights packed by an earlier call with the same kernel choice, bit 5 = f32-MFMA kernel.  */
 int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
                          int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
                          float scale, float* wpk, float* y, int32_t flags, void* stream);

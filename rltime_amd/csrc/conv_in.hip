@@ -180,6 +180,163 @@ k_conv1_u8_fwd(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
 #undef C1_TILE_COMPUTE
 
 // ---------------------------------------------------------------------------
+// The same forward on the bf16 matrix pipe, still an f32 result.  A uint8 pixel is EXACT in bf16 (8 significand
+// bits), so only the weights need the three-way split of csrc/gemm3.hip (w * scale = hi + mid + lo exactly) and
+// the product x * w is the sum of THREE bf16 products, each exact in the MFMA's f32 accumulator (8 x 8 bits).
+// v_mfma_f32_16x16x32_bf16 with filters as rows and positions as columns, as above, takes k = 32 = (plane = lane >> 4,
+// kw = 0..7): the 8 bytes a lane reads per (plane, kh) row ARE its 8 k-elements, so one instruction covers one
+// kh row of the 8 x 8 patch over all four planes — 8 kh x 2 filter halves x 3 weight parts = 48 MFMAs of 16 cycles
+// per tile against 128 of 32 cycles on the f32 pipe.  hi and mid parts of a lane's weights live in registers
+// (2 x 16 x 4 VGPRs), the lo parts in LDS (16 KB, one ds_read_b128 per MFMA); the three parts accumulate on
+// separate chains and are added smallest first.  Byte -> bf16 is v_cvt_f32_ubyteN + one v_perm_b32 per pair (the
+// upper half of the f32 is the exact bf16).  Staging, tile walk and epilogue are the f32 kernel's.
+typedef __bf16 cv_bf8 __attribute__((ext_vector_type(8)));
+constexpr int C1_WPK3 = 3 * 2 * C1_K * 64 * 4;      // packed bf16 image in dwords: [part][half][kh][lane] x 16 B
+
+__device__ __forceinline__ unsigned c1_pk_bf(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// wpk3[((part*2 + m)*8 + kh)*64 + lane] = 8 bf16 (kw = 0..7) of part `part` of w[f][c][kh][kw] * scale with the
+// A-operand lane map row i = lane & 15 -> filter f = (i>>2)*8 + m*4 + (i&3) (as k_conv1_pack_w), k group lane >> 4 = c
+__global__ void __launch_bounds__(256)
+k_conv1_pack_w3(const float* __restrict__ w, int64_t so, int64_t sc, int64_t sh, int64_t sw, float scale, uint4* __restrict__ wpk3) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 2 * C1_K * 64) return;
+  const int lane = t & 63, kh = (t >> 6) & 7, m = t >> 9;
+  const int i = lane & 15, c = lane >> 4;
+  const int f = (i >> 2) * 8 + m * 4 + (i & 3);
+  unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float x0 = w[f * so + c * sc + kh * sh + (2 * e) * sw] * scale, x1 = w[f * so + c * sc + kh * sh + (2 * e + 1) * sw] * scale;
+    ph[e] = c1_pk_bf(x0, x1);
+    const float r0 = x0 - __uint_as_float(ph[e] << 16), r1 = x1 - __uint_as_float(ph[e] & 0xffff0000u);
+    pm[e] = c1_pk_bf(r0, r1);
+    const float s0 = r0 - __uint_as_float(pm[e] << 16), s1 = r1 - __uint_as_float(pm[e] & 0xffff0000u);
+    pl[e] = c1_pk_bf(s0, s1);
+  }
+  const int o = (m * 8 + kh) * 64 + lane;
+  wpk3[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+  wpk3[16 * 64 + o] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+  wpk3[32 * 64 + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+
+__device__ __forceinline__ cv_bf8 c1_as_bf8(uint4 v) { return __builtin_bit_cast(cv_bf8, v); }
+
+// bytes (2e, 2e+1) of v -> two bf16 in one dword
+__device__ __forceinline__ unsigned c1_bytes_bf(uint32_t v, int e) {
+  const float a = (float)((v >> (16 * e)) & 0xffu), b = (float)((v >> (16 * e + 8)) & 0xffu);
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+
+#define C1_TILE_ADDR(tt_, f_, p_, base_)                                                        \
+  {                                                                                             \
+    f_ = (FPI > 1 && tt_ >= tiles) ? 1 : 0;                                                     \
+    p_ = (tt_ - f_ * tiles) * 16 + j;                                                           \
+    const int pc_ = p_ < OHW ? p_ : OHW - 1;                                                    \
+    const int oh_ = OW == 1 ? pc_ : (int)__umulhi((unsigned)pc_, ow_magic);                     \
+    base_ = c1_lds + (f_ * C1_PLANES + kq) * pitch + (oh_ * C1_S) * W + (pc_ - oh_ * OW) * C1_S; \
+  }
+#define C1_TILE_READ(base_, px_)                                                                \
+  _Pragma("unroll") for (int kh = 0; kh < C1_K; ++kh) {                                         \
+    px_[2 * kh] = *reinterpret_cast<const uint32_t*>(base_ + kh * W);                           \
+    px_[2 * kh + 1] = *reinterpret_cast<const uint32_t*>(base_ + kh * W + 4);                   \
+  }
+#define C1B_TILE_COMPUTE(px_, f_, p_)                                                           \
+  {                                                                                             \
+    cv_f4 h0 = {0.f, 0.f, 0.f, 0.f}, m0 = h0, l0 = h0, h1 = h0, m1 = h0, l1 = h0;               \
+    _Pragma("unroll") for (int kh = 0; kh < C1_K; ++kh) {                                       \
+      const cv_bf8 b_ = c1_as_bf8(make_uint4(c1_bytes_bf(px_[2 * kh], 0), c1_bytes_bf(px_[2 * kh], 1),       \
+                                             c1_bytes_bf(px_[2 * kh + 1], 0), c1_bytes_bf(px_[2 * kh + 1], 1))); \
+      l0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1_as_bf8(wlo[kh * 64 + lane]), b_, l0, 0, 0, 0);          \
+      l1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1_as_bf8(wlo[(C1_K + kh) * 64 + lane]), b_, l1, 0, 0, 0); \
+      m0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm0[kh], b_, m0, 0, 0, 0);                   \
+      m1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm1[kh], b_, m1, 0, 0, 0);                   \
+      h0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh0[kh], b_, h0, 0, 0, 0);                   \
+      h1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh1[kh], b_, h1, 0, 0, 0);                   \
+    }                                                                                           \
+    if (p_ < OHW) {                                                                             \
+      cv_f4 o0 = ((l0 + m0) + h0) + b0, o1 = ((l1 + m1) + h1) + b1;                             \
+      o0.x = o0.x > 0.f ? o0.x : 0.f; o0.y = o0.y > 0.f ? o0.y : 0.f; o0.z = o0.z > 0.f ? o0.z : 0.f; o0.w = o0.w > 0.f ? o0.w : 0.f; \
+      o1.x = o1.x > 0.f ? o1.x : 0.f; o1.y = o1.y > 0.f ? o1.y : 0.f; o1.z = o1.z > 0.f ? o1.z : 0.f; o1.w = o1.w > 0.f ? o1.w : 0.f; \
+      cv_f4* dst = reinterpret_cast<cv_f4*>(y + ((n0 + f_) * (int64_t)OHW + p_) * C1_F + kq * 8); \
+      if (NTS) { __builtin_nontemporal_store(o0, dst); __builtin_nontemporal_store(o1, dst + 1); } \
+      else { dst[0] = o0; dst[1] = o1; }                                                        \
+    }                                                                                           \
+  }
+
+template <int FPI, int NTS>
+__global__ void __launch_bounds__(256, 2)
+k_conv1_u8_fwd_bf(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, int split, const uint8_t* __restrict__ x,
+                  const uint4* __restrict__ wpk3, const float* __restrict__ bias, float* __restrict__ y) {
+  extern __shared__ __align__(16) uint8_t c1_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  cv_bf8 wh0[C1_K], wh1[C1_K], wm0[C1_K], wm1[C1_K];
+#pragma unroll
+  for (int kh = 0; kh < C1_K; ++kh) {
+    wh0[kh] = c1_as_bf8(wpk3[kh * 64 + lane]);             wh1[kh] = c1_as_bf8(wpk3[(C1_K + kh) * 64 + lane]);
+    wm0[kh] = c1_as_bf8(wpk3[(16 + kh) * 64 + lane]);      wm1[kh] = c1_as_bf8(wpk3[(16 + C1_K + kh) * 64 + lane]);
+  }
+  // lo parts: 16 KB behind the frame area
+  uint4* wlo = reinterpret_cast<uint4*>(c1_lds + FPI * C1_PLANES * pitch);
+  for (int o = tid; o < 16 * 64; o += 256) wlo[o] = wpk3[32 * 64 + o];
+  const cv_f4 b0 = *reinterpret_cast<const cv_f4*>(bias + kq * 8), b1 = *reinterpret_cast<const cv_f4*>(bias + kq * 8 + 4);
+  const int HW = H * W, OHW = OH * OW, tiles = (OHW + 15) >> 4, hw16 = HW >> 4;
+  const int groups = (N + FPI - 1) / FPI, units = groups * split, step = 4 * split;
+  bool first = true;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int group = split == 1 ? u : u / split, part = u - group * split;
+    const int n0 = group * FPI;
+    const int frames = N - n0 < FPI ? N - n0 : FPI;
+    if (!first) __syncthreads();      // every wave is done reading the previous frames
+    first = false;
+    {
+      const int vecs = frames * C1_PLANES * hw16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(x + (int64_t)n0 * (C1_PLANES * HW));
+      for (int o0 = tid; o0 < vecs; o0 += 256 * C1_LD) {
+        uint4 v[C1_LD];
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; v[k] = s4[o < vecs ? o : vecs - 1]; }
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) {
+          const int o = o0 + k * 256;
+          if (o < vecs) { const int pl = o / hw16; *reinterpret_cast<uint4*>(c1_lds + pl * pitch + (o - pl * hw16) * 16) = v[k]; }
+        }
+      }
+      __syncthreads();
+    }
+    const int tend = frames * tiles;
+    int tt = part * 4 + wave;
+    if (tt >= tend) continue;
+    uint32_t pxa[2 * C1_K], pxb[2 * C1_K];
+    int fa, pa, fb = 0, pb = 0;
+    const uint8_t* base;
+    C1_TILE_ADDR(tt, fa, pa, base);
+    C1_TILE_READ(base, pxa);
+    for (;;) {
+      const bool more_b = tt + step < tend;
+      if (more_b) { C1_TILE_ADDR(tt + step, fb, pb, base); C1_TILE_READ(base, pxb); }
+      __builtin_amdgcn_sched_barrier(0);            // LDS words of the next tile in flight before this chain
+      C1B_TILE_COMPUTE(pxa, fa, pa);
+      if (!more_b) break;
+      tt += 2 * step;
+      const bool more_a = tt < tend;
+      if (more_a) { C1_TILE_ADDR(tt, fa, pa, base); C1_TILE_READ(base, pxa); }
+      __builtin_amdgcn_sched_barrier(0);
+      C1B_TILE_COMPUTE(pxb, fb, pb);
+      if (!more_a) break;
+    }
+  }
+}
+#undef C1_TILE_ADDR
+#undef C1_TILE_READ
+#undef C1B_TILE_COMPUTE
+
+// ---------------------------------------------------------------------------
 // Weight gradient of the same layer from the same uint8 frames:
 //   dW[f][c][kh][kw] = scale * sum over (n, oh, ow) of g[n][oh][ow][f] * float(x[n][c][4 oh + kh][4 ow + kw])
 // (what autograd derives for cnn.py:44-49; the layer's input needs no gradient).
@@ -365,9 +522,13 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   hipStream_t st = (hipStream_t)stream;
   const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
   const int tiles = (OH * OW + 15) / 16;
+  static const int bf_env = getenv("MIRL_CONV1_BF16") ? atoi(getenv("MIRL_CONV1_BF16")) : 1;
+  const int dbg0 = (flags >> 24) & 7;
+  const bool bf = bf_env && !dbg0 && !(flags & 32) && !(flags & 4);      // bit 5: force the f32-MFMA kernel (probe / A-B)
   if (!(flags & 8)) {                                     // bit 3: wpk already holds these weights packed (acting steps between updates)
     ProfScope ps("k_conv1_pack_w", 2.0 * C1_WPK * 4, st);
-    hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, wpk);
+    if (bf) hipLaunchKernelGGL(k_conv1_pack_w3, dim3(4), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, (uint4*)wpk);
+    else hipLaunchKernelGGL(k_conv1_pack_w, dim3((C1_WPK + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, wpk);
     MIRL_LAUNCH_CHECK();
   }
   int fpi = (flags >> 8) & 0xff, split = (flags >> 16) & 0xff;
@@ -379,9 +540,28 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   if (fpi == 2) split = 1;
   const int64_t units = (N + fpi - 1) / fpi * split;
   const unsigned grid = (unsigned)(units < 512 ? units : 512);
-  const size_t lds = (size_t)fpi * C1_PLANES * pitch;
+  const size_t lds = (size_t)fpi * C1_PLANES * pitch + (bf ? 16 * 1024 : 0);
   ProfScope ps("k_conv1_u8_fwd", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
   const bool nts = !(flags & 1);
+  if (bf) {
+    const uint4* w3 = (const uint4*)wpk;
+#define C1B_LAUNCH(FPI_, NTS_) \
+  hipLaunchKernelGGL((k_conv1_u8_fwd_bf<FPI_, NTS_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic_bf, pitch, split, x, w3, bias, y)
+    const unsigned ow_magic_bf = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
+    static bool attr_set = false;
+    if (!attr_set) {                                        // 2 frames + 16 KB of weight parts = 74 KB of dynamic LDS
+      MIRL_HIP(hipFuncSetAttribute((const void*)k_conv1_u8_fwd_bf<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      MIRL_HIP(hipFuncSetAttribute((const void*)k_conv1_u8_fwd_bf<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      MIRL_HIP(hipFuncSetAttribute((const void*)k_conv1_u8_fwd_bf<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      MIRL_HIP(hipFuncSetAttribute((const void*)k_conv1_u8_fwd_bf<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr_set = true;
+    }
+    if (fpi == 2) { if (nts) C1B_LAUNCH(2, 1); else C1B_LAUNCH(2, 0); }
+    else          { if (nts) C1B_LAUNCH(1, 1); else C1B_LAUNCH(1, 0); }
+#undef C1B_LAUNCH
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
   const int dbg = (flags >> 24) & 7;
   const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;   // exact n / OW for n < 2^16
 #define C1_LAUNCH(FPI_, NTS_, DBG_) \

@@ -199,7 +199,7 @@ class _ConvU8BiasReLU(torch.autograd.Function):
         oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
         y = torch.empty((n, f, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if n:
-            wpk = torch.empty(8192, dtype=torch.float32, device=x.device)
+            wpk = torch.empty(12288, dtype=torch.float32, device=x.device)
             so, sc, sh, sw = weight.stride()
             b = bias if bias.data_ptr() % 16 == 0 else bias.clone()
             L.check(L.lib.mirl_conv1_u8_fwd(n, h, w, _p(x), _p(weight), so, sc, sh, sw, _p(b), float(scale), _p(wpk), _p(y),

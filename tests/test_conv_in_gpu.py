@@ -23,7 +23,7 @@ def _call(x, w, b, scale, flags=None):
     n, _, h, ww = x.shape
     oh, ow = (h - 8) // 4 + 1, (ww - 8) // 4 + 1
     y = torch.full((n, 32, oh, ow), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
-    wpk = torch.empty(8192, device="cuda")
+    wpk = torch.empty(12288, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     so, sc, sh, sw = w.stride()
@@ -60,8 +60,12 @@ def test_launch_shapes_agree_bitwise(n, h, w):
             for cached in (0, 1):
                 got = _call(x, wt, b, 1.0 / 255.0, flags=cached | (fpi << 8) | (split << 16))
                 assert torch.equal(got, base), (fpi, split, cached)
-    # conversions hoisted in front of the MFMA chain (flag bit 2): same sums in the same order
-    assert torch.equal(_call(x, wt, b, 1.0 / 255.0, flags=4 | (2 << 8)), base)
+    # the f32-MFMA kernel (flag bit 5), conversions hoisted in front of its chain or interleaved (bit 2): same sums in
+    # the same order; against the default bf16-pipe kernel (exact pixels x three-way split weights) only the order of
+    # the 256-term f32 sum differs
+    f32k = _call(x, wt, b, 1.0 / 255.0, flags=32 | (2 << 8))
+    assert torch.equal(_call(x, wt, b, 1.0 / 255.0, flags=4 | 32 | (2 << 8)), f32k)
+    assert float((f32k - base).abs().max()) <= 2e-6 * float(base.abs().max())
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 84, 84), (257, 84, 84), (2050, 84, 84), (5, 44, 52)])

@@ -36,7 +36,7 @@ def main():
     for n in sizes:
         x = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, device="cuda")
         y = torch.empty((n, 32, 20, 20), device="cuda").contiguous(memory_format=torch.channels_last)
-        wpk = torch.empty(8192, device="cuda")
+        wpk = torch.empty(12288, device="cuda")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         so, sc, sh, sw = conv.weight.stride()
         flop = n * 400 * 2.0 * 256 * 32
