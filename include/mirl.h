@@ -492,6 +492,15 @@ int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, int64_t K, 
 int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
                const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu,
                void* workspace, int64_t workspace_bytes, void* stream);
+/* layout NT with the IQN feature product in the epilogue (rltime/policies/torch/iqn.py:82-102:
+ * relu(linear(phi)) times the state's features repeated over its quantile rows):
+ *   C[r][c] = f(A B^T + bias)[r][c] * mul[r >> group_shift][c],  f = ReLU if relu
+ * and, if `pre` is given, pre[r][c] = f(...)[r][c] (what the backward needs).  Rows of one state are
+ * 2^group_shift consecutive rows.  Removes the separate multiply pass over the (rows, N) embedding. */
+int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu,
+                      const float* mul, int64_t ldmul, int32_t group_shift, float* pre, int64_t ldpre,
+                      void* stream);
 
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC

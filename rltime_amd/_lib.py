@@ -167,6 +167,7 @@ _SIGNATURES = {
     "mirl_gemm3_supported": [_i32, _i64, _i64, _i64],
     "mirl_gemm3_workspace_bytes": [_i32, _i64, _i64, _i64, _P(_i64)],
     "mirl_gemm3": [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp],
+    "mirl_gemm3_nt_mul": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "mirl_bias_relu_rows": [_i64, _i32, _vp, _vp, _vp],
     "mirl_colsum_blocks": [_i64, _i32, _P(_i32)],
     "mirl_relu_bwd_bias_rows": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],

@@ -36,11 +36,13 @@ namespace mirl {
 
 typedef __bf16 g3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float g3_f32x16 __attribute__((ext_vector_type(16)));
+typedef float g3_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G3_PITCH = 48;                 // bytes per LDS row: 16 bf16 + 16 B pad
 constexpr int G3_PLANE = 256 * G3_PITCH;     // one part of one operand
 constexpr int G3_STAGE = 6 * G3_PLANE;
 constexpr int G3_LDS = 2 * G3_STAGE;
+constexpr int G3_EPITCH = 68;               // floats per row of a wave's 64 x 64 epilogue transpose (8 x 17 408 B <= G3_LDS)
 
 struct G3Args {
   const float* A; const float* B; float* C; const float* bias;
@@ -51,6 +53,10 @@ struct G3Args {
   int splits;            // K chunks (1 = none); with splits > 1, C is [splits][M][N] partials (ldc = N)
   int steps_per_split;   // K-steps of 16 per chunk
   int order;             // 0: the two waves of a SIMD take opposite stage/compute orders; 1: all stage first; 2: all compute first
+  // epilogue extension (NT): C = f(A B^T + bias) * mul[row >> mul_shift][col]; `pre` (optional) receives f(...) itself
+  const float* mul; int64_t ldmul; int mul_shift;
+  float* pre; int64_t ldpre;
+  int vec_ok;            // 16-byte stores possible: N % 4 == 0, every output / bias / multiplier row 16-byte aligned
 };
 
 __device__ __forceinline__ unsigned g3_pk(float lo, float hi) {
@@ -135,8 +141,8 @@ __device__ __forceinline__ g3_f32x16 g3_mfma(g3_bf16x8 a, g3_bf16x8 b, g3_f32x16
 }
 
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
-// of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.
-template <int FRAGS_UP_FRONT>
+// of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.  (Issuing all 18 fragment reads before the
+// first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.)
 __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4][2], int a_off, int b_off) {
   const char* pa = stage + a_off;
   const char* pb = stage + 3 * G3_PLANE + b_off;
@@ -148,36 +154,19 @@ __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const g3_bf16x8*>(pb + p * G3_PLANE + j * 32 * G3_PITCH);
-  if (FRAGS_UP_FRONT) {
-    // all 18 fragment reads in flight before the first MFMA: one exposed LDS latency per K-step instead of one
-    // per A half (72 fragment registers)
-    g3_bf16x8 a[3][4];
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    g3_bf16x8 a[3][2];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + i * 32 * G3_PITCH);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[i][j]);
-  } else {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      g3_bf16x8 a[3][2];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
-    }
+        for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
   }
 }
 
@@ -186,7 +175,7 @@ __device__ __forceinline__ void g3_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool AKC, bool BKC, int UF>
+template <bool AKC, bool BKC, int EP, bool VEC>
 __global__ void __launch_bounds__(512)
 k_gemm3(G3Args g) {
   extern __shared__ __attribute__((aligned(16))) char g3_lds[];
@@ -252,7 +241,7 @@ k_gemm3(G3Args g) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
       }
-      g3_compute<UF>(cur, acc, a_off, b_off);
+      g3_compute(cur, acc, a_off, b_off);
       if (!stage_first) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
@@ -272,22 +261,70 @@ k_gemm3(G3Args g) {
       }
     }
 
-    // epilogue: C/D register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+    // epilogue: C/D register r of a 32x32 tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 — one column
+    // per lane, so storing straight from the accumulators is 128 four-byte store instructions per wave, and the
+    // store ISSUE (not bandwidth) was 13 us of a 90 us K = 512 tile.  Each wave transposes its block through its own
+    // 17 KB of the (now idle) staging LDS in two 64-row halves and stores 16 bytes per lane, 256 contiguous bytes per row.
     float* C = g.C + (g.splits > 1 ? (int64_t)split * g.M * g.N : 0);
+    if (VEC) {
+      float* tl = reinterpret_cast<float*>(g3_lds) + wu * (64 * G3_EPITCH);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
-      const bool col_ok = col < g.N;
-      const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = rb + (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][r] + bv;
-          if (g.relu) v = v > 0.0f ? v : 0.0f;
-          if (col_ok && row < g.M) __builtin_nontemporal_store(v, C + row * g.ldc + col);
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              tl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * G3_EPITCH + j * 32 + (lane & 31)] = acc[2 * h + ii][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int c4 = lane & 15;
+        const int64_t col = n0 + wn * 64 + c4 * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && col < g.N) {      // N % 4 == 0 on this path
+          bv = *reinterpret_cast<const float4*>(g.bias + col);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int rl = q * 4 + (lane >> 4);
+          const int64_t row = m0 + wm * 128 + h * 64 + rl;
+          float4 v = *reinterpret_cast<const float4*>(tl + rl * G3_EPITCH + c4 * 4);
+          if (row < g.M && col < g.N) {
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (g.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            if (EP == 1) {
+              // IQN feature product (iqn.py:84,102): the row group r >> mul_shift (one state's quantile rows) shares one row of `mul`
+              if (g.pre) __builtin_nontemporal_store(g3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<g3_f32x4*>(g.pre + row * g.ldpre + col));
+              const float4 m = *reinterpret_cast<const float4*>(g.mul + (row >> g.mul_shift) * g.ldmul + col);
+              v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+            }
+            __builtin_nontemporal_store(g3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<g3_f32x4*>(C + row * g.ldc + col));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this half read before the next one overwrites it
+      }
+      if (more) g3_barrier();          // persistent walk: every wave's transpose done before the next tile is staged
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool col_ok = col < g.N;
+        const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = rb + (r & 3) + 8 * (r >> 2);
+            if (!(col_ok && row < g.M)) continue;
+            float v = acc[i][j][r] + bv;
+            if (g.relu) v = v > 0.0f ? v : 0.0f;
+            if (EP == 1) {
+              if (g.pre) __builtin_nontemporal_store(v, g.pre + row * g.ldpre + col);
+              v *= g.mul[(row >> g.mul_shift) * g.ldmul + col];
+            }
+            __builtin_nontemporal_store(v, C + row * g.ldc + col);
+          }
         }
       }
     }
@@ -340,9 +377,10 @@ extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, 
   return MIRL_OK;
 }
 
-extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
-                          int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
-                          int64_t workspace_bytes, void* stream) {
+static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                     int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
+                     int64_t workspace_bytes, const float* mul, int64_t ldmul, int32_t mul_shift, float* pre, int64_t ldpre,
+                     void* stream) {
   using namespace mirl;
   if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
   if (!A || !B || !C) return fail(MIRL_ERR_ARG, "gemm3: null operand");
@@ -357,13 +395,17 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
   G3Args g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.relu = relu ? 1 : 0;
+  g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
+  static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
+  g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!bias || !((uintptr_t)bias % 16)) &&
+             (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));
   g.mt = (int)((M + 255) / 256); g.nt = (int)((N + 255) / 256);
   g.splits = 1; g.steps_per_split = (int)(K / 16);
   static const int order_env = getenv("MIRL_GEMM3_ORDER") ? atoi(getenv("MIRL_GEMM3_ORDER")) : 0;
   g.order = order_env;
   static const int persist_env = getenv("MIRL_GEMM3_PERSIST") ? atoi(getenv("MIRL_GEMM3_PERSIST")) : 0;   // measured: no gain (7.36 vs 7.32 ms), opt-in
   unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);                 // one tile per workgroup
-  if (persist_env) {
+  if (persist_env || K <= 128) {          // short K: the tile is mostly epilogue — let the next tile's loads fly during the stores
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -379,18 +421,20 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
     g.C = (float*)workspace; g.ldc = N;
     grid = (unsigned)(g.mt * g.nt * g.splits);
   }
-  static const int uf_env = getenv("MIRL_GEMM3_UF") ? atoi(getenv("MIRL_GEMM3_UF")) : 0;
-  static bool attr[3][2] = {{false, false}, {false, false}, {false, false}};
-  const int uf = uf_env ? 1 : 0;
-  const void* fns[3][2] = {{(const void*)k_gemm3<true, true, 0>, (const void*)k_gemm3<true, true, 1>},
-                           {(const void*)k_gemm3<true, false, 0>, (const void*)k_gemm3<true, false, 1>},
-                           {(const void*)k_gemm3<false, false, 0>, (const void*)k_gemm3<false, false, 1>}};
-  if (!attr[layout][uf]) { MIRL_HIP(hipFuncSetAttribute(fns[layout][uf], hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[layout][uf] = true; }
+  const int vec = g.vec_ok ? 1 : 0;
+  static bool attr[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
+  const void* fns[4][2] = {{(const void*)k_gemm3<true, true, 0, false>, (const void*)k_gemm3<true, true, 0, true>},
+                           {(const void*)k_gemm3<true, false, 0, false>, (const void*)k_gemm3<true, false, 0, true>},
+                           {(const void*)k_gemm3<false, false, 0, false>, (const void*)k_gemm3<false, false, 0, true>},
+                           {(const void*)k_gemm3<true, true, 1, false>, (const void*)k_gemm3<true, true, 1, true>}};
+  const int which = mul ? 3 : layout;
+  const void* fn = fns[which][vec];
+  if (!attr[which][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[which][vec] = true; }
   {
     const double flop = 2.0 * (double)M * (double)N * (double)K;
-    ProfScope ps(layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", flop, st);   // "bytes" slot carries flop here
+    ProfScope ps(mul ? "k_gemm3_nt_mul" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", flop, st);   // "bytes" slot carries flop here
     void* kargs[] = {(void*)&g};
-    MIRL_HIP(hipLaunchKernel(fns[layout][uf], dim3(grid), dim3(512), kargs, G3_LDS, st));
+    MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
   if (layout == 2) {
     ProfScope ps("k_gemm3_reduce", (double)(g.splits + 1) * (double)M * (double)N * 4.0, st);
@@ -400,4 +444,19 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
     MIRL_LAUNCH_CHECK();
   }
   return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
+                          int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+  return g3_launch(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, workspace, workspace_bytes, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                 float* C, int64_t ldc, const float* bias, int32_t relu, const float* mul, int64_t ldmul,
+                                 int32_t group_shift, float* pre, int64_t ldpre, void* stream) {
+  using namespace mirl;
+  if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
+    return fail(MIRL_ERR_ARG, "gemm3_nt_mul: bad multiplier / pre-activation arguments");
+  return g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream);
 }

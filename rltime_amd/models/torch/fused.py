@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from . import gemm3
 
 _TAIL_WGRAD = os.environ.get("MIRL_TAIL_WGRAD", "1") != "0"
+_QP_EPILOGUE = os.environ.get("MIRL_QP_EPILOGUE", "1") != "0"
 
 
 def _lib():
@@ -258,14 +259,18 @@ class _QuantileProduct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, phi, weight, bias, n, track=True):
         L = _lib()
-        emb = torch._addmm_activation(bias, phi, weight.t(), use_gelu=False)
         M, Cf = x.shape
-        # no-grad passes (target / selection / acting): the embedding is not needed again, multiply in place
+        # no-grad passes (target / selection / acting): the embedding is not needed again
         # (`track` comes from the caller's torch.is_grad_enabled(): ctx.needs_input_grad mirrors
         # requires_grad even under no_grad)
         need = track and any(ctx.needs_input_grad)
-        out = torch.empty_like(emb) if need else emb
-        L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
+        if _QP_EPILOGUE and gemm3.quantile_product_supported(x, phi, weight, bias, n):
+            # embedding GEMM + ReLU + product in ONE launch (split-bf16 kernel, multiply in its epilogue)
+            out, emb = gemm3.quantile_product(x, phi, weight, bias, n, need)
+        else:
+            emb = torch._addmm_activation(bias, phi, weight.t(), use_gelu=False)
+            out = torch.empty_like(emb) if need else emb     # no-grad: multiply in place
+            L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
         ctx.n = n
         ctx.save_for_backward(x, phi, weight, emb)
         return out

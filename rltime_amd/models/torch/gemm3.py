@@ -132,3 +132,22 @@ def linear(x, w, bias):
     if enabled() and x.dim() == 2 and supported(NT, x, w) and bias is not None:
         return _Linear.apply(x, w, bias.contiguous())
     return torch.nn.functional.linear(x, w, bias)
+
+
+def quantile_product_supported(x, phi, weight, bias, n):
+    """Can relu(linear(phi)) * x[row // n] run as ONE NT product with the multiply in its epilogue?"""
+    return (enabled() and n > 0 and (n & (n - 1)) == 0 and supported(NT, phi, weight) and _rowmajor(x)
+            and x.shape[1] == weight.shape[0] and x.shape[0] * n == phi.shape[0]
+            and bias is not None and bias.is_contiguous() and bias.dtype == torch.float32)
+
+
+def quantile_product(x, phi, weight, bias, n, keep_embedding):
+    """-> (out, emb or None): out[m*n + j] = x[m] * relu(phi[m*n + j] @ weight^T + bias)  (iqn.py:82-102)."""
+    L = _lib()
+    R, K, N = phi.shape[0], phi.shape[1], weight.shape[0]
+    out = torch.empty((R, N), dtype=torch.float32, device=phi.device)
+    emb = torch.empty((R, N), dtype=torch.float32, device=phi.device) if keep_embedding else None
+    L.check(L.lib.mirl_gemm3_nt_mul(R, N, K, _p(phi), phi.stride(0), _p(weight), weight.stride(0), _p(out), out.stride(0),
+                                    _p(bias), 1, _p(x), x.stride(0), n.bit_length() - 1,
+                                    _p(emb) if emb is not None else None, N, _stream()), "mirl_gemm3_nt_mul")
+    return out, emb

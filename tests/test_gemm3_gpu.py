@@ -168,3 +168,53 @@ def test_dueling_tail_and_linear_relu_match_the_library_path(monkeypatch):
             # dW1 / dWv / element of db then differ legitimately — a handful of rows at most
             bad = int(off.any(dim=-1).sum()) if off.dim() == 2 else int(off.sum())
             assert bad <= 8, (name, bad)
+
+
+@pytest.mark.parametrize("M,n", [(4096, 32), (3000, 8), (1500, 64), (777, 1)])
+def test_quantile_product_in_the_epilogue(M, n):
+    """relu(linear(phi)) * x[row // n] as one NT product with the multiply in its epilogue (iqn.py:82-102)."""
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(M + n)
+    K, N = 64, 512
+    x = torch.randn(M, N, device="cuda", generator=gen)
+    phi = torch.cos(torch.rand(M * n, 1, device="cuda", generator=gen) * torch.arange(1, K + 1, device="cuda") * 3.14159265)
+    w = torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=gen) * 0.1
+    emb64 = torch.relu(phi.double() @ w.double().t() + b.double())
+    want = emb64 * x.double().repeat_interleave(n, dim=0)
+    for keep in (True, False):
+        out, emb = gemm3.quantile_product(x, phi, w, b, n, keep)
+        assert float((out.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        if keep:
+            assert float((emb.double() - emb64).abs().max()) <= 1e-5 * float(emb64.abs().max())
+            assert torch.equal(out, emb * x.repeat_interleave(n, dim=0))       # the product itself is one f32 multiply
+        else:
+            assert emb is None
+
+
+def test_quantile_product_autograd_with_and_without_the_epilogue(monkeypatch):
+    from rltime_amd.models.torch import fused
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    M, n, K, N = 4096, 32, 64, 512
+    x = torch.randn(M, N, device="cuda", generator=gen)
+    phi = torch.cos(torch.rand(M * n, 1, device="cuda", generator=gen) * torch.arange(1, K + 1, device="cuda") * 3.14159265)
+    w = torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=gen) * 0.1
+    go = torch.randn(M * n, N, device="cuda", generator=gen)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(fused, "_QP_EPILOGUE", mode)
+        xx, ww, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = fused.quantile_product(xx, phi, ww, bb, n)
+        out.backward(go)
+        with torch.no_grad():
+            nograd = fused.quantile_product(xx, phi, ww, bb, n)
+        res[mode] = (out.detach(), nograd, xx.grad, ww.grad, bb.grad)
+    for k, (got, lib) in enumerate(zip(res[True], res[False])):
+        tol = (2e-5 if k < 2 else 1e-4) * float(lib.abs().max())
+        off = (got - lib).abs() > tol
+        if k < 2:
+            assert not bool(off.any()), k
+        else:                                                   # ReLU-threshold flips: a handful of rows at most
+            bad = int(off.any(dim=-1).sum()) if off.dim() == 2 else int(off.sum())
+            assert bad <= 8, (k, bad)
