@@ -675,7 +675,7 @@ def main():
                 entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
                               "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
-            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn") and by > 0:
+            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul") and by > 0:
                 # the split-bf16 GEMMs record their f32 flop (2 M N K) in the bytes slot; they issue six bf16 MFMAs
                 # per f32 product block, so the f32 product is priced against 2.5 PFLOP/s / 6
                 tf = by / (avg_us * 1e-6) / 1e12
@@ -710,7 +710,13 @@ def main():
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
                 "acting_overlapped_on_second_stream": res["overlap"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
-                "replay_fill_seconds": round(res["fill_s"], 2)},
+                "replay_fill_seconds": round(res["fill_s"], 2),
+                "f32_products_on": ("bf16 matrix pipe for the wide GEMMs (6 exact-split bf16 MFMAs per f32 product block, "
+                                    "csrc/gemm3.hip) and the input layer's forward (uint8 pixels are exact bf16, weights split "
+                                    "three ways, csrc/conv_in.hip); f32 accumulation, results within the library f32 GEMM's own "
+                                    "distance from float64 (tests/test_gemm3_gpu.py, DESIGN 3.6); everything else f32 pipe"
+                                    if (os.environ.get("MIRL_GEMM3", "1") != "0" or os.environ.get("MIRL_CONV1_BF16", "1") != "0")
+                                    else "f32 MFMA pipe only (MIRL_GEMM3=0 MIRL_CONV1_BF16=0)")},
             "roofline": {
                 "kernel": "k_gather_rows_dedup (frames)" if args.frame_dedup else "k_gather_rows (frames)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
