@@ -675,7 +675,7 @@ def main():
                 entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
                               "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
-            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul") and by > 0:
+            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd") and by > 0:
                 # the split-bf16 GEMMs record their f32 flop (2 M N K) in the bytes slot; they issue six bf16 MFMAs
                 # per f32 product block, so the f32 product is priced against 2.5 PFLOP/s / 6
                 tf = by / (avg_us * 1e-6) / 1e12

@@ -502,6 +502,20 @@ int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       const float* mul, int64_t ldmul, int32_t group_shift, float* pre, int64_t ldpre,
                       void* stream);
 
+/* ---- forward of the middle conv layers on the bf16 matrix pipe, f32 result (csrc/conv3.hip).  Replaces
+ * `F.relu(conv(x))` of rltime/models/torch/modules/cnn.py:47-49 for NHWC activations (the Atari models' layers 2
+ * and 3: configs/models/cnn_*.json) — the library's f32 implicit GEMM plus a separate bias + ReLU pass — by ONE
+ * implicit GEMM with the exact three-way bf16 split of mirl_gemm3 (six part products accumulated in f32):
+ *   x     float [N][H][W][C]            (NHWC memory of the logical (N, C, H, W) tensor)
+ *   w     float [F][KH][KW][C]          (channels_last memory of the logical (F, C, KH, KW) weight)
+ *   y     float [N][OH][OW][F] = f(conv(x, w, stride S, no padding) + bias), f = ReLU if relu
+ * mirl_conv3_fwd_supported(): C % 4 == 0, F % 4 == 0, F <= 64, (KW * C) % 16 == 0; otherwise MIRL_ERR_ARG and
+ * the caller keeps the library path.  fp32 tolerance as mirl_gemm3 (tests/test_conv3_gpu.py; bit-exact on
+ * small-integer operands).                                                                                   */
+int mirl_conv3_fwd_supported(int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S, int32_t H, int32_t W);
+int mirl_conv3_fwd(int64_t N, int32_t H, int32_t W, int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S,
+                   const float* x, const float* w, const float* bias, int32_t relu, float* y, void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

@@ -191,7 +191,6 @@ k_conv1_u8_fwd(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
 // separate chains and are added smallest first.  Byte -> bf16 is v_cvt_f32_ubyteN + one v_perm_b32 per pair (the
 // upper half of the f32 is the exact bf16).  Staging, tile walk and epilogue are the f32 kernel's.
 typedef __bf16 cv_bf8 __attribute__((ext_vector_type(8)));
-constexpr int C1_WPK3 = 3 * 2 * C1_K * 64 * 4;      // packed bf16 image in dwords: [part][half][kh][lane] x 16 B
 
 __device__ __forceinline__ unsigned c1_pk_bf(float lo, float hi) {
   unsigned r;

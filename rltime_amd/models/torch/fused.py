@@ -31,6 +31,7 @@ from . import gemm3
 
 _TAIL_WGRAD = os.environ.get("MIRL_TAIL_WGRAD", "1") != "0"
 _QP_EPILOGUE = os.environ.get("MIRL_QP_EPILOGUE", "1") != "0"
+_CONV3 = os.environ.get("MIRL_CONV3", "1") != "0"
 
 
 def _lib():
@@ -104,13 +105,48 @@ def linear_relu(x, weight, bias):
     return F.relu(F.linear(x, weight, bias))
 
 
+def conv3_supported(x, weight, stride, min_work=1 << 31):
+    """Does the split-bf16 implicit GEMM (csrc/conv3.hip) take this NHWC conv forward?"""
+    if not (_CONV3 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
+            and stride[0] == stride[1]):
+        return False
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    s = int(stride[0])
+    if h < kh or w < kw:
+        return False
+    work = n * ((h - kh) // s + 1) * ((w - kw) // s + 1) * f * c * kh * kw
+    return work >= min_work and bool(_lib().lib.mirl_conv3_fwd_supported(c, f, kh, kw, s, h, w))
+
+
+def conv3_bias_relu(x, weight, bias, stride, relu=True):
+    """relu(conv2d(x, weight, bias, stride)) for NHWC x in ONE launch; returns the NHWC (channels_last) result."""
+    L = _lib()
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    s = int(stride[0])
+    wk = weight.permute(0, 2, 3, 1)                   # (F, KH, KW, C): a view for channels_last weights
+    if not wk.is_contiguous():
+        wk = wk.contiguous()
+    y = torch.empty((n, f, (h - kh) // s + 1, (w - kw) // s + 1), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    b = bias.contiguous() if bias is not None else None
+    L.check(L.lib.mirl_conv3_fwd(n, h, w, c, f, kh, kw, s, _p(x), _p(wk), _p(b) if b is not None else None,
+                                 1 if relu else 0, _p(y), _stream()), "mirl_conv3_fwd")
+    return y
+
+
 class _ConvBiasReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
-        y = F.conv2d(x, weight, None, stride)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        bias_relu_rows_(y, bias, y.shape[1])          # NHWC memory: (N*H*W, C) rows
+        if conv3_supported(x, weight, stride):
+            y = conv3_bias_relu(x, weight, bias, stride)    # implicit GEMM on the bf16 pipe, bias + ReLU in its epilogue
+        else:
+            y = F.conv2d(x, weight, None, stride)
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            bias_relu_rows_(y, bias, y.shape[1])          # NHWC memory: (N*H*W, C) rows
         ctx.stride = stride
         ctx.save_for_backward(x, weight, y)
         return y
