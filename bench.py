@@ -711,12 +711,13 @@ def main():
                 "acting_overlapped_on_second_stream": res["overlap"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2),
-                "f32_products_on": ("bf16 matrix pipe for the wide GEMMs (6 exact-split bf16 MFMAs per f32 product block, "
-                                    "csrc/gemm3.hip) and the input layer's forward (uint8 pixels are exact bf16, weights split "
+                "f32_products_on": ("bf16 matrix pipe for the wide GEMMs and conv layers 2-3 forward (6 exact-split bf16 MFMAs per f32 product "
+                                    "block, csrc/gemm3.hip, conv3.hip) and the input layer's forward (uint8 pixels are exact bf16, weights split "
                                     "three ways, csrc/conv_in.hip); f32 accumulation, results within the library f32 GEMM's own "
                                     "distance from float64 (tests/test_gemm3_gpu.py, DESIGN 3.6); everything else f32 pipe"
-                                    if (os.environ.get("MIRL_GEMM3", "1") != "0" or os.environ.get("MIRL_CONV1_BF16", "1") != "0")
-                                    else "f32 MFMA pipe only (MIRL_GEMM3=0 MIRL_CONV1_BF16=0)")},
+                                    if (os.environ.get("MIRL_GEMM3", "1") != "0" or os.environ.get("MIRL_CONV1_BF16", "1") != "0"
+                                        or os.environ.get("MIRL_CONV3", "1") != "0")
+                                    else "f32 MFMA pipe only (MIRL_GEMM3=0 MIRL_CONV1_BF16=0 MIRL_CONV3=0)")},
             "roofline": {
                 "kernel": "k_gather_rows_dedup (frames)" if args.frame_dedup else "k_gather_rows (frames)", "bound": "hbm",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

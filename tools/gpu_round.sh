@@ -150,7 +150,7 @@ print(json.dumps(res, indent=1)); json.dump(res, open(os.path.join(out, "gemm3_p
 PY
              find "$OUT" -path "*g3pmc*" -name "*.csv" -size +1M -delete; find "$OUT" -path "*g3pmc*" -name "*.db" -delete; tail -3 "$OUT"/g3pmc*.err | tail -20;;
     gemmshapes) BENCH_GEMM_SHAPES="$OUT/gemm_shapes.jsonl" timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 1 > "$OUT/bench_gemmshapes.json" 2> "$OUT/bench_gemmshapes.err"; echo "gemmshapes rc=$?"; tail -3 "$OUT/bench_gemmshapes.err"; cat "$OUT/gemm_shapes.jsonl";;
-    f32pipe) MIRL_GEMM3=0 MIRL_CONV1_BF16=0 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_f32_pipe_only.json" 2> "$OUT/bench_f32_pipe_only.err"; echo "f32pipe rc=$?"; head -c 700 "$OUT/bench_f32_pipe_only.json"; echo;;
+    f32pipe) MIRL_GEMM3=0 MIRL_CONV1_BF16=0 MIRL_CONV3=0 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_f32_pipe_only.json" 2> "$OUT/bench_f32_pipe_only.err"; echo "f32pipe rc=$?"; head -c 700 "$OUT/bench_f32_pipe_only.json"; echo;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
 done
