@@ -20,7 +20,7 @@
 // 128 accumulator registers), K in steps of 16 floats.  LDS holds two stages of six bf16 planes
 // [operand A|B][part][256 rows][16 k], 48-byte row pitch (ds_read_b128 of a 32-row fragment is conflict free),
 // 147 456 bytes: one workgroup per CU, two waves per SIMD.  Per K-step a wave issues 48 MFMAs (1 536 cycles on its
-// SIMD's matrix pipe, 3 072 for the pair) against 18 fragment reads, 2 x 16-byte global loads, ~90 VALU split ops
+// SIMD's matrix pipe, 3 072 for the pair) against 18 fragment reads, 2 x 16-byte global loads, ~100 VALU split ops
 // and 12 LDS writes; the two waves of a SIMD run the stage/compute halves of the step in opposite order so one
 // splits while the other multiplies.  Global loads for tile k+2 are in flight across the (raw) barrier.
 //
@@ -29,6 +29,14 @@
 // a weight gradient or an un-transposed weight in a data gradient).  layout 0 "NT": C = A[M][K] . B[N][K]^T (+bias,
 // ReLU); 1 "NN": C = A[M][K] . B[K][N]; 2 "TN": C = A[K][M]^T . B[K][N], K split over workgroups into
 // partial tiles that a second deterministic kernel sums.
+//
+// Epilogue: an accumulator lane owns one column of a 32 x 32 tile; each wave transposes its block through its own
+// 17 KB of the idle staging LDS and stores 16 bytes per lane (256 contiguous bytes per row) — with bias, ReLU and,
+// for the quantile layer (mirl_gemm3_nt_mul), the IQN feature product applied on those vectors.  Outputs whose
+// rows are not 16-byte aligned take a scalar-store instantiation.
+// Measured (MI355X, profiles/r03_gemm3_*): 200-226 TFLOP/s of f32 product against 142-145 for the library's f32
+// kernels; the matrix pipe is 67 % busy at a power-limited 1.67 GHz.  Opt-in experiments that measured no gain:
+// MIRL_GEMM3_PERSIST=1 (persistent workgroups), MIRL_GEMM3_ORDER=1|2 (all waves stage first / compute first).
 #include "common.hpp"
 #include "split3.hpp"
 #include <stdlib.h>
