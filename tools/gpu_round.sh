@@ -150,6 +150,31 @@ print(json.dumps(res, indent=1)); json.dump(res, open(os.path.join(out, "gemm3_p
 PY
              find "$OUT" -path "*g3pmc*" -name "*.csv" -size +1M -delete; find "$OUT" -path "*g3pmc*" -name "*.db" -delete; tail -3 "$OUT"/g3pmc*.err | tail -20;;
     gemmshapes) BENCH_GEMM_SHAPES="$OUT/gemm_shapes.jsonl" timeout 600 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --profile-steps 1 > "$OUT/bench_gemmshapes.json" 2> "$OUT/bench_gemmshapes.err"; echo "gemmshapes rc=$?"; tail -3 "$OUT/bench_gemmshapes.err"; cat "$OUT/gemm_shapes.jsonl";;
+    conv3)   timeout 300 python tools/conv3_probe.py > "$OUT/conv3_probe.jsonl" 2> "$OUT/conv3_probe.err"; echo "conv3 probe rc=$?"; cat "$OUT/conv3_probe.jsonl"; tail -3 "$OUT/conv3_probe.err"
+             R="$(pwd)"; export TMPDIR=/tmp; (cd /tmp && timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$R/$OUT/c3pmc" -o c -- python "$R/tools/conv3_probe.py" > /dev/null 2> "$R/$OUT/c3pmc.err"); echo "c3pmc rc=$?"
+             python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections, json
+out = sys.argv[1]
+res = {}
+for f in glob.glob(os.path.join(out, "c3pmc", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n_disp = collections.Counter(); seen = set(); dur = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "k_conv3_fwd" not in n and "igemm_fwd" not in n: continue
+        n = n.split("(")[0][:50] + " grid " + r.get("Grid_Size", "?")
+        acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n_disp[n] += 1; dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    for n, c in acc.items():
+        d = {k: v / n_disp[n] for k, v in c.items()}
+        d["avg_ms_under_counters"] = round(dur[n] / n_disp[n], 4); d["dispatches"] = n_disp[n]
+        if d.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_fraction"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (d["GRBM_GUI_ACTIVE"] * 128), 3)
+            d["clock_GHz"] = round(d["GRBM_GUI_ACTIVE"] / 8 / d["avg_ms_under_counters"] / 1e6, 3)
+        res[n] = d
+print(json.dumps(res, indent=1)); json.dump(res, open(os.path.join(out, "conv3_pmc.json"), "w"), indent=1)
+PY
+             find "$OUT" -path "*c3pmc*" -name "*.csv" -size +1M -delete; find "$OUT" -path "*c3pmc*" -name "*.db" -delete;;
     f32pipe) MIRL_GEMM3=0 MIRL_CONV1_BF16=0 MIRL_CONV3=0 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 > "$OUT/bench_f32_pipe_only.json" 2> "$OUT/bench_f32_pipe_only.err"; echo "f32pipe rc=$?"; head -c 700 "$OUT/bench_f32_pipe_only.json"; echo;;
     noact)   timeout 600 python bench.py --steps 20 --warmup 5 --no-acting --no-cpu-baseline > "$OUT/bench_noacting.json" 2> "$OUT/bench_noacting.err"; echo "noact rc=$?"; head -c 3000 "$OUT/bench_noacting.json";;
   esac
