@@ -42,6 +42,10 @@ def main():
         # a few scaled rows / columns so magnitudes differ across the tile
         a[:: 7] *= 37.0
         b[:: 5] *= 0.013
+        if os.environ.get("GEMM3_ZERO") == "1":        # power experiment: the same instruction stream on all-zero operands
+            a.zero_(); b.zero_()
+        elif os.environ.get("GEMM3_ZERO") == "2":      # ... and on operands with one significant bit (lo / mid parts are zero)
+            a.copy_(torch.sign(a)); b.copy_(torch.sign(b))
         ok = gemm3.supported(layout, a, b, min_work=0)
         rec = {"layout": lay, "M": M, "N": N, "K": K, "supported": ok}
         if ok:
@@ -55,7 +59,7 @@ def main():
                 ref64 = a[rows].double() @ b.double()
             else:
                 ref64 = a[rows].double() @ b.double().t()
-            scale = float(ref64.abs().max())
+            scale = float(ref64.abs().max()) or 1.0
             rec["max_err_gemm3"] = float((out[rows].double() - ref64).abs().max()) / scale
             rec["max_err_lib_f32"] = float((ref32[rows].double() - ref64).abs().max()) / scale
             rec["max_diff_vs_lib"] = float((out - ref32).abs().max()) / scale
