@@ -14,7 +14,7 @@ import bench  # noqa: E402
 
 class A:
     config, scaling, mbatch, nstep_train, burn_in, nstep_target, envs, replay_size = "iqn_lstm", "weak", None, None, None, None, None, 60000
-    train_arg, frame_dedup = [], False
+    train_arg, frame_dedup, no_acting, overlap_acting = [], False, False, "off"
 
 
 cfg = bench.build_config(A, 0, 1, "strong")
