@@ -734,7 +734,9 @@ def main():
                 "how": "%d extra steps after the timed region with a HIP event pair around every librltime_hip launch "
                        "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
                        "latency-bound kernels (tree / sampling / bookkeeping) report us per call only; the input conv layer "
-                       "(k_conv1_u8_fwd / _wrw) and the second layer's data gradient (k_conv2_bwd_data) are priced against the dense f32 MFMA peak instead" % (args.profile_steps, HBM_PEAK_GBPS),
+                       "(k_conv1_u8_fwd / _wrw) and the second layer's data gradient (k_conv2_bwd_data) are priced against the dense f32 MFMA peak instead "
+                       "(the input layer's forward now runs three exact bf16 products per term, so its figure can exceed 1); the split-bf16 "
+                       "GEMMs and conv layers 2-3 (k_gemm3_*, k_conv3_fwd) against the dense bf16 MFMA peak / 6 part products" % (args.profile_steps, HBM_PEAK_GBPS),
                 "ms_per_step_with_events": res["prof_step_ms"], "kernels": kernels} if kernels else None,
         }
         if res["rccl"] is not None:
