@@ -675,6 +675,11 @@ def main():
                 entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
                               "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
                               "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+                if row["name"] == "k_conv1_u8_fwd" and os.environ.get("MIRL_CONV1_BF16", "1") != "0":
+                    # the forward runs on the bf16 pipe: three exact bf16 products per f32 product (pixels are exact bf16)
+                    entry.update({"peak_TFLOPs": round(BF16_MFMA_PEAK_TFLOPS / 3, 1), "peak_is": "dense bf16 MFMA peak / 3 part products",
+                                  "frac_of_bf16x3_peak": round(3 * tf / BF16_MFMA_PEAK_TFLOPS, 4), "x_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 3)})
+                    entry.pop("frac_of_f32_mfma_peak", None)
             if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd") and by > 0:
                 # the split-bf16 GEMMs record their f32 flop (2 M N K) in the bytes slot; they issue six bf16 MFMAs
                 # per f32 product block, so the f32 product is priced against 2.5 PFLOP/s / 6
