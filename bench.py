@@ -95,12 +95,13 @@ def parse():
     ap.add_argument("--envs", type=int, default=None, help="envs (per GPU when weak, whole job when strong)")
     ap.add_argument("--replay-size", type=int, default=1000000, help="transitions (per GPU when weak, whole job when strong)")
     ap.add_argument("--no-acting", action="store_true", help="feed pre-generated actor output instead of running the device actor's policy forward inside the step")
-    ap.add_argument("--overlap-acting", default="auto", choices=["auto", "on", "off"],
+    ap.add_argument("--overlap-acting", default="off", choices=["auto", "on", "off"],
                     help="run the acting + ingest of iteration k+1 on a second HIP stream against iteration k's training "
                          "(MultiStepTrainer overlap_acting: the actor's weights are one learner step old, like the reference's async "
-                         "actors).  auto: on when a rank trains at most 8192 rows per step (strong scaling at >= 8 GPUs: the learner's "
-                         "kernels no longer fill the chip; measured 23.9 vs 27.4 ms per step at B=64, T=80) — a tie at B=256 and a loss "
-                         "at B=512 (138.9 vs 136.1), where it stays off")
+                         "actors).  off (default): the HEADLINE is the same algorithm at every N — the synchronous actor of "
+                         "rltime/acting/actor.py:108-147; at N > 1 the overlapped schedule is measured as the `overlapped_acting` "
+                         "sub-record when a rank trains at most 8192 rows per step (where it pays).  auto: on for such ranks "
+                         "(the round-3 headline at N = 8); on: always")
     ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,7 +116,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_config(args, rank, world, scaling):
+def build_config(args, rank, world, scaling, overlap=None):
     from rltime_amd.general.config import load_config
     from rltime_amd.general.utils import deep_dictionary_update
     from rltime_amd.parallel import shard_config
@@ -138,7 +139,9 @@ def build_config(args, rank, world, scaling):
     ta = config["training"]["args"]
     if "overlap_acting" not in targs and not args.no_acting:
         rows = int(ta.get("mbatch_size") or 0) * int(ta.get("nstep_train") or 1)
-        ta["overlap_acting"] = args.overlap_acting == "on" or (args.overlap_acting == "auto" and 0 < rows <= 8192 and ta.get("nstep_train", 1) > 1)
+        pays = 0 < rows <= 8192 and ta.get("nstep_train", 1) > 1
+        mode = args.overlap_acting if overlap is None else overlap
+        ta["overlap_acting"] = mode == "on" or (mode == "auto" and pays)
     return config
 
 
@@ -408,7 +411,26 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries exactly ONE line: rank 0's JSON record.  Everything else the ranks or the launcher print there
+    # (RCCL / gloo banners, warnings) goes to stderr so that a parser of the last stdout line cannot trip over it.
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    record = None
+    for line in proc.stdout:
+        text = line.strip()
+        is_record = False
+        if text.startswith("{") and text.endswith("}"):
+            try:
+                is_record = "metric" in json.loads(text)
+            except ValueError:
+                is_record = False
+        if is_record:
+            record = text
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if record is not None:
+        print(record, flush=True)
+    return rc
 
 
 def copy_peak(device, stream_ptr_fn):
@@ -438,14 +460,100 @@ def copy_peak(device, stream_ptr_fn):
     return best
 
 
-def run_mode(args, scaling, rank, world, device, dp, want_tables):
+# Which pipe a kernel's matrix work runs on (its `flop` is the f32-product work 2 M N K the call site states):
+#   bf16x6  six exact-split bf16 MFMAs per f32 product block (csrc/gemm3.hip, conv3.hip)  -> 2.5 PF / 6
+#   bf16x3  uint8 pixel x three-way split weight (csrc/conv_in.hip forward)                 -> 2.5 PF / 3
+#   f32     v_mfma_f32_16x16x4_f32 (input layer's weight gradient, layer 2's data gradient, LSTM sweeps)
+PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
+           "k_conv1_u8_fwd": "bf16x3", "k_conv1_u8_wrw": "f32", "k_conv2_bwd_data": "f32",
+           "k_lstm_seq_fwd": "f32", "k_lstm_seq_bwd": "f32", "k_lstm_step_fwd": "f32"}
+# launch / dependency-latency bound by construction (one workgroup of bookkeeping, one tree level per barrier, 256-row
+# acting batches, one LSTM step per launch): microseconds per call is the figure, an HBM fraction would be noise
+LATENCY_KERNELS = {"k_ingest_fused", "k_ingest_scalars", "k_plan_apply", "k_actor_pre", "k_actor_head", "k_lstm_cell_fwd", "k_lstm_cell_bwd",
+                   "k_tree_fix", "k_tree_fix(ingest)", "k_per_sample", "k_per_sample_global", "k_uniform_sample", "k_loss_stamp",
+                   "k_loss_write", "k_recalc_flagged", "k_recalc_flagged_wave", "k_gather_scalars", "k_conv1_pack_w", "k_conv2_pack_w",
+                   "k_colsum_partials", "k_episode_track", "k_acting_td", "k_dedup_depth", "k_gemm3_reduce", "k_conv1_wrw_reduce"}
+
+
+def pipe_peak_tflops(pipe):
+    if pipe == "bf16x6":
+        return BF16_MFMA_PEAK_TFLOPS / 6
+    if pipe == "bf16x3":
+        return BF16_MFMA_PEAK_TFLOPS / 3 if os.environ.get("MIRL_CONV1_BF16", "1") != "0" else F32_MFMA_PEAK_TFLOPS
+    return F32_MFMA_PEAK_TFLOPS
+
+
+def kernel_table(table, profile_steps):
+    """mirl_profile_* rows -> (roofline_all kernel entries, sum of the kernels' roofline times in ms per step).
+    Every kernel is priced by ITS bound: max(algorithmic HBM bytes / 8 TB/s, f32-product flop / its pipe's dense peak);
+    launch- / latency-bound kernels report microseconds per call only and count with a roofline time of zero."""
+    kernels, ideal_ms = [], 0.0
+    for row in sorted(table, key=lambda r: -r["total_ms"]):
+        if not row["calls"]:
+            continue
+        name = row["name"]
+        avg_us = row["total_ms"] / row["calls"] * 1e3
+        by, fl = row["algorithmic_bytes"] / row["calls"], row.get("flop", 0.0) / row["calls"]
+        entry = {"kernel": name, "launches_per_step": round(row["calls"] / profile_steps, 2),
+                 "avg_us": round(avg_us, 2), "ms_per_step": round(row["total_ms"] / profile_steps, 4)}
+        if name in LATENCY_KERNELS or (by < (1 << 20) and fl <= 0):
+            entry["bound"] = "latency"
+            kernels.append(entry)
+            continue
+        hbm_us = by / (HBM_PEAK_GBPS * 1e9) * 1e6
+        pipe = PIPE_OF.get(name)
+        mfma_us = fl / (pipe_peak_tflops(pipe) * 1e12) * 1e6 if (pipe and fl > 0) else 0.0
+        floor_us = max(hbm_us, mfma_us)
+        entry.update({"bound": "mfma" if mfma_us > hbm_us else "hbm", "roofline_us": round(floor_us, 2),
+                      "frac_of_roofline": round(floor_us / avg_us, 4) if avg_us > 0 else None,
+                      "algorithmic_bytes_per_launch": by if by > 0 else None,
+                      "achieved_GBps": round(by / (avg_us * 1e-6) / 1e9, 1) if by > 0 else None,
+                      "frac_of_hbm_peak": round(by / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if by > 0 else None})
+        if pipe and fl > 0:
+            tf = fl / (avg_us * 1e-6) / 1e12
+            entry.update({"flop_per_launch": fl, "achieved_TFLOPs": round(tf, 1), "pipe": pipe,
+                          "peak_TFLOPs": round(pipe_peak_tflops(pipe), 1), "frac_of_pipe_peak": round(tf / pipe_peak_tflops(pipe), 4),
+                          "x_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 3)})
+            if name in ("k_lstm_seq_fwd", "k_lstm_seq_bwd"):
+                entry["note"] = "MFMA + per-step exchange latency: roofline_us is the f32-MFMA time of the recurrent products alone"
+        ideal_ms += floor_us * row["calls"] / profile_steps * 1e-3
+        kernels.append(entry)
+    return kernels, ideal_ms
+
+
+def library_roofline(one_step):
+    """One extra step under the torch profiler (with_flops): the LIBRARY kernels of the step — hipBLASLt / rocBLAS GEMMs and
+    MIOpen convolutions called through aten — with the flop aten derives from their operand shapes, priced at the dense
+    f32 MFMA peak (they compute f32 products on the f32 pipe), and the device time of every kernel family that is not
+    librltime_hip.  -> dict or None when the profiler is unavailable."""
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_flops=True) as prof:
+            one_step()
+            torch.cuda.synchronize()
+        flop, dev_ms, lib_ms = 0.0, 0.0, 0.0
+        for ev in prof.key_averages():
+            t = getattr(ev, "self_device_time_total", getattr(ev, "self_cuda_time_total", 0)) / 1e3
+            dev_ms += t
+            if ev.flops:
+                flop += float(ev.flops)
+                lib_ms += t
+        return {"library_flop_per_step": flop, "library_contraction_ms": lib_ms, "aten_device_ms": dev_ms,
+                "library_roofline_ms": flop / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
+    except Exception as e:            # evidence, not the measurement: never sink the line
+        print("library roofline pass failed: %r" % (e,), file=sys.stderr)
+        return None
+
+
+
+def run_mode(args, scaling, rank, world, device, dp, want_tables, overlap=None):
     """Build the trainer for one scaling mode, pre-fill its replay shard, run W
     warm-up + K timed steps between barriers.  Returns the raw measurements."""
     import gc
     import torch.distributed as dist
     torch.manual_seed(1234 + rank)
     np.random.seed(1234 + rank)
-    config = build_config(args, rank, world, scaling)
+    config = build_config(args, rank, world, scaling, overlap)
     targs = config["training"]["args"]
     trainer = build_trainer(config, device, use_graph=not args.no_acting_graph, data_parallel=dp)
     hist = trainer.history_buffer
@@ -495,6 +603,7 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
     torch.cuda.synchronize()
     if dp is not None:
         dp.timing = []
+        dp.buckets_overlapped = 0
     if world > 1:
         dist.barrier()
     hist.profile(True)
@@ -526,8 +635,11 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
                 "allreduce_ms_per_step": float(np.sum(ar_ms)) / max(args.steps, 1) if ar_ms else None,
                 "allreduce_ms_median": float(np.median(ar_ms)) if ar_ms else None,
                 "bucket_bytes": dp.bucket_bytes,
-                "source": "HIP events around the gradient all-reduce on rank 0's stream inside the timed region; "
-                          "ranks_seen = all-reduced sum of one int per rank over the same process group"}
+                "buckets": [b["hi"] - b["lo"] for b in dp._buckets],
+                "buckets_issued_from_backward_hooks_per_step": dp.buckets_overlapped / max(args.steps, 1),
+                "source": "HIP events on rank 0's stream around the part of the gradient all-reduce that is still EXPOSED after "
+                          "the backward pass (buckets head -> LSTM -> conv go out asynchronously from autograd's post-accumulate "
+                          "hooks, rltime_amd/parallel.py); ranks_seen = all-reduced sum of one int per rank over the same group"}
 
     # ---- per-kernel pass (untimed): HIP events around every librltime_hip launch
     table, prof_step_ms = [], None
@@ -543,6 +655,8 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
         prof_step_ms = (time.perf_counter() - t1) / args.profile_steps * 1e3
         _lib.check(_lib.lib.mirl_profile_set(0))
         table = _lib.profile_table()
+
+    lib_roof = library_roofline(one_step) if (want_tables and args.profile_steps > 0) else None
 
     if want_tables and os.environ.get("BENCH_GEMM_SHAPES"):
         # one extra step under the torch profiler: every library GEMM call with its operand shapes
@@ -563,7 +677,7 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables):
     T, P, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs["mbatch_size"]
     n = targs.get("nstep_target") or targs["nstep_train"]
     res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
-               table=table, prof_step_ms=prof_step_ms, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
+               table=table, prof_step_ms=prof_step_ms, lib_roof=lib_roof, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
                hist_stats=hist_stats, fill_s=fill_s, rccl=rccl, overlap=bool(targs.get("overlap_acting")) and not args.no_acting)
     trainer.actors = real_actors
     hist.close()
@@ -617,6 +731,12 @@ def main():
     modes = [args.scaling] if args.scaling != "both" else (["strong", "weak"] if world > 1 else ["strong"])
     runs = [run_mode(args, m, rank, world, device, dp, want_tables=(i == 0)) for i, m in enumerate(modes)]
     res = runs[0]
+    # N > 1: the headline keeps the synchronous actor (same algorithm as N = 1); the overlapped schedule (actor weights
+    # one learner step stale) is measured next to it where a rank's batch is small enough for it to pay
+    overlapped = None
+    if world > 1 and args.overlap_acting == "off" and not args.no_acting and modes[0] == "strong" \
+            and 0 < res["B"] * res["T"] <= 8192 and res["T"] > 1:
+        overlapped = run_mode(args, "strong", rank, world, device, dp, want_tables=False, overlap="on")
     measured_peak = None
     if rank == 0:
         try:
@@ -646,50 +766,7 @@ def main():
                               "`tools/gpu_round.sh <tag> pmc` — NOT measured in this run"
             except Exception:
                 traffic = None
-        kernels = []
-        for row in sorted(table, key=lambda r: -r["total_ms"]):
-            if not row["calls"]:
-                continue
-            avg_us = row["total_ms"] / row["calls"] * 1e3
-            by = row["algorithmic_bytes"] / row["calls"]
-            gbps = by / (avg_us * 1e-6) / 1e9 if by > 0 else None
-            entry = {"kernel": row["name"], "launches_per_step": round(row["calls"] / args.profile_steps, 2),
-                     "avg_us": round(avg_us, 2), "ms_per_step": round(row["total_ms"] / args.profile_steps, 4),
-                     "algorithmic_bytes_per_launch": by if by > 0 else None,
-                     "achieved_GBps": round(gbps, 1) if gbps else None,
-                     "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4) if gbps else None,
-                     "bound": "hbm" if by >= 1 << 20 else "latency"}
-            if row["name"] in ("k_conv1_u8_fwd", "k_conv1_u8_wrw", "k_conv2_bwd_data") and by > 0:
-                # the hand-written conv kernels are bound by the f32 MFMA pipe, not by HBM: price them in flop.
-                # Input layer, per (4,84,84) frame: 28 224 B in + 20*20*32*4 B out (or g in); 20*20 positions x
-                # 2*256*32 flop.  Second layer's data gradient, per frame: 9*9*64*4 B of g in + 20*20*32*4 B out;
-                # 4 parity classes x 10*10 pixels x 2*256*32 flop ISSUED, of which 81*2*512*64 are the convolution's
-                # own (the rest multiplies the zero border that replaces edge masks).
-                if row["name"] == "k_conv2_bwd_data":
-                    frames = by / (81 * 64 * 4.0 + 400 * 32 * 4.0)
-                    flop, useful = frames * (400 * 2.0 * 256 * 32), frames * (81 * 2.0 * 512 * 64)
-                else:
-                    frames = by / (F + 400 * 32 * 4.0)
-                    flop = useful = frames * (400 * 2.0 * 256 * 32)
-                tf = flop / (avg_us * 1e-6) / 1e12
-                entry.update({"bound": "mfma", "flop_per_launch": flop, "achieved_TFLOPs": round(tf, 1),
-                              "useful_TFLOPs": round(useful / (avg_us * 1e-6) / 1e12, 1),
-                              "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS, "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
-                if row["name"] == "k_conv1_u8_fwd" and os.environ.get("MIRL_CONV1_BF16", "1") != "0":
-                    # the forward runs on the bf16 pipe: three exact bf16 products per f32 product (pixels are exact bf16)
-                    entry.update({"peak_TFLOPs": round(BF16_MFMA_PEAK_TFLOPS / 3, 1), "peak_is": "dense bf16 MFMA peak / 3 part products",
-                                  "frac_of_bf16x3_peak": round(3 * tf / BF16_MFMA_PEAK_TFLOPS, 4), "x_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 3)})
-                    entry.pop("frac_of_f32_mfma_peak", None)
-            if row["name"] in ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd") and by > 0:
-                # the split-bf16 GEMMs record their f32 flop (2 M N K) in the bytes slot; they issue six bf16 MFMAs
-                # per f32 product block, so the f32 product is priced against 2.5 PFLOP/s / 6
-                tf = by / (avg_us * 1e-6) / 1e12
-                entry.update({"bound": "mfma", "algorithmic_bytes_per_launch": None, "achieved_GBps": None, "frac_of_hbm_peak": None,
-                              "flop_per_launch": by, "achieved_TFLOPs": round(tf, 1), "issued_bf16_TFLOPs": round(6 * tf, 1),
-                              "peak_TFLOPs": round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "peak_is": "dense bf16 MFMA peak / 6 part products",
-                              "frac_of_bf16x6_peak": round(6 * tf / BF16_MFMA_PEAK_TFLOPS, 4),
-                              "x_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 3)})
-            kernels.append(entry)
+        kernels, ideal_ours_ms = kernel_table(table, args.profile_steps)
         head = summary(res, world, args.steps)
         mode_text = {"strong": "strong scaling: the configured batch (global B=%d), envs and replay size are whole-job values "
                                "split evenly over the ranks" % (B * world),
@@ -737,13 +814,34 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src},
             "roofline_all": {
                 "how": "%d extra steps after the timed region with a HIP event pair around every librltime_hip launch "
-                       "(mirl_profile_*); algorithmic bytes per launch as stated in DESIGN.md section 3; peak %.0f GB/s; "
-                       "latency-bound kernels (tree / sampling / bookkeeping) report us per call only; the input conv layer "
-                       "(k_conv1_u8_fwd / _wrw) and the second layer's data gradient (k_conv2_bwd_data) are priced against the dense f32 MFMA peak instead "
-                       "(the input layer's forward now runs three exact bf16 products per term, so its figure can exceed 1); the split-bf16 "
-                       "GEMMs and conv layers 2-3 (k_gemm3_*, k_conv3_fwd) against the dense bf16 MFMA peak / 6 part products" % (args.profile_steps, HBM_PEAK_GBPS),
+                       "(mirl_profile_*).  Every kernel is priced by its own bound: roofline_us = max(algorithmic HBM bytes / %.0f GB/s, "
+                       "f32-product flop / the dense peak of the pipe it runs on) and frac_of_roofline = roofline_us / avg_us; pipes: "
+                       "bf16x6 = dense bf16 MFMA peak / 6 exact-split part products (k_gemm3_*, k_conv3_fwd), bf16x3 = / 3 (input "
+                       "layer's forward: uint8 pixels are exact bf16), f32 = v_mfma_f32 peak (input layer's weight gradient, layer 2's "
+                       "data gradient, the LSTM sweeps' recurrent products).  Launch- / latency-bound kernels (bookkeeping, tree, "
+                       "sampling, 256-row acting batches, per-step LSTM cells) report microseconds per call only"
+                       % (args.profile_steps, HBM_PEAK_GBPS),
                 "ms_per_step_with_events": res["prof_step_ms"], "kernels": kernels} if kernels else None,
         }
+        if kernels:
+            # how good is the WHOLE step: the sum of every kernel's roofline time (ours from the table above, the library
+            # contractions from one torch-profiler step at the f32 MFMA peak) over the measured step time
+            lr = res["lib_roof"]
+            lib_ms = lr["library_roofline_ms"] if lr else None
+            total = ideal_ours_ms + (lib_ms or 0.0)
+            out["roofline_step"] = {
+                "roofline_ms": round(total, 3), "ms_per_step": head["ms_per_step"], "frac": round(total / head["ms_per_step"], 4),
+                "librltime_hip_roofline_ms": round(ideal_ours_ms, 3),
+                "librltime_hip_measured_ms": round(sum(k["ms_per_step"] for k in kernels), 3),
+                "library_contractions_roofline_ms": round(lib_ms, 3) if lib_ms is not None else None,
+                "library_contractions_measured_ms": round(lr["library_contraction_ms"], 3) if lr else None,
+                "library_flop_per_step": lr["library_flop_per_step"] if lr else None,
+                "all_aten_kernels_measured_ms": round(lr["aten_device_ms"], 3) if lr else None,
+                "how": "sum over the step's kernels of max(algorithmic bytes / 8 TB/s, flop / pipe peak): librltime_hip kernels from "
+                       "roofline_all (latency-bound ones count 0), hipBLASLt / MIOpen contractions from one extra step under "
+                       "torch.profiler(with_flops) priced at the dense f32 MFMA peak (157.3 TFLOP/s); elementwise / copy kernels of "
+                       "PyTorch and the runtime count 0 (pure overhead); divided by the timed ms_per_step"}
+
         if res["rccl"] is not None:
             out["rccl"] = res["rccl"]
         for other in runs[1:]:
@@ -752,6 +850,13 @@ def main():
             if other["rccl"] is not None:
                 sub["rccl"] = other["rccl"]
             out[other["scaling"]] = sub
+        if overlapped is not None:
+            sub = summary(overlapped, world, args.steps)
+            sub["workload"] = mode_text["strong"] + "; acting + ingest of iteration k+1 on a second HIP stream against iteration k's " \
+                              "training (actor weights one learner step stale, like the reference's async actors) — NOT the headline"
+            if overlapped["rccl"] is not None:
+                sub["rccl"] = overlapped["rccl"]
+            out["overlapped_acting"] = sub
         if args.config == "iqn_lstm":
             out["config"]["lstm_state"] = "2x512 f32 per transition"
         if world == 1 and not args.no_cpu_baseline and args.config == "iqn_lstm":

@@ -280,6 +280,9 @@ int mirl_profile_collect(int32_t* n_kernels);
 int mirl_profile_get(int32_t i, char* name_host, int32_t name_cap, int64_t* calls,
                      double* total_ms, double* algorithmic_bytes);
 int mirl_profile_reset(void);
+/* matrix-pipe work (flop, summed over the entry's launches) the call sites state next to the bytes: 2 M N K of a
+ * GEMM / implicit GEMM, the recurrent products of an LSTM sweep; 0 for streaming and latency kernels.          */
+int mirl_profile_get_flop(int32_t i, double* flop);
 
 /* ---- introspection / test hooks (host results; these DO synchronise) ------- */
 int mirl_replay_stats(mirl_replay* h, int64_t* total_items, int64_t* active_sequences,
@@ -418,6 +421,9 @@ int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* 
  * anything else returns MIRL_ERR_ARG and the caller keeps the generic path
  * (mirl_frames_to_f32_nhwc + library convolution).                              */
 int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t F, int32_t K, int32_t S);
+/* process-wide choice of the forward's matrix pipe: 1 = bf16 (exact split), 0 = f32 MFMA, < 0 = back to the
+ * MIRL_CONV1_BF16 environment default.  For in-process A/B runs (tests/test_network_ab_gpu.py).              */
+int mirl_conv1_bf16_set(int32_t mode);
 int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
                       int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
                       float scale, float* wpk, float* y, void* stream);

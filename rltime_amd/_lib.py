@@ -124,6 +124,7 @@ _SIGNATURES = {
     "mirl_profile_set": [_i32],
     "mirl_profile_collect": [_P(_i32)],
     "mirl_profile_get": [_i32, C.c_char_p, _i32, _P(_i64), _P(_f64), _P(_f64)],
+    "mirl_profile_get_flop": [_i32, _vp],
     "mirl_profile_reset": [],
     "mirl_replay_save": [_vp, C.c_char_p],
     "mirl_replay_load": [_vp, C.c_char_p],
@@ -157,6 +158,7 @@ _SIGNATURES = {
     "mirl_frames_to_f32_nhwc": [_i64, _i32, _i32, _vp, C.c_float, _vp, _vp],
     "mirl_frames_to_f32_nhwc_ex": [_i64, _i32, _i32, _vp, C.c_float, _vp, _i32, _i32, _vp],
     "mirl_conv1_u8_supported": [_i32, _i32, _i32, _i32, _i32, _i32],
+    "mirl_conv1_bf16_set": [_i32],
     "mirl_conv1_u8_fwd": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, C.c_float, _vp, _vp, _vp],
     "mirl_conv1_u8_fwd_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, C.c_float, _vp, _vp, _i32, _vp],
     "mirl_conv1_u8_wrw_scratch_floats": [_P(_i64)],
@@ -241,8 +243,10 @@ def profile_table():
         name = C.create_string_buffer(96)
         calls, ms, by = C.c_int64(), C.c_double(), C.c_double()
         check(lib.mirl_profile_get(i, name, 96, C.byref(calls), C.byref(ms), C.byref(by)), "mirl_profile_get")
+        fl = C.c_double()
+        check(lib.mirl_profile_get_flop(i, C.byref(fl)), "mirl_profile_get_flop")
         out.append({"name": name.value.decode(), "calls": calls.value, "total_ms": ms.value,
-                    "algorithmic_bytes": by.value})
+                    "algorithmic_bytes": by.value, "flop": fl.value})
     return out
 
 

@@ -168,9 +168,14 @@ class Actor(ActingInterface):
         self._graphed = None                   # the acting graph is re-captured from this state
         self._fast_restore = state.get("fast")
         self._tracker_restore = state.get("tracker")
-        if self._fast:
+        if self._fast and self._fast_restore is not None:
             self._fast.set_state(self._fast_restore)
             self._fast_restore = None
+        elif self._fast_restore is None and any(pair is not None for pair in state["carry"]):
+            # a checkpoint written by the generic device path carries no fused-step buffers: the fused step cannot
+            # continue from it (its carry / last observation live in its own static buffers) — this run takes the
+            # generic path, which continues from `carry` / `last_state`
+            self._fast = False
         if self._tracker is not None and self._tracker_restore is not None:
             self._tracker.set_state(self._tracker_restore)
             self._tracker_restore = None
@@ -275,13 +280,15 @@ class Actor(ActingInterface):
             if sink._h is None:
                 pf = self._action_space.n if sink._keep_policy else 0
                 sink.configure(fs.example, self._num_envs, self._base_env_id, policy_f32=pf)
-                if getattr(sink, "_dedup", False) and fs.trusted_stack:
+                if getattr(sink, "_dedup", False) and fs.trusted_stack and not getattr(sink, "_acting_priority_init", False):
                     sink.prime_stack(self._reset_obs)
             keep_policy = bool(sink._policy_f32)
         out = None
         for _ in range(iters):
             obs, rewards, dones, stats = self._vec_env.step_device(fs.actions)
-            assert stats is None, "the fused acting step keeps the episode statistics on the device"
+            if stats is not None:
+                raise RuntimeError("the fused acting step keeps the episode statistics on the device; this env returns "
+                                   "host episode stats (set actor.fast_step = False for it)")
             fields = fs.step(obs, rewards, dones, sink=sink, keep_policy=keep_policy, clip=self.clip_rewards and sink is not None)
             if sink is None:
                 if out is None:

@@ -266,7 +266,9 @@ class FastActingStep:
         if sink is not None:
             sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
                               policy=self.qvalues if keep_policy else None, transient=True,
-                              newest_plane_only=bool(getattr(sink, "_dedup", False)) and self.trusted_stack)
+                              # acting-time priority init reads whole stored stacks through the verifying ingest
+                              newest_plane_only=(bool(getattr(sink, "_dedup", False)) and self.trusted_stack
+                                                 and not getattr(sink, "_acting_priority_init", False)))
         else:
             fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
                           policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)

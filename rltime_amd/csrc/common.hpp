@@ -87,7 +87,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // (DESIGN.md section 3), so that bench.py can print achieved GB/s per kernel
 // against the HBM roofline.  Event pairs are resolved by mirl_profile_collect()
 // (which synchronises); nothing in the hot path waits.
-struct ProfEntry { std::string name; int64_t calls = 0; double ms = 0.0, bytes = 0.0; };
+struct ProfEntry { std::string name; int64_t calls = 0; double ms = 0.0, bytes = 0.0, flop = 0.0; };
 class Profiler {
  public:
   int level = 0;
@@ -119,11 +119,13 @@ Profiler& profiler();
 
 struct ProfScope {
   int idx = -1; hipEvent_t a = nullptr; hipStream_t st;
-  ProfScope(const char* name, double bytes, hipStream_t s) : st(s) {
+  // bytes: ALGORITHMIC HBM bytes of the launch; flop: its matrix-pipe work (0 for streaming / latency kernels)
+  ProfScope(const char* name, double bytes, hipStream_t s, double flop = 0.0) : st(s) {
     Profiler& p = profiler();
     if (p.level < 2) return;
     idx = p.index_of(name);
     p.entries[(size_t)idx].bytes += bytes;
+    p.entries[(size_t)idx].flop += flop;
     a = p.get();
     (void)hipEventRecord(a, st);
   }

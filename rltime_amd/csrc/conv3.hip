@@ -198,7 +198,7 @@ extern "C" int mirl_conv3_fwd(int64_t N, int32_t H, int32_t W, int32_t C, int32_
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) { MIRL_HIP(hipFuncSetAttribute((const void*)k_conv3_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS)); attr = true; }
-  ProfScope ps("k_conv3_fwd", 2.0 * (double)M * F * g.K, st);      // "bytes" slot carries flop here
+  ProfScope ps("k_conv3_fwd", 4.0 * ((double)N * H * W * C + (double)M * F + (double)F * g.K), st, 2.0 * (double)M * F * g.K);
   hipLaunchKernelGGL(k_conv3_fwd, dim3((unsigned)((M + 255) / 256)), dim3(512), C3_LDS, st, g);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;

@@ -498,6 +498,12 @@ static int c1_pitch(int HW) {
 
 }  // namespace mirl
 
+static int g_conv1_bf16 = -1;      // -1: MIRL_CONV1_BF16 (default on); 0 / 1: set by mirl_conv1_bf16_set (in-process A/B tests)
+extern "C" int mirl_conv1_bf16_set(int32_t mode) {
+  g_conv1_bf16 = mode < 0 ? -1 : (mode ? 1 : 0);
+  return MIRL_OK;
+}
+
 extern "C" int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t F, int32_t K, int32_t S) {
   using namespace mirl;
   if (C != C1_PLANES || F != C1_F || K != C1_K || S != C1_S) return 0;
@@ -521,7 +527,8 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   hipStream_t st = (hipStream_t)stream;
   const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
   const int tiles = (OH * OW + 15) / 16;
-  static const int bf_env = getenv("MIRL_CONV1_BF16") ? atoi(getenv("MIRL_CONV1_BF16")) : 1;
+  static const int bf_env0 = getenv("MIRL_CONV1_BF16") ? atoi(getenv("MIRL_CONV1_BF16")) : 1;
+  const int bf_env = g_conv1_bf16 >= 0 ? g_conv1_bf16 : bf_env0;
   const int dbg0 = (flags >> 24) & 7;
   const bool bf = bf_env && !dbg0 && !(flags & 32) && !(flags & 4);      // bit 5: force the f32-MFMA kernel (probe / A-B)
   if (!(flags & 8)) {                                     // bit 3: wpk already holds these weights packed (acting steps between updates)
@@ -540,7 +547,8 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   const int64_t units = (N + fpi - 1) / fpi * split;
   const unsigned grid = (unsigned)(units < 512 ? units : 512);
   const size_t lds = (size_t)fpi * C1_PLANES * pitch + (bf ? 16 * 1024 : 0);
-  ProfScope ps("k_conv1_u8_fwd", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
+  ProfScope ps("k_conv1_u8_fwd", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st,
+               (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
   const bool nts = !(flags & 1);
   if (bf) {
     const uint4* w3 = (const uint4*)wpk;
@@ -618,7 +626,8 @@ extern "C" int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8
   if (lds < (size_t)C1_DW * 4) lds = (size_t)C1_DW * 4;          // the workgroup's 32 KB partial is reduced there
   const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
   {
-    ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st);
+    ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st,
+                 (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
 #define C1_WLAUNCH(FPI_, WC_, PC_) \
   hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch)
     const bool atari = W == 84 && pitch == 7232;

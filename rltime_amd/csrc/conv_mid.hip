@@ -156,7 +156,10 @@ extern "C" int mirl_conv2_bwd_data(int64_t N, int32_t OH, int32_t OW, const floa
   const unsigned grid = (unsigned)(units < 512 ? units : 512);
   const int V = OW + 1;
   const unsigned v_magic = V > 1 ? (unsigned)(((1ULL << 32) + V - 1) / V) : 0u;
-  ProfScope ps("k_conv2_bwd_data", (double)N * ((double)OH * OW * C2_F * 4 + (double)(2 * OH + 2) * (2 * OW + 2) * C2_C * 4), st);
+  // flop: the convolution's own 2 * K*K*C*F per output position (the zero border the kernel multiplies instead of masking
+  // edges is issued work, not algorithmic work)
+  ProfScope ps("k_conv2_bwd_data", (double)N * ((double)OH * OW * C2_F * 4 + (double)(2 * OH + 2) * (2 * OW + 2) * C2_C * 4), st,
+               (double)N * OH * OW * 2.0 * C2_K * C2_K * C2_C * C2_F);
   if (fpi == 2) hipLaunchKernelGGL((k_conv2_bwd_data<2>), dim3(grid), dim3(256), c2_lds_bytes(2, OH, OW), st, (int)N, OH, OW, v_magic, g, wpk, dx);
   else          hipLaunchKernelGGL((k_conv2_bwd_data<1>), dim3(grid), dim3(256), c2_lds_bytes(1, OH, OW), st, (int)N, OH, OW, v_magic, g, wpk, dx);
   MIRL_LAUNCH_CHECK();

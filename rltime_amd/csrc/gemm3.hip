@@ -402,7 +402,10 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   if (!attr[which][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[which][vec] = true; }
   {
     const double flop = 2.0 * (double)M * (double)N * (double)K;
-    ProfScope ps(mul ? "k_gemm3_nt_mul" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", flop, st);   // "bytes" slot carries flop here
+    // HBM bytes: both operands read once, the result (and the pre-product embedding / the multiplier rows) written / read once
+    double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
+    if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N);
+    ProfScope ps(mul ? "k_gemm3_nt_mul" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }

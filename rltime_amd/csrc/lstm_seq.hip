@@ -782,7 +782,7 @@ extern "C" int mirl_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, float* gates, 
   }
   SeqBwdArgs a{T, B, gates, w_hh, c_all, cm, d_out, keep};
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps("k_lstm_seq_bwd", 4.0 * B * H * T * (8.0 + 3.0) + 4.0 * 4.0 * H * H, st);
+  ProfScope ps("k_lstm_seq_bwd", 4.0 * B * H * T * (8.0 + 3.0) + 4.0 * 4.0 * H * H, st, 2.0 * B * H * 4.0 * H * T);
   return seq_bwd_launch<512>(a, workspace, st);
 }
 
@@ -814,7 +814,7 @@ extern "C" int mirl_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, float* gx, con
   hipStream_t st = (hipStream_t)stream;
   // per step: pre-activations read (+ activated gates written), h / c outputs; HBM-side algorithmic bytes of the sweep
   const double per_step = 4.0 * B * H * (4.0 + (save_gates ? 4.0 : 0.0) + (out ? 1.0 : 0.0) + (c_all ? 1.0 : 0.0) + (hm ? 2.0 : 0.0));
-  ProfScope ps("k_lstm_seq_fwd", per_step * T + 4.0 * 4.0 * H * H, st);
+  ProfScope ps("k_lstm_seq_fwd", per_step * T + 4.0 * 4.0 * H * H, st, 2.0 * B * H * 4.0 * H * T);
   if (H == 512) return seq_launch<512>(a, workspace, st);
   if (H == 256) return seq_launch<256>(a, workspace, st);
   return seq_launch<128>(a, workspace, st);

@@ -930,6 +930,12 @@ extern "C" int mirl_profile_get(int32_t i, char* name_host, int32_t name_cap, in
   if (algorithmic_bytes) *algorithmic_bytes = e.bytes;
   return MIRL_OK;
 }
+extern "C" int mirl_profile_get_flop(int32_t i, double* flop) {
+  Profiler& p = profiler();
+  if (i < 0 || (size_t)i >= p.entries.size() || !flop) return fail(MIRL_ERR_ARG, "bad profile_get_flop arguments");
+  *flop = p.entries[(size_t)i].flop;
+  return MIRL_OK;
+}
 
 struct mirl_replay {
   Book book;
@@ -1120,6 +1126,12 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   if (K > 65535) return fail(MIRL_ERR_ARG, "at most 65535 transitions per ingest call (split the vector step)");
   if ((d.X && !in->extra) || (d.S && !in->state) || (d.has_init && !in->initials) || (d.A && !in->policy))
     return fail(MIRL_ERR_ARG, "a configured payload array is NULL");
+  // every argument check sits AHEAD of the host bookkeeping: a refused call must leave the book, the staging
+  // ring and the device rings exactly where they were
+  if (d.planes && in->newest_plane_only && (h->book.cfg.acting_priority_init && d.per))
+    return fail(MIRL_ERR_ARG, "newest_plane_only ingest cannot be combined with acting_priority_init");
+  if (d.planes && !in->newest_plane_only && (((uintptr_t)in->frames) % 16))
+    return fail(MIRL_ERR_ARG, "stack_planes: the frames array must be 16-byte aligned");
   int rc = h->book.ingest(K, in->env_ids_host, h->plan);
   if (rc) { last_error_ref() = h->book.err; return rc; }
   Plan& p = h->plan;
@@ -1139,8 +1151,6 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   const int32_t* s_env = (const int32_t*)(db + o_env);
   const int64_t* s_off = (const int64_t*)(db + o_off);
   if (g_ingest_fused < 0) g_ingest_fused = (getenv("MIRL_INGEST_FUSED") && atoi(getenv("MIRL_INGEST_FUSED")) == 0) ? 0 : 1;
-  if (d.planes && in->newest_plane_only && (h->book.cfg.acting_priority_init && d.per))
-    return fail(MIRL_ERR_ARG, "newest_plane_only ingest cannot be combined with acting_priority_init");
   if ((g_ingest_fused && !d.planes && !(h->book.cfg.acting_priority_init && d.per)) || (d.planes && in->newest_plane_only)) {
     const bool planes = d.planes != 0;
     const int64_t f_stride = in->frames_stride > 0 ? in->frames_stride : (planes ? d.plane_bytes : d.F);
@@ -1167,7 +1177,6 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   if (d.planes) {
     // de-dup: verify the stack-shift contract against the stored planes, record the
     // depth, keep the newest plane only
-    if (((uintptr_t)in->frames) % 16) return fail(MIRL_ERR_ARG, "stack_planes: the frames array must be 16-byte aligned");
     {
       ProfScope ps("k_dedup_depth", (double)K * (2.0 * d.F - d.plane_bytes), st);
       hipLaunchKernelGGL(k_dedup_depth, dim3(K), dim3(256), 0, st, d, in->frames, s_env, s_off);

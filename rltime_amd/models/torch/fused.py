@@ -32,6 +32,8 @@ from . import gemm3
 _TAIL_WGRAD = os.environ.get("MIRL_TAIL_WGRAD", "1") != "0"
 _QP_EPILOGUE = os.environ.get("MIRL_QP_EPILOGUE", "1") != "0"
 _CONV3 = os.environ.get("MIRL_CONV3", "1") != "0"
+# multiply-adds below which a conv layer's forward stays on MIOpen; MIRL_CONV3_MIN_WORK=0 forces every supported shape
+_CONV3_MIN_WORK = int(os.environ.get("MIRL_CONV3_MIN_WORK", str(1 << 31)))
 
 
 def _lib():
@@ -105,7 +107,7 @@ def linear_relu(x, weight, bias):
     return F.relu(F.linear(x, weight, bias))
 
 
-def conv3_supported(x, weight, stride, min_work=1 << 31):
+def conv3_supported(x, weight, stride, min_work=None):
     """Does the split-bf16 implicit GEMM (csrc/conv3.hip) take this NHWC conv forward?"""
     if not (_CONV3 and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
@@ -117,7 +119,7 @@ def conv3_supported(x, weight, stride, min_work=1 << 31):
     if h < kh or w < kw:
         return False
     work = n * ((h - kh) // s + 1) * ((w - kw) // s + 1) * f * c * kh * kw
-    return work >= min_work and bool(_lib().lib.mirl_conv3_fwd_supported(c, f, kh, kw, s, h, w))
+    return work >= (_CONV3_MIN_WORK if min_work is None else min_work) and bool(_lib().lib.mirl_conv3_fwd_supported(c, f, kh, kw, s, h, w))
 
 
 def conv3_bias_relu(x, weight, bias, stride, relu=True):

@@ -10,7 +10,9 @@ import os
 import torch
 
 NT, NN, TN = 0, 1, 2
-_MIN_WORK = 1 << 31        # M*N*K below this stays on the library (launch-bound anyway)
+# M*N*K below this stays on the library (launch-bound anyway).  MIRL_GEMM3_MIN_WORK=0 sends every product the
+# kernel takes through it (tests/test_e2e_gpu.py pins the reference trajectories that way).
+_MIN_WORK = int(os.environ.get("MIRL_GEMM3_MIN_WORK", str(1 << 31)))
 _ws = {}
 
 

@@ -8,11 +8,13 @@ samples its share of the batch locally and gathers locally — no frame ever
 crosses xGMI (the reference has no multi-GPU path at all).
 Exchanged per learner step:
 
-  1. gradients: ONE flat fp32 bucket that the parameters' .grad tensors are views
+  1. gradients: ONE flat fp32 buffer that the parameters' .grad tensors are views
      of (no pack / unpack copies), all-reduce(AVG) between backward and the
      clip / Adam step (the hook TorchTrainer._reduce_gradients calls).  8.1 M
-     parameters = 32.5 MB: ~0.2 ms on xGMI against a 180 ms step, so it is one
-     blocking collective rather than a bucketed overlap;
+     parameters = 32.5 MB.  With overlap (default at world > 1) the buffer is cut into
+     buckets in backward order — head, recurrent layer, conv stack — and each bucket's
+     all-reduce is issued on a side stream as soon as autograd has finished its last
+     gradient, so only the conv bucket (0.3 MB) is exposed after the backward;
   2. 3 doubles per rank — (sum of priorities, active sequences, local max raw
      weight) — exchanged (all-reduce of a zero-padded (R, 3) buffer, so the same
      code serves RCCL and gloo) to turn shard-local importance weights into the
@@ -34,6 +36,9 @@ import torch.distributed as dist
 
 STEP_FIELDS = ("total_steps", "early_stop_steps", "warmup_steps", "target_update_freq", "log_freq",
                "actor_update_frequency_steps")
+# defaults of the step-denominated trainer arguments (reference signatures: policy_trainer.py:284-286 log_freq=10000,
+# multi_step_trainer.py:152-156 actor_update_frequency_steps=1000; warmup_steps / target_update_freq default to 0 = off)
+STEP_DEFAULTS = {"log_freq": 10000, "actor_update_frequency_steps": 1000}
 
 
 def shard_config(config, rank, world, scaling="strong"):
@@ -68,9 +73,17 @@ def shard_config(config, rank, world, scaling="strong"):
         if mb:
             assert mb % world == 0, "mbatch_size must divide by the number of ranks"
             targs["mbatch_size"] = mb // world
+        # the trainers' own defaults are whole-job values too: a config that omits a key must behave like one
+        # that spells the default out (training/policy_trainer.py train(), multi_step_trainer.py _train())
+        for key, default in STEP_DEFAULTS.items():
+            targs.setdefault(key, default)
         for key in STEP_FIELDS:
             if targs.get(key):
                 targs[key] = max(1, -(-int(targs[key]) // world))
+        if rank == 0:
+            import logging
+            logging.getLogger(__name__).info("strong scaling over %d ranks: per-rank %s", world,
+                                             {k: targs.get(k) for k in STEP_FIELDS + ("mbatch_size",)})
     else:
         per = envs
         acting["total_envs"] = envs * world
@@ -90,7 +103,11 @@ class DataParallel:
         self.force = bool(os.environ.get("BENCH_FORCE_DIST")) if force is None else force
         self.host_group = host_group
         self._backend = dist.get_backend(group)
-        self.timing = None      # a list: (start, end) HIP event pairs around every gradient all-reduce (bench.py)
+        self.timing = None      # a list: (start, end) HIP event pairs around the EXPOSED part of every gradient all-reduce (bench.py)
+        # bucketed all-reduce overlapped with the backward pass (MIRL_DP_OVERLAP=0: one blocking collective)
+        self.overlap = os.environ.get("MIRL_DP_OVERLAP", "1") != "0"
+        self.buckets_overlapped = 0
+        self._buckets, self._bucket_of, self._hooks = [], {}, []
 
     @property
     def active(self):
@@ -123,23 +140,93 @@ class DataParallel:
                 else:
                     dist.broadcast(t.data, src, group=self.group)
 
-    def attach(self, module):
-        """Make every parameter's .grad a view of one flat bucket.  Autograd then
-        accumulates straight into the bucket and the all-reduce needs no copies;
-        zero_grad() must zero the bucket (TorchTrainer does) instead of dropping
-        the .grad tensors."""
+    def attach(self, module, buckets="auto"):
+        """Make every parameter's .grad a view of one flat buffer.  Autograd then
+        accumulates straight into it and the all-reduce needs no copies;
+        zero_grad() must zero the buffer (TorchTrainer does) instead of dropping
+        the .grad tensors.
+
+        buckets: the buffer is laid out in BACKWARD order (last child module first) and
+        cut into contiguous buckets; a bucket's all-reduce is issued from autograd's
+        post-accumulate hook of its last gradient, asynchronously on the process group's
+        stream, and all_reduce_gradients() only waits for what is still in flight.
+        "auto": one bucket per top-level stage of a policy — everything outside
+        `module.model` (heads, quantile layer) + the model's last layers, the recurrent
+        layer, the conv stack — i.e. head -> LSTM -> conv, the order their gradients
+        complete in; modules without a `.model.layers` get one bucket.  None / 1: the
+        single blocking all-reduce of rounds 1-3."""
         params = [p for p in module.parameters() if p.requires_grad]
+        groups = self._bucket_groups(module, params) if buckets == "auto" else None
+        if not groups or buckets in (None, 1) or not self.overlap:
+            groups = [params]
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         at = 0
-        for p in params:
-            p.grad = flat[at:at + p.numel()].view_as(p)
-            at += p.numel()
-        self._flat, self._params = flat, params
+        self._buckets, self._bucket_of, self._hooks = [], {}, []
+        for gi, group in enumerate(groups):
+            lo = at
+            for p in group:
+                p.grad = flat[at:at + p.numel()].view_as(p)
+                at += p.numel()
+                self._bucket_of[id(p)] = gi
+            self._buckets.append({"lo": lo, "hi": at, "count": len(group), "left": len(group), "work": None, "done": False})
+        assert at == n
+        self._flat, self._params = flat, [p for g in groups for p in g]
+        if len(groups) > 1:
+            for p in self._params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         return flat
+
+    @staticmethod
+    def _bucket_groups(module, params):
+        model = getattr(module, "model", None)
+        layers = getattr(model, "layers", None)
+        if layers is None or len(layers) < 2:
+            return None
+        want = {id(p) for p in params}
+        in_layer = {}
+        for i, layer in enumerate(layers):
+            for p in layer.parameters():
+                in_layer[id(p)] = i
+        rec = [i for i, layer in enumerate(layers) if getattr(layer, "is_recurrent", lambda: False)()]
+        first_rec = rec[0] if rec else len(layers) - 1
+        head, mid, front = [], [], []
+        for p in module.parameters():
+            if id(p) not in want:
+                continue
+            i = in_layer.get(id(p))
+            (head if (i is None or i > first_rec) else mid if i == first_rec else front).append(p)
+        return [g for g in (head, mid, front) if g]
 
     def zero_grad(self):
         self._flat.zero_()
+        for b in self._buckets:
+            b["left"], b["work"], b["done"] = b["count"], None, False
+
+    def _reduce_bucket(self, b, overlap):
+        view = self._flat[b["lo"]:b["hi"]]
+        if self._backend == "nccl":
+            # async: the collective runs on the process group's stream behind an event of the current one;
+            # nobody waits here — all_reduce_gradients() does, when the optimizer needs the result
+            b["work"] = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=overlap)
+        else:
+            self._all_reduce(view, dist.ReduceOp.SUM)
+            view.div_(self.world)
+        b["done"] = True
+        self.buckets_overlapped += 1 if overlap else 0
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        b = self._buckets[self._bucket_of[id(p)]]
+        b["left"] -= 1
+        # buckets go out strictly in index order (the same order on every rank): a bucket whose gradients complete
+        # before an earlier bucket's (a parameter unused this step) waits for all_reduce_gradients()
+        while True:
+            nxt = next((x for x in self._buckets if not x["done"]), None)
+            if nxt is None or nxt["left"] > 0:
+                break
+            self._reduce_bucket(nxt, overlap=True)
 
     def all_reduce_gradients(self, module=None):
         if not self.active:
@@ -153,11 +240,13 @@ class DataParallel:
         if self.timing is not None and self._flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        if self._backend == "nccl":
-            dist.all_reduce(self._flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            self._all_reduce(self._flat, dist.ReduceOp.SUM)
-            self._flat.div_(self.world)
+        for b in self._buckets:                     # whatever the hooks did not issue (in order), then the waits
+            if not b["done"]:
+                self._reduce_bucket(b, overlap=False)
+        for b in self._buckets:
+            if b["work"] is not None:
+                b["work"].wait()                    # RCCL: the CURRENT STREAM waits for the collective; the host does not
+                b["work"] = None
         if ev is not None:
             ev[1].record()
             self.timing.append(ev)

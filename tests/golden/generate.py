@@ -716,7 +716,31 @@ E2E_IQN = dict(
     seed=6)
 
 
-def run_e2e_iqn_case():
+# The same algorithm on a model whose layer shapes are the ones the round-3 HIP kernels take, so that the GPU test
+# can force EVERY hand-written product into this reference-pinned run (MIRL_GEMM3_MIN_WORK=0, MIRL_CONV3_MIN_WORK=0):
+# (4,36,36) uint8 frames -> conv 32@8x8/4 (csrc/conv_in.hip, bf16 pipe) -> 64@4x4/2 -> 64@3x3/1 (csrc/conv3.hip,
+# conv_mid.hip data gradient) -> LSTM 128 (csrc/lstm_seq.hip persistent sweeps: H in {128,256,512}, B % 16 == 0)
+# -> quantile layer 64 -> 128 (gemm3 NT with the feature product in its epilogue) -> FC 128 | value-hidden 128
+# (gemm3 NT / NN / TN).  The reference trains it on CPU like the small case.
+E2E_IQN_WIDE = dict(
+    spec=dict(seed=47, num_envs=8, frame_shape=(4, 36, 36), lstm_units=128, n_actions=6, done_prob=0.06),
+    model={"type": "sequential", "args": {"layer_configs": [
+        {"type": "cnn", "args": {"layers": [{"filters": 32, "kernel": 8, "stride": 4},
+                                            {"filters": 64, "kernel": 4, "stride": 2},
+                                            {"filters": 64, "kernel": 3, "stride": 1}]}},
+        {"type": "lstm", "args": {"num_units": 128}},
+        {"type": "fc", "args": {"fc_size": 128}}]}},
+    policy_args={"dueling": True, "cuda": False, "embedding_dim": 64, "num_sampling_quantiles": 8},
+    train=dict(total_steps=8 * 200, log_freq=10 ** 9, target_update_freq=256, clip_rewards=True,
+               double_q=True, huber_kappa=1.0, clip_grad=10.0, adam_epsilon=1e-5, gamma=0.99,
+               nstep_train=6, burn_in_timesteps=4, nstep_target=2, mbatch_size=16, lr=1e-3,
+               rnn_bootstrap=True, warmup_steps=0, vf_scale_epsilon=None,
+               history_mode={"type": "prioritized_replay",
+                             "args": {"size": 640, "train_frequency": 4, "alpha": 0.7, "beta": 0.5}}),
+    seed=8)
+
+
+def run_e2e_iqn_case(E2E_IQN=E2E_IQN, fname="e2e_iqn_lstm_per.npz"):
     import copy
     import gym
     import io
@@ -795,8 +819,8 @@ def run_e2e_iqn_case():
            "init_online": init["online"], "init_target": init["target"],
            "tau_sizes": np.array([len(t) for t in taus], dtype=np.int64),
            "taus": np.concatenate(taus).astype(np.float32)}
-    np.savez_compressed(os.path.join(HERE, "e2e_iqn_lstm_per.npz"), **out)
-    print("e2e IQN case: %d learner steps, %d tau draws (%d values), qloss[0..3]=%s" % (
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("e2e IQN case " + fname + ": %d learner steps, %d tau draws (%d values), qloss[0..3]=%s" % (
         len(series["qloss"]), len(taus), out["taus"].size, series["qloss"][:4]))
 
 
@@ -921,6 +945,7 @@ if __name__ == "__main__":
     run_model_cases()
     run_e2e_case()
     run_e2e_iqn_case()
+    run_e2e_iqn_case(E2E_IQN_WIDE, "e2e_iqn_lstm_per_wide.npz")
     run_schedule_cases()
     run_config_cases()
     run_signature_cases()

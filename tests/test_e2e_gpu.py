@@ -143,22 +143,9 @@ def test_shared_online_cnn_gives_the_same_trajectory():
     np.testing.assert_allclose(runs[0][:60], runs[1][:60], rtol=2e-4, atol=1e-6)
 
 
-def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
-    """The headline algorithm end to end: recurrent IQN (dueling, double-Q,
-    rnn_bootstrap, burn-in) + prioritized sequence replay, trained by the unmodified
-    reference on CPU (tests/golden/generate.py: run_e2e_iqn_case).  The reference
-    draws its quantile fractions with torch.rand on the CPU; the fixture holds every
-    tau tensor in call order and this run replays them through IQNPolicy.tau_source
-    (burn_in_full_forward=True: the reference's burn-in runs the whole head and so
-    consumes taus, multi_step_trainer.py:104-117).  Same tolerance as the DQN-LSTM
-    series: 2e-3 over the first 40 Adam steps of a CPU-fp32 vs GPU-fp32 trajectory."""
+def _scripted_actor(spec):
     from rltime_amd.acting.acting_interface import ActingInterface
-    from rltime_amd.general.loggers import NullLogger
     from rltime_amd.spaces import Box, Discrete
-    from rltime_amd.training.iqn import IQN
-    d = np.load(os.path.join(scenario.GOLDEN, "e2e_iqn_lstm_per.npz"))
-    cfg = json.loads(str(d["config"]))
-    spec = StreamSpec(**cfg["spec"])
 
     class ScriptedActor(ActingInterface):
         def __init__(self):
@@ -184,7 +171,17 @@ def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
                 out.extend(as_reference_samples(spec, step, empty_layers=(0, 2)))
             self.t += iters
             return out
+    return ScriptedActor()
 
+
+def _iqn_series_with_replayed_taus(fixture):
+    """Train rltime_amd's IQN on the fixture's scripted stream from the reference's initial weights, replaying the
+    reference's quantile fractions in call order -> (series, fixture arrays)."""
+    from rltime_amd.general.loggers import NullLogger
+    from rltime_amd.training.iqn import IQN
+    d = np.load(os.path.join(scenario.GOLDEN, fixture))
+    cfg = json.loads(str(d["config"]))
+    spec = StreamSpec(**cfg["spec"])
     sizes, flat = d["tau_sizes"], torch.from_numpy(d["taus"])
     cursor = {"call": 0, "at": 0}
 
@@ -198,7 +195,7 @@ def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
     random.seed(cfg["seed"]); np.random.seed(cfg["seed"]); torch.manual_seed(cfg["seed"])   # noqa: E702
     pargs = dict(cfg["policy_args"])
     pargs["cuda"] = True
-    tr = IQN(logger=NullLogger(), actors=ScriptedActor(), model_config=cfg["model"], policy_args=pargs)
+    tr = IQN(logger=NullLogger(), actors=_scripted_actor(spec), model_config=cfg["model"], policy_args=pargs)
     series = {"qloss": [], "grad_norm": []}
     orig = tr.value_log.log
 
@@ -220,8 +217,72 @@ def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
     tr.train(**args)
     assert cursor["call"] == len(sizes)                      # same number and order of tau draws
     assert len(series["qloss"]) == len(d["qloss"])
+    return series, d
+
+
+def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
+    """The headline algorithm end to end: recurrent IQN (dueling, double-Q,
+    rnn_bootstrap, burn-in) + prioritized sequence replay, trained by the unmodified
+    reference on CPU (tests/golden/generate.py: run_e2e_iqn_case).  The reference
+    draws its quantile fractions with torch.rand on the CPU; the fixture holds every
+    tau tensor in call order and this run replays them through IQNPolicy.tau_source
+    (burn_in_full_forward=True: the reference's burn-in runs the whole head and so
+    consumes taus, multi_step_trainer.py:104-117).  Same tolerance as the DQN-LSTM
+    series: 2e-3 over the first 40 Adam steps of a CPU-fp32 vs GPU-fp32 trajectory."""
+    series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per.npz")
     n = 40
     np.testing.assert_allclose(series["qloss"][:n], d["qloss"][:n], rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
     print("IQN-LSTM e2e: max rel dev over all %d steps: qloss %.2e" % (
         len(d["qloss"]), np.max(np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"]))))
+
+
+# kernels of rounds 2-3 the wide trajectory must have gone through (names as mirl_profile_* records them)
+ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd", "k_conv1_u8_fwd",
+                  "k_conv1_u8_wrw", "k_conv2_bwd_data", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
+
+
+@pytest.mark.parametrize("forced", [True, False], ids=["every-hip-kernel-forced-on", "library-products"])
+def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, monkeypatch):
+    """The reference-pinned run that EXECUTES the round-3 arithmetic: the same algorithm as above on a model whose
+    layer shapes the hand-written kernels take ((4,36,36) frames -> 32@8/4 -> 64@4/2 -> 64@3/1 -> LSTM 128 ->
+    quantile 64 -> FC 128 | value-hidden 128; B = 16 sequences, T = 6, burn-in 4), trained by the unmodified
+    reference on CPU (tests/golden/generate.py: E2E_IQN_WIDE).  forced: the work gates are lifted
+    (gemm3._MIN_WORK = fused._CONV3_MIN_WORK = 0), so the input layer (bf16 pipe), conv layers 2-3 (split-bf16
+    implicit GEMM), layer 2's data gradient, every nn.Linear product (split-bf16 NT / NN / TN, quantile product in the
+    epilogue), the dueling tail's fused backward and the persistent LSTM sweeps (forward AND backward) all run inside
+    the pinned trajectory — asserted from the per-kernel launch table.  Not forced: the same model with those
+    products on the library (MIOpen / hipBLASLt f32) — both must follow the reference equally well.
+    Bar: 2e-3 over the first 40 Adam steps (rltime/training/torch/iqn.py:54-129, multi_step_trainer.py:278-353)."""
+    from rltime_amd import _lib
+    from rltime_amd.models.torch import fused, gemm3, lstm_seq
+    if forced:
+        monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+        monkeypatch.setattr(fused, "_CONV3_MIN_WORK", 0)
+        monkeypatch.setattr(lstm_seq, "_PERSISTENT", True)
+    else:
+        monkeypatch.setattr(gemm3, "_MIN_WORK", 1 << 62)
+        monkeypatch.setattr(fused, "_CONV3_MIN_WORK", 1 << 62)
+        monkeypatch.setattr(lstm_seq, "_PERSISTENT", False)
+        _lib.check(_lib.lib.mirl_conv1_bf16_set(0))
+    _lib.check(_lib.lib.mirl_profile_reset())
+    _lib.check(_lib.lib.mirl_profile_set(2))
+    try:
+        series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per_wide.npz")
+        torch.cuda.synchronize()
+        table = {r["name"]: r["calls"] for r in _lib.profile_table()}
+    finally:
+        _lib.check(_lib.lib.mirl_profile_set(0))
+        _lib.check(_lib.lib.mirl_conv1_bf16_set(-1))
+    n = 40
+    np.testing.assert_allclose(series["qloss"][:n], d["qloss"][:n], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
+    dev = np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"])
+    print("wide IQN-LSTM e2e (%s): max rel dev of qloss over the first 40 / all %d steps: %.2e / %.2e" % (
+        "forced" if forced else "library", len(d["qloss"]), dev[:n].max(), dev.max()))
+    if forced:
+        missing = [k for k in ROUND3_KERNELS if not table.get(k)]
+        assert not missing, ("kernels that never ran inside the pinned trajectory", missing, table)
+    else:
+        ran = [k for k in ROUND3_KERNELS if table.get(k) and k.startswith(("k_gemm3", "k_conv3", "k_lstm_seq"))]
+        assert not ran, ran

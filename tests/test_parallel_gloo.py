@@ -103,3 +103,137 @@ def test_shard_config():
     assert weak[1]["acting"]["total_envs"] == 1024
     assert weak[2]["training"]["args"]["mbatch_size"] == 512
     assert weak[2]["training"]["args"]["history_mode"]["args"]["size"] == 1000000
+
+
+class _Rec(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.cell = torch.nn.Linear(6, 6)
+
+    @staticmethod
+    def is_recurrent():
+        return True
+
+    def forward(self, x):
+        return torch.tanh(self.cell(x))
+
+
+class _Front(torch.nn.Linear):
+    @staticmethod
+    def is_recurrent():
+        return False
+
+
+class _ToyPolicy(torch.nn.Module):
+    """The shape DataParallel's automatic buckets look for: policy.model.layers = [front, recurrent, last] + heads."""
+
+    def __init__(self):
+        super().__init__()
+        self.model = torch.nn.Module()
+        self.model.layers = torch.nn.ModuleList([_Front(5, 6), _Rec(), _Front(6, 4)])
+        self.out_layer = torch.nn.Linear(4, 3)
+        self.unused = torch.nn.Linear(2, 2)            # never takes part in the loss: its bucket cannot complete by hooks
+
+    def forward(self, x, use_head=True):
+        for layer in self.model.layers:
+            x = layer(x)
+        return self.out_layer(x) if use_head else x
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rltime_amd.parallel import DataParallel
+    dp = DataParallel()
+    torch.manual_seed(3)
+    net = _ToyPolicy()
+    dp.broadcast_parameters(net)
+    flat = dp.attach(net)
+    spans = [(b["lo"], b["hi"], b["count"]) for b in dp._buckets]
+    names = {id(p): n for n, p in net.named_parameters()}
+    order = [names[id(p)] for p in dp._params]
+    g = torch.Generator().manual_seed(50 + rank)
+    res = []
+    for step, use_head in enumerate((True, True, False)):       # third pass: the head gets no gradient at all
+        x = torch.randn(9, 5, generator=g)
+        dp.zero_grad()
+        net(x, use_head).pow(2).mean().backward()
+        issued_by_hooks = [b["done"] for b in dp._buckets]
+        dp.all_reduce_gradients(net)
+        res.append(dict(issued=issued_by_hooks, reduced=flat.clone()))
+        # the same gradients without any exchange, for the expected mean
+        ref = _ToyPolicy()
+        ref.load_state_dict(net.state_dict())
+        ref(x, use_head).pow(2).mean().backward()
+        local = torch.cat([(dict(ref.named_parameters())[n].grad if dict(ref.named_parameters())[n].grad is not None
+                            else torch.zeros_like(dict(ref.named_parameters())[n])).reshape(-1) for n in order])
+        res[-1]["local"] = local
+    out[rank] = dict(spans=spans, order=order, res=res, overlapped=dp.buckets_overlapped)
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_all_reduce_from_backward_hooks():
+    """Three buckets in backward order (heads + last layer, recurrent layer, front), each reduced exactly once — by
+    the post-accumulate hook of its last gradient when every parameter of it (and of the buckets before it) got one,
+    by all_reduce_gradients() otherwise — and the result is the mean of the ranks' gradients, bit-identical on both."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["order"] == r1["order"]
+    order = r0["order"]
+    first_front = order.index("model.layers.0.weight")
+    first_rec = order.index("model.layers.1.cell.weight")
+    assert order.index("out_layer.weight") < first_rec < first_front          # head -> recurrent -> front
+    assert order.index("model.layers.2.weight") < first_rec                    # the model's last layer rides with the heads
+    assert len(r0["spans"]) == 3 and r0["spans"][0][0] == 0 and r0["spans"][-1][1] == len(r0["res"][0]["reduced"])
+    for step in range(3):
+        a, b = r0["res"][step], r1["res"][step]
+        assert torch.equal(a["reduced"], b["reduced"])
+        assert torch.allclose(a["reduced"], (a["local"] + b["local"]) / 2, atol=1e-7)
+        # `unused` sits in the head bucket: that bucket never completes by hooks, so nothing may go out early
+        # (buckets are issued strictly in order) and all_reduce_gradients() reduces all three
+        assert a["issued"] == [False, False, False]
+    assert r0["overlapped"] == 0
+
+
+def _bucket_worker_all_used(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rltime_amd.parallel import DataParallel
+    dp = DataParallel()
+    torch.manual_seed(4)
+    net = _ToyPolicy()
+    del net.unused
+    dp.broadcast_parameters(net)
+    flat = dp.attach(net)
+    x = torch.randn(9, 5, generator=torch.Generator().manual_seed(60 + rank))
+    dp.zero_grad()
+    net(x).pow(2).mean().backward()
+    issued = [b["done"] for b in dp._buckets]
+    dp.all_reduce_gradients(net)
+    names = {id(p): n for n, p in net.named_parameters()}
+    ref = _ToyPolicy()
+    del ref.unused
+    ref.load_state_dict(net.state_dict())
+    ref(x).pow(2).mean().backward()
+    grads = dict(ref.named_parameters())
+    local = torch.cat([grads[names[id(p)]].grad.reshape(-1) for p in dp._params])
+    out[rank] = dict(issued=issued, reduced=flat.clone(), overlapped=dp.buckets_overlapped, local=local)
+    dist.destroy_process_group()
+
+
+def test_every_bucket_goes_out_from_the_hooks_when_all_parameters_get_gradients():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker_all_used, args=(world, port, out), nprocs=world, join=True)
+    assert out[0]["issued"] == out[1]["issued"] == [True, True, True]
+    assert out[0]["overlapped"] == 3
+    assert torch.equal(out[0]["reduced"], out[1]["reduced"])
+    assert torch.allclose(out[0]["reduced"], (out[0]["local"] + out[1]["local"]) / 2, atol=1e-7)
