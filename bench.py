@@ -522,28 +522,39 @@ def kernel_table(table, profile_steps):
 
 
 def library_roofline(one_step):
-    """One extra step under the torch profiler (with_flops): the LIBRARY kernels of the step — hipBLASLt / rocBLAS GEMMs and
-    MIOpen convolutions called through aten — with the flop aten derives from their operand shapes, priced at the dense
-    f32 MFMA peak (they compute f32 products on the f32 pipe), and the device time of every kernel family that is not
-    librltime_hip.  -> dict or None when the profiler is unavailable."""
+    """One extra step under the torch profiler: the LIBRARY contractions of the step — hipBLASLt / rocBLAS GEMMs and MIOpen
+    convolutions called through aten — with their flop (aten's own count for mm / addmm / conv2d; 2 x MACs per requested
+    gradient for aten::convolution_backward from its operand shapes and output mask), priced at the dense f32 MFMA peak
+    (they compute f32 products on the f32 pipe), and the device time of every kernel that is not librltime_hip.
+    -> dict or None when the profiler is unavailable."""
     try:
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_flops=True) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_flops=True, record_shapes=True) as prof:
             one_step()
             torch.cuda.synchronize()
-        flop, dev_ms, lib_ms = 0.0, 0.0, 0.0
-        for ev in prof.key_averages():
-            t = getattr(ev, "self_device_time_total", getattr(ev, "self_cuda_time_total", 0)) / 1e3
-            dev_ms += t
+        flop = 0.0
+        for ev in prof.events():
             if ev.flops:
                 flop += float(ev.flops)
+            elif ev.name == "aten::convolution_backward" and len(ev.input_shapes) >= 3:
+                go, _, w = ev.input_shapes[:3]
+                mask = (getattr(ev, "concrete_inputs", None) or [None])[-1]
+                wanted = sum(1 for m in mask[:2] if m) if isinstance(mask, (list, tuple)) and len(mask) >= 2 else 2
+                if len(go) == 4 and len(w) == 4:
+                    flop += 2.0 * go[0] * go[1] * go[2] * go[3] * w[1] * w[2] * w[3] * wanted
+        dev_ms, lib_ms = 0.0, 0.0
+        for ev in prof.key_averages():
+            if "CPU" not in str(getattr(ev, "device_type", "CPU")):
+                continue                  # device-side rows repeat the time their launching op already carries
+            t = getattr(ev, "self_device_time_total", getattr(ev, "self_cuda_time_total", 0)) / 1e3
+            dev_ms += t
+            if "mm" in ev.key or "convolution" in ev.key or "conv2d" in ev.key:
                 lib_ms += t
         return {"library_flop_per_step": flop, "library_contraction_ms": lib_ms, "aten_device_ms": dev_ms,
                 "library_roofline_ms": flop / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
     except Exception as e:            # evidence, not the measurement: never sink the line
         print("library roofline pass failed: %r" % (e,), file=sys.stderr)
         return None
-
 
 
 def run_mode(args, scaling, rank, world, device, dp, want_tables, overlap=None):

@@ -159,6 +159,22 @@ int mirl_replay_destroy(mirl_replay* h);
  * per-env split of Actor.get_samples (actor.py:132-145), as one batched
  * device write per vector step.                                               */
 int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream);
+/* The same History.update, split so that a WHOLE acting rollout (actor.py:97-149: `iters` vector steps of env
+ * step -> policy forward -> History.update) can be captured into one HIP graph: everything History.update decides on
+ * the host is data-independent (ring heads, global-FIFO eviction, sequence activation / deactivation, free list), so
+ *   mirl_replay_ingest_plan     advances the host bookkeeping by `steps` vector steps of `count` transitions
+ *                               (env_ids_host as in mirl_ingest; NULL = env_base .. env_base + count - 1) and copies
+ *                               their op lists, stream-ordered, into the shard's rollout-plan buffer (device address
+ *                               fixed for the shard's lifetime; sized at the first call for max(steps, 64) steps —
+ *                               later calls with more steps return MIRL_ERR_ARG);
+ *   mirl_replay_ingest_planned  enqueues the device side of step `step` of the CURRENT plan (frames / state / scalars
+ *                               into the rings, table / env / leaf ops, tree fix: one launch).  Its arguments do not
+ *                               change from rollout to rollout, so the call can sit in a captured graph; `in->count`
+ *                               must equal the plan's, env_ids_host / newest_plane_only are ignored / refused.
+ * Shards with de-duplicated frame storage or acting_priority_init return MIRL_ERR_ARG (they need the multi-kernel
+ * ingest); callers keep mirl_replay_ingest for those.                                                                */
+int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t count, const int32_t* env_ids_host, void* stream);
+int mirl_replay_ingest_planned(mirl_replay* h, int32_t step, const mirl_ingest* in, void* stream);
 
 /* De-duplicated storage fed in the newest-plane form (mirl_ingest.newest_plane_only): the stack of an
  * env's FIRST transition reaches back to the observation its reset returned, which is not a
@@ -610,12 +626,23 @@ int mirl_stack_shift(int32_t E, int32_t P, int32_t plane_bytes, const uint8_t* i
  * [features | h_in] input), c_in = c * (1 - done), state_pack [E][2H] = [h_in | c_in] and
  * initials = done (the transition's stored recurrent state), rewards_out (clipped when
  * clip_rewards), dones_out (uint8), the mirl_episode_track accumulators (optional) and
- * *rng_step = step.                                                                    */
+ * *rng_step = step — or, with step = MIRL_STEP_ADVANCE, *rng_step + 1: the counter then lives on
+ * the device alone and the call can be replayed from a captured graph.                     */
+#define MIRL_STEP_ADVANCE (~0ull)
 int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, const uint8_t* dones,
                    const int32_t* actions, const float* h, const float* c, float* xh_tail, int64_t xh_pitch,
                    float* c_in, float* state_pack, float* initials, float* rewards_out, uint8_t* dones_out,
                    int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
                    int32_t* action_counts, uint64_t* rng_step, uint64_t step, void* stream);
+/* One step of the synthetic Atari-shaped vector env of the benchmark (i.i.d. uint8 frames from a
+ * pre-generated pool, rewards in {-1, 0, 1}, done with a fixed probability) decided entirely on the device:
+ * step t = clock[0] + 1, obs [E][frame_bytes] <- pool[t % pool_n] (pool [pool_n][E][frame_bytes]), reward / done from one
+ * Philox4x32-10 block per (seed, t, env) with cumulative reward probabilities p_neg <= p_nonpos; the launch's last
+ * workgroup stores clock[0] = t.  `clock` is a 16-byte aligned, zero-initialised block of two 64-bit words (step
+ * counter, arrival counter).  No host-side state: capturable into a rollout graph.                                  */
+int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock,
+                        uint64_t seed, float p_neg, float p_nonpos, float p_done, uint8_t* obs, float* rewards,
+                        uint8_t* dones, void* stream);
 int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,
                        const int32_t* actions, float* ep_reward, int32_t* ep_len,
                        float* out_reward, int32_t* out_len, int32_t* action_counts, void* stream);

@@ -112,6 +112,8 @@ _SIGNATURES = {
     "mirl_replay_create": [_P(ReplayConfig), _P(_vp)],
     "mirl_replay_destroy": [_vp],
     "mirl_replay_ingest": [_vp, _P(Ingest), _vp],
+    "mirl_replay_ingest_plan": [_vp, _i32, _i32, _vp, _vp],
+    "mirl_replay_ingest_planned": [_vp, _i32, _P(Ingest), _vp],
     "mirl_ingest_fused_set": [_i32],
     "mirl_replay_prime_stack": [_vp, _vp, _i64, _vp],
     "mirl_replay_needed_feed_count": [_vp, _i32, _i32, _P(_i64)],
@@ -184,6 +186,7 @@ _SIGNATURES = {
     "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_stack_shift": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "mirl_synth_env_step": [_i32, _i64, _vp, _i32, _vp, _u64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp],
     "mirl_actor_pre": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                        _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -10,7 +10,7 @@ import torch
 
 from .acting_interface import ActingInterface, DeviceSamples
 from rltime_amd.general.type_registry import get_registered_type
-from rltime_amd.general.utils import deep_apply
+from rltime_amd.general.utils import deep_apply, quiet_gc
 
 
 class GraphedStep:
@@ -67,11 +67,11 @@ class GraphedStep:
         self.graph_a = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events concurrently in multi-GPU
         # runs; it must not invalidate this thread's capture
-        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+        with quiet_gc(), torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             self.states, self.fields = head()
             self.next_actions, self.next_q = tail(self.states)
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
+        with quiet_gc(), torch.cuda.graph(self.graph_b, pool=self.graph_a.pool(), capture_error_mode="thread_local"):
             self.b_actions, self.b_q = tail(self.states)
 
     def after_env_step(self, obs, dones, eps):
@@ -284,8 +284,16 @@ class Actor(ActingInterface):
                     sink.prime_stack(self._reset_obs)
             keep_policy = bool(sink._policy_f32)
         out = None
+        if fs.can_rollout(iters, sink) and fs.rollout(iters, sink, keep_policy=keep_policy, clip=self.clip_rewards):
+            # the whole call — env steps, pre-step kernels, ingests, forwards — went out as ONE captured graph
+            self._tracker.flush()
+            return IngestedSamples(iters * self._num_envs, self._tracker)
         for _ in range(iters):
-            obs, rewards, dones, stats = self._vec_env.step_device(fs.actions)
+            if fs.env_into:
+                obs, rewards, dones = fs.env_step()
+                stats = None
+            else:
+                obs, rewards, dones, stats = self._vec_env.step_device(fs.actions)
             if stats is not None:
                 raise RuntimeError("the fused acting step keeps the episode statistics on the device; this env returns "
                                    "host episode stats (set actor.fast_step = False for it)")

@@ -52,6 +52,17 @@ class EpisodeTracker:
         self.row += 1
         return r
 
+    def begin_rollout(self, n):
+        """Rows 0 .. n-1 of the ring for the next n vector steps — the SAME rows for every rollout, so that a captured
+        graph of the rollout can hold their addresses.  Everything written so far is handed to a copy first (stream
+        order keeps that copy ahead of the rollout's writes)."""
+        assert 0 < n <= self.ROWS
+        self.flush()
+        self.row = self.flushed = 0
+
+    def end_rollout(self, n):
+        self.row = n
+
     def get_state(self):
         return {"ep_reward": self.ep_reward.cpu(), "ep_len": self.ep_len.cpu()}
 

@@ -21,14 +21,24 @@ weight concatenations, rand / randint, fills).  Here one step is
 Everything that only depends on the weights (b_ih + b_hh, [W_ih | W_hh], the joint
 [last FC | dueling value-hidden] weights) is rebuilt once per get_samples call
 (`refresh`) into static buffers the graph reads, instead of inside every step.
+
+A whole get_samples call as ONE graph launch (`rollout`): when the env can step into static
+buffers without host state (env.step_into: the synthetic env's one-kernel step) and the replay
+can plan its host bookkeeping ahead (History.plan_ingest: everything History.update decides on
+the host is data-independent), the `iters` vector steps of a call — env step, pre-step kernel,
+ingest, input layer, network, head — are captured into a single HIP graph.  At 32 envs per rank
+(one rank of the 8-GPU job) the per-step host work (~320 us of launches against ~100 us of
+kernels) was what bounded the acting; the rollout graph leaves one plan upload and one graph
+launch per learner step.
 """
+import os
 import ctypes as C
 
 import numpy as np
 import torch
 
 from rltime_amd._lib import lib, check
-from rltime_amd.general.utils import deep_apply
+from rltime_amd.general.utils import deep_apply, quiet_gc
 from rltime_amd.models.torch.fused import conv_bias_relu, conv_u8_supported, cos_embed
 
 
@@ -150,6 +160,16 @@ class FastActingStep:
         self.trusted_stack = bool(getattr(actor._vec_env, "frame_stack", False)) and os.environ.get("MIRL_DEDUP_VERIFY", "0") != "1"
         self.tracker = None
         self.graph = None
+        # env steps that write static buffers with a fixed launch (capturable); the per-step fast path uses them too, so
+        # that the rollout graph and the per-step path see the same env stream
+        env = actor._vec_env
+        self.env_into = bool(getattr(env, "supports_step_into", lambda: False)())
+        if self.env_into:
+            self.obs_buf = torch.empty_like(obs0)
+            self.env_rewards = torch.zeros(E, **f32)
+            self.env_dones = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self._rollouts = {}              # (iters, keep_policy, clip, sink id) -> [calls so far, CUDAGraph or None]
+        self.rollout_graphs = os.environ.get("MIRL_ROLLOUT_GRAPH", "1") != "0"
         assert cell.weight_ih.shape == (4 * H, F)
         # the reference's first input state: every env starts an episode (actor.py:78-89)
         self.refresh()
@@ -180,9 +200,12 @@ class FastActingStep:
         self.eps.fill_(eps)
 
     # -- pieces ------------------------------------------------------------------------------
-    def _pre(self, rewards, dones_u8, track=True, clip=False):
+    def _pre(self, rewards, dones_u8, track=True, clip=False, row=None):
+        """row: the episode tracker's ring row (None: reserve the next one).  The step counter the in-kernel draws are
+        keyed with advances ON THE DEVICE (MIRL_STEP_ADVANCE); step_no mirrors it on the host."""
         tr = self.tracker if track else None
-        row = tr.begin_step() if tr is not None else None
+        if tr is not None and row is None:
+            row = tr.begin_step()
         self.step_no += 1
         check(lib.mirl_actor_pre(
             self.E, self.H, self.A, _p(rewards), _p(dones_u8), _p(self.actions), _p(self.h), _p(self.c),
@@ -190,7 +213,7 @@ class FastActingStep:
             _p(self.rewards), _p(self.dones), 1 if clip else 0,
             _p(tr.ep_reward) if tr is not None else None, _p(tr.ep_len) if tr is not None else None,
             _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
-            _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), self.step_no, _stream()), "mirl_actor_pre")
+            _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), 0xFFFFFFFFFFFFFFFF, _stream()), "mirl_actor_pre")
 
     def _conv1(self, obs, packed=False):
         """packed=True: self.wpk still holds the current weights (packed by the call's re-selection)."""
@@ -242,7 +265,7 @@ class FastActingStep:
                 self._body()
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with quiet_gc(), torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._body()
         self.graph = graph
         self.h.copy_(keep[0])
@@ -270,12 +293,65 @@ class FastActingStep:
                               newest_plane_only=(bool(getattr(sink, "_dedup", False)) and self.trusted_stack
                                                  and not getattr(sink, "_acting_priority_init", False)))
         else:
+            if self.env_into and obs is self.obs_buf:
+                obs = obs.clone()                 # the caller keeps it; the static block is rewritten by the next env step
             fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
                           policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)
         self.last_obs = obs
         self._conv1(obs, packed=True)
         self.graph.replay()
         return fields
+
+    def env_step(self):
+        """One env step into the static buffers (same kernel eagerly or captured)."""
+        self.actor._vec_env.step_into(self.obs_buf, self.env_rewards, self.env_dones)
+        return self.obs_buf, self.env_rewards, self.env_dones
+
+    # -- a whole get_samples call as one graph launch --------------------------------------------------
+    def can_rollout(self, iters, sink):
+        return (self.rollout_graphs and self.env_into and sink is not None and iters >= 2 and self.tracker is not None
+                and iters <= self.tracker.ROWS and getattr(sink, "supports_planned_ingest", lambda: False)())
+
+    def _rollout_body(self, iters, sink, keep_policy, clip):
+        for k in range(iters):
+            obs, rewards, dones = self.env_step()
+            self._pre(rewards, dones, clip=clip, row=k)
+            sink.ingest_planned(k, obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
+                                policy=self.qvalues if keep_policy else None)
+            self._conv1(obs, packed=True)
+            self._body()
+
+    def rollout(self, iters, sink, keep_policy=False, clip=False):
+        """`iters` vector steps after reselect(): the first call of a shape runs them eagerly (the same launches, and the
+        warm-up a capture needs), the second captures them into ONE HIP graph, every later one is a plan upload + a
+        graph launch.  Identical results either way (tests/test_fast_acting_gpu.py)."""
+        key = (iters, bool(keep_policy), bool(clip), id(sink))
+        state = self._rollouts.setdefault(key, [0, None])
+        try:
+            sink.plan_ingest(iters, self.E)      # refused calls leave the book untouched (checked before any bookkeeping)
+        except Exception as e:
+            import logging
+            logging.getLogger().warning("rollout plan refused (%s); acting per step", e)
+            self.rollout_graphs = False
+            return False
+        self.tracker.begin_rollout(iters)
+        state[0] += 1
+        if state[1] is None and state[0] >= 2:
+            keep_step = self.step_no
+            graph = torch.cuda.CUDAGraph()
+            with quiet_gc(), torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                self._rollout_body(iters, sink, keep_policy, clip)
+            self.step_no = keep_step                 # capture enqueues nothing: the counters have not moved
+            state[1] = graph
+        if state[1] is not None:
+            state[1].replay()
+            self.step_no += iters
+        else:
+            with torch.no_grad():
+                self._rollout_body(iters, sink, keep_policy, clip)
+        self.tracker.end_rollout(iters)
+        self.last_obs = self.obs_buf
+        return True
 
     # -- resume --------------------------------------------------------------------------------------
     def get_state(self):

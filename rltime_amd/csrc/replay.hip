@@ -233,10 +233,10 @@ __device__ __forceinline__ void copy_row(const uint8_t* s, uint8_t* t, int row_b
   }
 }
 
-__global__ void __launch_bounds__(1024)
-k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
-               int n_table, const TableOp* __restrict__ tops, int n_env, const EnvOp* __restrict__ eops,
-               int n_leaf, const LeafOp* __restrict__ lops) {
+__device__ __forceinline__ void
+ingest_fused_body(const Dev& d, int K, const IngestSrc& in, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
+                  int n_table, const TableOp* __restrict__ tops, int n_env, const EnvOp* __restrict__ eops,
+                  int n_leaf, const LeafOp* __restrict__ lops) {
   const int k = blockIdx.y;
   if (k < K) {
     const int64_t slot = (int64_t)s_env[k] * d.C + s_off[k] % d.C;
@@ -294,6 +294,26 @@ k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, co
     __syncthreads();
     tree_fix_body(d);
   }
+}
+
+__global__ void __launch_bounds__(1024)
+k_ingest_fused(Dev d, int K, IngestSrc in, const int32_t* __restrict__ s_env, const int64_t* __restrict__ s_off,
+               int n_table, const TableOp* __restrict__ tops, int n_env, const EnvOp* __restrict__ eops,
+               int n_leaf, const LeafOp* __restrict__ lops) {
+  ingest_fused_body(d, K, in, s_env, s_off, n_table, tops, n_env, eops, n_leaf, lops);
+}
+
+// The same launch with its op lists taken from step `step` of a ROLLOUT PLAN that already sits in device memory
+// (mirl_replay_ingest_plan): no per-step host argument, so a whole acting rollout — env, policy, ingest x the
+// quota's vector steps — can be captured into ONE HIP graph and replayed with one launch per learner step.
+struct PlanHdr { int32_t n_table, n_env, n_leaf, pad; int64_t o_env, o_off, o_tab, o_eop, o_lop; };
+
+__global__ void __launch_bounds__(1024)
+k_ingest_fused_planned(Dev d, int K, IngestSrc in, const char* __restrict__ plan, int step) {
+  const PlanHdr hd = reinterpret_cast<const PlanHdr*>(plan)[step];
+  ingest_fused_body(d, K, in, reinterpret_cast<const int32_t*>(plan + hd.o_env), reinterpret_cast<const int64_t*>(plan + hd.o_off),
+                    hd.n_table, reinterpret_cast<const TableOp*>(plan + hd.o_tab), hd.n_env, reinterpret_cast<const EnvOp*>(plan + hd.o_eop),
+                    hd.n_leaf, reinterpret_cast<const LeafOp*>(plan + hd.o_lop));
 }
 
 // full rebuild of one level (test hook mirl_replay_tree_set_leaves)
@@ -955,6 +975,9 @@ struct mirl_replay {
   int dedup_lds = 1;
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  // rollout plan (mirl_replay_ingest_plan / _planned): ONE device buffer at a fixed address — captured graphs hold it
+  char* roll_plan = nullptr; size_t roll_cap = 0; int roll_steps = 0, roll_count = 0, roll_cap_steps = 0;
+  std::vector<char> roll_host;
 };
 
 extern "C" const char* mirl_last_error(void) { return last_error_ref().c_str(); }
@@ -1114,6 +1137,20 @@ extern "C" int mirl_replay_prime_stack(mirl_replay* h, const uint8_t* newest_pla
   return MIRL_OK;
 }
 
+static IngestSrc make_ingest_src(const Dev& d, const mirl_ingest* in) {
+  const bool planes = d.planes != 0;
+  const int64_t f_stride = in->frames_stride > 0 ? in->frames_stride : (planes ? d.plane_bytes : d.F);
+  const int32_t f_row = planes ? d.plane_bytes : d.F, f_slot = planes ? d.plane_bytes : d.Fp;
+  auto vec_ok = [](const void* src, const void* dst, int64_t row_bytes, int64_t src_stride, int64_t dst_stride) {
+    return (int)(row_bytes && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0 &&
+                 ((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0);
+  };
+  return IngestSrc{in->frames, in->extra, in->state, in->policy, in->initials, in->actions, in->rewards, in->dones,
+                   vec_ok(in->frames, d.frames, f_row, f_stride, f_slot), vec_ok(in->extra, d.extra, d.X * 4, d.X * 4, d.X * 4),
+                   vec_ok(in->state, d.state, d.S * 4, d.S * 4, d.S * 4), vec_ok(in->policy, d.policy, d.A * 4, d.A * 4, d.A * 4),
+                   f_stride, f_row, f_slot};
+}
+
 static int g_ingest_fused = -1;     // -1: take MIRL_INGEST_FUSED (default on) at the first ingest
 extern "C" int mirl_ingest_fused_set(int32_t on) { g_ingest_fused = on ? 1 : 0; return MIRL_OK; }
 
@@ -1152,17 +1189,8 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
   const int64_t* s_off = (const int64_t*)(db + o_off);
   if (g_ingest_fused < 0) g_ingest_fused = (getenv("MIRL_INGEST_FUSED") && atoi(getenv("MIRL_INGEST_FUSED")) == 0) ? 0 : 1;
   if ((g_ingest_fused && !d.planes && !(h->book.cfg.acting_priority_init && d.per)) || (d.planes && in->newest_plane_only)) {
-    const bool planes = d.planes != 0;
-    const int64_t f_stride = in->frames_stride > 0 ? in->frames_stride : (planes ? d.plane_bytes : d.F);
-    const int32_t f_row = planes ? d.plane_bytes : d.F, f_slot = planes ? d.plane_bytes : d.Fp;
-    auto vec_ok = [](const void* src, const void* dst, int64_t row_bytes, int64_t src_stride, int64_t dst_stride) {
-      return (int)(row_bytes && row_bytes % 16 == 0 && src_stride % 16 == 0 && dst_stride % 16 == 0 &&
-                   ((uintptr_t)src) % 16 == 0 && ((uintptr_t)dst) % 16 == 0);
-    };
-    IngestSrc src{in->frames, in->extra, in->state, in->policy, in->initials, in->actions, in->rewards, in->dones,
-                  vec_ok(in->frames, d.frames, f_row, f_stride, f_slot), vec_ok(in->extra, d.extra, d.X * 4, d.X * 4, d.X * 4),
-                  vec_ok(in->state, d.state, d.S * 4, d.S * 4, d.S * 4), vec_ok(in->policy, d.policy, d.A * 4, d.A * 4, d.A * 4),
-                  f_stride, f_row, f_slot};
+    const IngestSrc src = make_ingest_src(d, in);
+    const int32_t f_row = src.row_bytes;
     const int nt = d.per ? (int)p.table_ops.size() : 0, ne = (int)p.env_ops.size(), nl = d.per ? (int)p.leaf_ops.size() : 0;
     // 16 KB per copy workgroup: a (4, 84, 84) frame row takes 2
     int parts = (int)((f_row + 16383) / 16384); if (parts < 1) parts = 1; if (parts > 8) parts = 8;
@@ -1226,6 +1254,90 @@ extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* s
     rc = update_losses_impl(h, K, h->td_idx, h->td_loss, st); if (rc) return rc;
   }
   return h->staging.mark(st);
+}
+
+// ---- rollout plan: the host bookkeeping of `steps` vector steps ahead of their device side ------------------
+// Everything the ingest decides on the host is data-independent (ring heads, global-FIFO eviction, sequence
+// activation / deactivation, the FIFO free list: history.py:123-176, prioritized_replay_history.py:136-172,210-230),
+// so the plans of a whole acting rollout can be made before its first kernel runs.  mirl_replay_ingest_plan advances
+// the book by `steps` vector steps of `count` transitions, packs their op lists behind a table of PlanHdr into
+// pinned memory and copies them (stream-ordered) into the shard's rollout-plan buffer, whose device address never
+// changes; mirl_replay_ingest_planned enqueues the device side of ONE of those steps with no host argument that
+// varies from rollout to rollout — the call a HIP graph of the whole rollout captures (acting/fast_step.py).
+static bool planned_ingest_ok(mirl_replay* h) {
+  if (g_ingest_fused < 0) g_ingest_fused = (getenv("MIRL_INGEST_FUSED") && atoi(getenv("MIRL_INGEST_FUSED")) == 0) ? 0 : 1;
+  return g_ingest_fused && !h->d.planes && !(h->book.cfg.acting_priority_init && h->d.per);
+}
+
+extern "C" int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t count, const int32_t* env_ids_host, void* stream) {
+  if (!h || steps <= 0 || steps > 4096 || count <= 0 || count > 65535) return fail(MIRL_ERR_ARG, "bad ingest_plan arguments");
+  if (!planned_ingest_ok(h)) return fail(MIRL_ERR_ARG, "planned ingest needs the fused ingest kernel (no de-duplicated storage, no acting_priority_init)");
+  hipStream_t st = (hipStream_t)stream;
+  const int K = count;
+  if (!h->roll_plan) {
+    // sized once (the address is baked into captured graphs): at least 64 steps, op lists bounded by 4 ops per transition
+    const int cap_steps = steps > 64 ? steps : 64;
+    const size_t per_step = align_up(sizeof(int32_t) * K, 16) + align_up(sizeof(int64_t) * K, 16) +
+                            4 * (size_t)K * (sizeof(TableOp) + sizeof(EnvOp) + sizeof(LeafOp)) + 64;
+    h->roll_cap = align_up(sizeof(PlanHdr) * (size_t)cap_steps, 256) + per_step * (size_t)cap_steps;
+    MIRL_HIP(hipMalloc((void**)&h->roll_plan, h->roll_cap));
+    h->allocs.push_back(h->roll_plan);
+    h->roll_cap_steps = cap_steps;
+  }
+  if (steps > h->roll_cap_steps) return fail(MIRL_ERR_ARG, "ingest_plan: more steps than the rollout-plan buffer was sized for");
+  std::vector<char>& buf = h->roll_host;
+  const size_t hdr_bytes = align_up(sizeof(PlanHdr) * (size_t)h->roll_cap_steps, 256);
+  buf.assign(hdr_bytes, 0);
+  auto put = [&buf](const void* src, size_t bytes) -> int64_t {
+    const size_t at = align_up(buf.size(), 16);
+    buf.resize(at + bytes);
+    if (bytes) memcpy(buf.data() + at, src, bytes);
+    return (int64_t)at;
+  };
+  for (int s = 0; s < steps; ++s) {
+    int rc = h->book.ingest(K, env_ids_host, h->plan);
+    if (rc) { last_error_ref() = h->book.err; return rc; }
+    const Plan& p = h->plan;
+    PlanHdr hd;
+    hd.n_table = h->d.per ? (int32_t)p.table_ops.size() : 0;
+    hd.n_env = (int32_t)p.env_ops.size();
+    hd.n_leaf = h->d.per ? (int32_t)p.leaf_ops.size() : 0;
+    hd.pad = 0;
+    hd.o_env = put(p.sample_env.data(), sizeof(int32_t) * K);
+    hd.o_off = put(p.sample_off.data(), sizeof(int64_t) * K);
+    hd.o_tab = put(p.table_ops.data(), sizeof(TableOp) * p.table_ops.size());
+    hd.o_eop = put(p.env_ops.data(), sizeof(EnvOp) * p.env_ops.size());
+    hd.o_lop = put(p.leaf_ops.data(), sizeof(LeafOp) * p.leaf_ops.size());
+    memcpy(buf.data() + sizeof(PlanHdr) * (size_t)s, &hd, sizeof(PlanHdr));
+  }
+  const size_t total = align_up(buf.size(), 16);
+  if (total > h->roll_cap) return fail(MIRL_ERR_STATE, "ingest_plan: the rollout's op lists exceed the plan buffer");
+  char *hb, *db;
+  int rc = h->staging.acquire(total, &hb, &db); if (rc) return rc;
+  memcpy(hb, buf.data(), buf.size());
+  rc = h->staging.upload(total, st); if (rc) return rc;
+  MIRL_HIP(hipMemcpyAsync(h->roll_plan, db, total, hipMemcpyDeviceToDevice, st));     // stream order: after the last rollout that read it
+  h->roll_steps = steps; h->roll_count = K;
+  return h->staging.mark(st);
+}
+
+extern "C" int mirl_replay_ingest_planned(mirl_replay* h, int32_t step, const mirl_ingest* in, void* stream) {
+  if (!h || !in || in->count <= 0 || step < 0) return fail(MIRL_ERR_ARG, "bad ingest_planned arguments");
+  if (!h->roll_plan || step >= h->roll_cap_steps) return fail(MIRL_ERR_STATE, "ingest_planned: no rollout plan covers this step (call mirl_replay_ingest_plan first)");
+  if (!planned_ingest_ok(h) || in->newest_plane_only) return fail(MIRL_ERR_ARG, "planned ingest needs the fused ingest kernel (no de-duplicated storage, no acting_priority_init)");
+  Dev& d = h->d;
+  const int K = in->count;
+  if (K != h->roll_count) return fail(MIRL_ERR_ARG, "ingest_planned: transition count differs from the plan's");
+  if (!in->frames || !in->actions || !in->rewards || !in->dones) return fail(MIRL_ERR_ARG, "frames/actions/rewards/dones are required");
+  if ((d.X && !in->extra) || (d.S && !in->state) || (d.has_init && !in->initials) || (d.A && !in->policy))
+    return fail(MIRL_ERR_ARG, "a configured payload array is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const IngestSrc src = make_ingest_src(d, in);
+  int parts = (int)((src.row_bytes + 16383) / 16384); if (parts < 1) parts = 1; if (parts > 8) parts = 8;
+  ProfScope ps("k_ingest_fused", 2.0 * K * ((double)src.row_bytes + 4.0 * (d.X + d.S + d.A) + 13 + (d.per ? 16 : 0)), st);
+  hipLaunchKernelGGL(k_ingest_fused_planned, dim3(parts, K + 1), dim3(1024), 0, st, d, K, src, (const char*)h->roll_plan, (int)step);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
 }
 
 extern "C" int mirl_replay_needed_feed_count(mirl_replay* h, int32_t mbatch, int32_t num_envs, int64_t* out) {

@@ -62,3 +62,24 @@ def anneal_value(base_value, progress, anneal_mode, default_target=0.0):
         return base_value
     target = default_target if anneal_mode is True else float(anneal_mode)
     return base_value + (target - base_value) * progress
+
+
+class quiet_gc:
+    """Context manager around a HIP graph capture: collect garbage BEFORE it and keep the cyclic collector off
+    while the stream is capturing.  A collection that fires inside a capture can finalise objects of earlier work
+    (HIP graphs, events, cached allocator blocks of a dead trainer) whose destructors issue HIP calls that are illegal
+    on a capturing stream — the process aborts.  torch.cuda.graph itself stopped collecting on entry (torch >= 2.4:
+    only with torch.compiler.config.force_cudagraph_gc)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False

@@ -331,6 +331,33 @@ class ReplayHistoryBuffer(History):
                 if t is not None:
                     t.record_stream(s)
 
+    # -- a whole acting rollout ahead of its device side (mirl_replay_ingest_plan / _planned) ---------------
+    def supports_planned_ingest(self):
+        """The fused one-launch ingest covers this shard (no de-duplicated storage, no acting-time priority init)."""
+        return self._h is not None and not getattr(self, "_dedup", False) and not getattr(self, "_acting_priority_init", False)
+
+    def plan_ingest(self, steps, count, env_ids=None):
+        """Host bookkeeping of `steps` vector steps of `count` transitions (history.py:123-176 and the PER hooks: all of
+        it data-independent) + one stream-ordered upload of their op lists.  The device side of step k follows with
+        ingest_planned(k, ...) — from a captured graph, if the caller wants."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32) if env_ids is not None else None
+        check(lib.mirl_replay_ingest_plan(self._h, int(steps), int(count), _lib.np_ptr(ids) if ids is not None else None,
+                                          _stream()), "mirl_replay_ingest_plan")
+
+    def ingest_planned(self, step, frames, actions, rewards, dones, extra=None, state=None, initials=None, policy=None):
+        """Device side of step `step` of the current plan: same payload contract as update_batch; the buffers must stay
+        valid (and are re-read) on every replay of a graph this call was captured into."""
+        K = int(frames.shape[0])
+        for t in (frames, actions, rewards, dones, extra, state, initials, policy):
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous()
+        assert frames.dtype == torch.uint8 and actions.dtype == torch.int32
+        assert rewards.dtype == torch.float32 and dones.dtype == torch.uint8
+        arg = _lib.Ingest(count=K, env_ids_host=None, frames=_ptr(frames), extra=_ptr(extra), state=_ptr(state),
+                          initials=_ptr(initials), actions=_ptr(actions), policy=_ptr(policy), rewards=_ptr(rewards),
+                          dones=_ptr(dones), newest_plane_only=0, frames_stride=0)
+        check(lib.mirl_replay_ingest_planned(self._h, int(step), C.byref(arg), _stream()), "mirl_replay_ingest_planned")
+
     def prime_stack(self, obs):
         """De-duplicated storage + newest-plane ingest: hand over the observation block the env's
         reset returned ((E, P, h, w) uint8) so that the first transitions' stacks can reach back to it."""

@@ -719,18 +719,20 @@ E2E_IQN = dict(
 # The same algorithm on a model whose layer shapes are the ones the round-3 HIP kernels take, so that the GPU test
 # can force EVERY hand-written product into this reference-pinned run (MIRL_GEMM3_MIN_WORK=0, MIRL_CONV3_MIN_WORK=0):
 # (4,36,36) uint8 frames -> conv 32@8x8/4 (csrc/conv_in.hip, bf16 pipe) -> 64@4x4/2 -> 64@3x3/1 (csrc/conv3.hip,
-# conv_mid.hip data gradient) -> LSTM 128 (csrc/lstm_seq.hip persistent sweeps: H in {128,256,512}, B % 16 == 0)
-# -> quantile layer 64 -> 128 (gemm3 NT with the feature product in its epilogue) -> FC 128 | value-hidden 128
-# (gemm3 NT / NN / TN).  The reference trains it on CPU like the small case.
+# conv_mid.hip data gradient) -> LSTM 512 (csrc/lstm_seq.hip persistent sweeps: H in {128,256,512}, B % 16 == 0)
+# -> quantile layer 64 -> 512 (gemm3 NT with the feature product in its epilogue) -> FC 128 | value-hidden 128
+# (gemm3 NT / NN / TN).  LSTM 512 because the persistent BACKWARD sweep exists for H = 512 only.  The reference trains
+# it on CPU like the small case; its initial weights are a seeded function of the parameter shapes.
 E2E_IQN_WIDE = dict(
-    spec=dict(seed=47, num_envs=8, frame_shape=(4, 36, 36), lstm_units=128, n_actions=6, done_prob=0.06),
+    spec=dict(seed=47, num_envs=8, frame_shape=(4, 36, 36), lstm_units=512, n_actions=6, done_prob=0.06),
     model={"type": "sequential", "args": {"layer_configs": [
         {"type": "cnn", "args": {"layers": [{"filters": 32, "kernel": 8, "stride": 4},
                                             {"filters": 64, "kernel": 4, "stride": 2},
                                             {"filters": 64, "kernel": 3, "stride": 1}]}},
-        {"type": "lstm", "args": {"num_units": 128}},
+        {"type": "lstm", "args": {"num_units": 512}},
         {"type": "fc", "args": {"fc_size": 128}}]}},
     policy_args={"dueling": True, "cuda": False, "embedding_dim": 64, "num_sampling_quantiles": 8},
+    init_seeds=(101, 202),      # online / target weights = tests/golden/streams.py seeded_weights (no blobs in the fixture)
     train=dict(total_steps=8 * 200, log_freq=10 ** 9, target_update_freq=256, clip_rewards=True,
                double_q=True, huber_kappa=1.0, clip_grad=10.0, adam_epsilon=1e-5, gamma=0.99,
                nstep_train=6, burn_in_timesteps=4, nstep_target=2, mbatch_size=16, lr=1e-3,
@@ -798,7 +800,13 @@ def run_e2e_iqn_case(E2E_IQN=E2E_IQN, fname="e2e_iqn_lstm_per.npz"):
 
     def init_and_snapshot():
         real_init()
-        for key, pol in (("online", tr.policy), ("target", tr.target_policy)):
+        seeds = E2E_IQN.get("init_seeds")
+        for i, (key, pol) in enumerate((("online", tr.policy), ("target", tr.target_policy))):
+            if seeds is not None:
+                from tests.golden.streams import seeded_weights
+                pol.load_state_dict(seeded_weights(pol.state_dict(), seeds[i]))
+                init[key] = np.zeros(0, dtype=np.uint8)
+                continue
             f = io.BytesIO()
             torch.save(pol.state_dict(), f)
             init[key] = np.frombuffer(f.getvalue(), dtype=np.uint8)

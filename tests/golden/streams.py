@@ -131,3 +131,22 @@ def scalar_kind(v):
     if isinstance(v, np.floating):
         return 2
     return 0
+
+
+def seeded_weights(state_dict, seed):
+    """Deterministic initial weights for a policy, as a pure function of (parameter names, shapes, seed): uniform in
+    +-sqrt(1 / fan_in) for matrices / filters (the reference's init_weight range, models/torch/utils.py:6-25) and
+    +-0.05 for biases (non-zero, so that every bias path matters).  The golden generator loads them into the
+    REFERENCE's policies and the GPU test into the mirror's — large models need no weight blobs in their fixture."""
+    import torch
+    out = {}
+    for i, key in enumerate(sorted(state_dict)):
+        t = state_dict[key]
+        if not t.dtype.is_floating_point or key.endswith("embedding_range"):
+            out[key] = t.clone()
+            continue
+        rng = np.random.RandomState((seed * 7919 + i * 104729) % (2 ** 31))
+        shape = tuple(t.shape)
+        bound = 0.05 if len(shape) == 1 else float(1.0 / np.sqrt(np.prod(shape[1:])))
+        out[key] = torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
+    return out

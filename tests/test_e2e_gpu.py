@@ -174,13 +174,17 @@ def _scripted_actor(spec):
     return ScriptedActor()
 
 
-def _iqn_series_with_replayed_taus(fixture):
+def _iqn_series_with_replayed_taus(fixture, channels_last=False):
     """Train rltime_amd's IQN on the fixture's scripted stream from the reference's initial weights, replaying the
-    reference's quantile fractions in call order -> (series, fixture arrays)."""
+    reference's quantile fractions in call order -> (series, fixture arrays).  channels_last: the CNN keeps NHWC
+    activations (the shipped model configs' layout, rltime_amd/configs/models/modules/nature_cnn.json; a memory layout,
+    not a change of arithmetic) — what the hand-written conv kernels take."""
     from rltime_amd.general.loggers import NullLogger
     from rltime_amd.training.iqn import IQN
     d = np.load(os.path.join(scenario.GOLDEN, fixture))
     cfg = json.loads(str(d["config"]))
+    if channels_last:
+        cfg["model"]["args"]["layer_configs"][0]["args"]["channels_last"] = True
     spec = StreamSpec(**cfg["spec"])
     sizes, flat = d["tau_sizes"], torch.from_numpy(d["taus"])
     cursor = {"call": 0, "at": 0}
@@ -208,8 +212,15 @@ def _iqn_series_with_replayed_taus(fixture):
 
     def init_from_reference():
         real_init()
-        tr.policy.load_state_dict(torch.load(io.BytesIO(d["init_online"].tobytes()), map_location="cuda"))
-        tr.target_policy.load_state_dict(torch.load(io.BytesIO(d["init_target"].tobytes()), map_location="cuda"))
+        if cfg.get("init_seeds"):
+            # large model: the generator loaded seeded weights into the reference's policies (same names and shapes)
+            from tests.golden.streams import seeded_weights
+            for pol, seed in zip((tr.policy, tr.target_policy), cfg["init_seeds"]):
+                host = {k: v.cpu() for k, v in pol.state_dict().items()}
+                pol.load_state_dict(seeded_weights(host, seed))
+        else:
+            tr.policy.load_state_dict(torch.load(io.BytesIO(d["init_online"].tobytes()), map_location="cuda"))
+            tr.target_policy.load_state_dict(torch.load(io.BytesIO(d["init_target"].tobytes()), map_location="cuda"))
         tr.policy.tau_source = tr.target_policy.tau_source = replay
     tr.init_policies = init_from_reference
     args = copy.deepcopy(cfg["train"])
@@ -242,10 +253,11 @@ ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k
                   "k_conv1_u8_wrw", "k_conv2_bwd_data", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
 
 
-@pytest.mark.parametrize("forced", [True, False], ids=["every-hip-kernel-forced-on", "library-products"])
-def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, monkeypatch):
+@pytest.mark.parametrize("forced,nhwc", [(True, True), (False, True), (False, False)],
+                         ids=["every-hip-kernel-forced-on", "library-products-nhwc", "library-products-nchw"])
+def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, nhwc, monkeypatch):
     """The reference-pinned run that EXECUTES the round-3 arithmetic: the same algorithm as above on a model whose
-    layer shapes the hand-written kernels take ((4,36,36) frames -> 32@8/4 -> 64@4/2 -> 64@3/1 -> LSTM 128 ->
+    layer shapes the hand-written kernels take ((4,36,36) frames -> 32@8/4 -> 64@4/2 -> 64@3/1 -> LSTM 512 ->
     quantile 64 -> FC 128 | value-hidden 128; B = 16 sequences, T = 6, burn-in 4), trained by the unmodified
     reference on CPU (tests/golden/generate.py: E2E_IQN_WIDE).  forced: the work gates are lifted
     (gemm3._MIN_WORK = fused._CONV3_MIN_WORK = 0), so the input layer (bf16 pipe), conv layers 2-3 (split-bf16
@@ -268,7 +280,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     _lib.check(_lib.lib.mirl_profile_reset())
     _lib.check(_lib.lib.mirl_profile_set(2))
     try:
-        series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per_wide.npz")
+        series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per_wide.npz", channels_last=nhwc)
         torch.cuda.synchronize()
         table = {r["name"]: r["calls"] for r in _lib.profile_table()}
     finally:
@@ -279,7 +291,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     np.testing.assert_allclose(series["grad_norm"][:n], d["grad_norm"][:n], rtol=2e-3, atol=1e-5)
     dev = np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"])
     print("wide IQN-LSTM e2e (%s): max rel dev of qloss over the first 40 / all %d steps: %.2e / %.2e" % (
-        "forced" if forced else "library", len(d["qloss"]), dev[:n].max(), dev.max()))
+        "forced" if forced else ("library nhwc" if nhwc else "library nchw"), len(d["qloss"]), dev[:n].max(), dev.max()))
     if forced:
         missing = [k for k in ROUND3_KERNELS if not table.get(k)]
         assert not missing, ("kernels that never ran inside the pinned trajectory", missing, table)

@@ -204,3 +204,83 @@ def test_dedup_newest_plane_ingest_equals_verified_whole_stacks(done_prob):
     for key in ("states", "target_states"):
         assert torch.equal(batches[0][key]["x"], batches[2][key]["x"]), "verified whole-stack form"
         assert torch.equal(batches[1][key]["x"], batches[2][key]["x"]), "newest-plane form"
+
+
+@pytest.mark.parametrize("kind,per", [("dqn", True), ("iqn", False), ("iqn", True)])
+def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
+    """A whole get_samples call from ONE captured HIP graph (FastActingStep.rollout: env step -> pre-step kernel ->
+    planned ingest -> input layer -> network -> head, x iters; host bookkeeping planned ahead by
+    mirl_replay_ingest_plan) against the same steps issued one by one (MIRL_ROLLOUT_GRAPH=0): the replay shard (rings,
+    scalars, priority tree, free list), a sampled batch, the episode statistics and the action histogram are
+    bit-identical — with epsilon-greedy draws and IQN quantile fractions made inside the kernels from the device-side
+    step counter.  Reference order of one step: rltime/acting/actor.py:108-147, history.py:123-176."""
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer, ReplayHistoryBuffer
+    E, calls, iters = 16, 7, 6
+    results = []
+    for mode in ("graph", "per-step"):
+        monkeypatch.setenv("MIRL_ROLLOUT_GRAPH", "1" if mode == "graph" else "0")
+        actor, pol, env = _make(kind, E, True, exploration=EXPL)
+        if kind == "iqn":
+            pol.tau_source = None                                  # quantile fractions drawn in the kernel (Philox, step counter)
+        kw = dict(size=E * 30, train_frequency=4, nstep_target=2, nstep_train=4, prefix_steps=2, gamma=0.99,
+                  device_rng=True, keep_policy_outputs=False)
+        hist = PrioritizedReplayHistoryBuffer(alpha=0.9, beta=0.6, **kw) if per else ReplayHistoryBuffer(**kw)
+        actor.set_sink(hist)
+        for c in range(calls):                                     # E * 30 slots, 42 steps per env: evictions included
+            s = actor.get_samples(E * iters)
+            assert getattr(s, "ingested", False)
+            hist.update(s)
+            if c == 3:
+                with torch.no_grad():                              # a "learner update" between calls: refresh() + reselect()
+                    for p in pol.parameters():
+                        p.mul_(1.01)
+        fs = actor._fast
+        captured = [v[1] is not None for v in fs._rollouts.values()]
+        assert (captured == [True]) if mode == "graph" else (captured == []), (mode, fs._rollouts)
+        torch.cuda.synchronize()
+        episodes = actor._tracker.drain(wait=True)
+        counts = actor._tracker.take_action_counts()
+        batch = hist.get_train_data(8, train_progress=0.5)
+        results.append((batch, hist.stats(), hist.tree_nodes() if per else None, hist.free_slots() if per else None,
+                        episodes, counts, int(fs.rng_step.item()), fs.step_no))
+        hist.close()
+    (ba, sa, ta, fa, ea, ca, ra, na), (bb, sb, tb, fb, eb, cb, rb, nb) = results
+    assert sa == sb and ea == eb and ca == cb and ra == rb == na == nb
+    assert len(ea) > 0 and sum(ca) == E * calls * iters
+    flat = lambda tree: [tree] if isinstance(tree, torch.Tensor) else [x for v in (tree.values() if isinstance(tree, dict) else tree) for x in flat(v)] if tree is not None else []   # noqa: E731
+    for x, y in zip(flat(ba), flat(bb)):
+        assert torch.equal(x, y)
+    if per:
+        assert np.array_equal(fa, fb)
+        for x, y in zip(ta, tb):
+            assert np.array_equal(x, y)
+
+
+def test_synthetic_env_steps_are_a_function_of_seed_and_step():
+    """csrc/acting.hip k_synth_env_step: the env's step counter lives on the device and advances once per launch;
+    frames cycle through the pool, rewards / dones are Philox draws of (seed, step, env) with the configured
+    probabilities; step_into (static buffers) and step_device (fresh tensors) are the same stream."""
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    E = 64
+    a = SyntheticAtariVecEnv(E, frame_shape=(4, 84, 84), seed=3, done_prob=0.1)
+    b = SyntheticAtariVecEnv(E, frame_shape=(4, 84, 84), seed=3, done_prob=0.1)
+    obs = torch.empty((E, 4, 84, 84), dtype=torch.uint8, device="cuda")
+    rew = torch.empty(E, device="cuda")
+    don = torch.empty(E, dtype=torch.uint8, device="cuda")
+    rs, ds = [], []
+    for t in range(1, 300):
+        o1, r1, d1, _ = a.step_device(None)
+        b.step_into(obs, rew, don)
+        assert torch.equal(o1, obs) and torch.equal(r1, rew) and torch.equal(d1.view(torch.uint8), don)
+        assert torch.equal(o1, a._pool[t % a._pool.shape[0]])
+        rs.append(r1.clone()); ds.append(d1.clone())          # noqa: E702
+    assert int(a._clock[0].item()) == 299 and int(a._clock[1].item()) == 0
+    r, d = torch.stack(rs).cpu(), torch.stack(ds).cpu().float()
+    assert abs(float((r == -1).float().mean()) - 0.1) < 0.01 and abs(float((r == 1).float().mean()) - 0.1) < 0.01
+    assert abs(float(d.mean()) - 0.1) < 0.01
+    assert not torch.equal(rs[0], rs[1])
+    st = a.get_state()
+    nxt = a.step_device(None)
+    a.set_state(st)
+    again = a.step_device(None)
+    assert all(torch.equal(x, y) for x, y in zip(nxt[:3], again[:3]))
