@@ -523,6 +523,21 @@ int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu,
                       const float* mul, int64_t ldmul, int32_t group_shift, float* pre, int64_t ldpre,
                       void* stream);
+/* The B operand of an NT / NN product split ONCE: a weight matrix multiplies with thousands of row tiles per launch and
+ * with several launches per optimizer step, each of which would otherwise split the same tile again.
+ *   mirl_gemm3_presplit   rows x K floats (element (r, k) at W[r * row_stride + k * k_stride]: (ld, 1) for the [N][K]
+ *                         weight of an NT product, (1, ld) for the [K][N] operand of an NN product) -> `planes`,
+ *                         mirl_gemm3_presplit_bytes(rows, K) bytes: per row K / 16 blocks of [hi 16 | mid 16 | lo 16] bf16
+ *   mirl_gemm3_ps[_mul]   C = A[M][K] . planes^T (+ bias, ReLU[, x multiplier rows as mirl_gemm3_nt_mul]): the same tiles,
+ *                         the same six part products in the same order as mirl_gemm3 — bit-identical results
+ *                         (tests/test_gemm3_gpu.py) — minus the B half of the split work in the loop.                  */
+int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes);
+int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes, void* stream);
+int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
+                  const float* bias, int32_t relu, void* stream);
+int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
+                      const float* bias, int32_t relu, const float* mul, int64_t ldmul, int32_t group_shift, float* pre,
+                      int64_t ldpre, void* stream);
 
 /* ---- forward of the middle conv layers on the bf16 matrix pipe, f32 result (csrc/conv3.hip).  Replaces
  * `F.relu(conv(x))` of rltime/models/torch/modules/cnn.py:47-49 for NHWC activations (the Atari models' layers 2

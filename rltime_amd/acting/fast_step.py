@@ -170,6 +170,7 @@ class FastActingStep:
             self.env_dones = torch.zeros(E, dtype=torch.uint8, device=dev)
         self._rollouts = {}              # (iters, keep_policy, clip, sink id) -> [calls so far, CUDAGraph or None]
         self.rollout_graphs = os.environ.get("MIRL_ROLLOUT_GRAPH", "1") != "0"
+        self.rollout_eager_calls = int(os.environ.get("MIRL_ROLLOUT_EAGER_CALLS", "0"))
         assert cell.weight_ih.shape == (4 * H, F)
         # the reference's first input state: every env starts an episode (actor.py:78-89)
         self.refresh()
@@ -322,9 +323,9 @@ class FastActingStep:
             self._body()
 
     def rollout(self, iters, sink, keep_policy=False, clip=False):
-        """`iters` vector steps after reselect(): the first call of a shape runs them eagerly (the same launches, and the
-        warm-up a capture needs), the second captures them into ONE HIP graph, every later one is a plan upload + a
-        graph launch.  Identical results either way (tests/test_fast_acting_gpu.py)."""
+        """`iters` vector steps after reselect(): the first call of a shape captures them into ONE HIP graph, every call
+        is a plan upload + a graph launch.  Identical results to the same launches issued one by one
+        (tests/test_fast_acting_gpu.py)."""
         key = (iters, bool(keep_policy), bool(clip), id(sink))
         state = self._rollouts.setdefault(key, [0, None])
         try:
@@ -336,7 +337,10 @@ class FastActingStep:
             return False
         self.tracker.begin_rollout(iters)
         state[0] += 1
-        if state[1] is None and state[0] >= 2:
+        # capture at the FIRST call of a shape: every kernel of the body has run before (the single-step graph's warm-ups,
+        # reselect, the constructor's pre-step), so nothing is left to initialise inside the capture.
+        # MIRL_ROLLOUT_EAGER_CALLS=n runs the first n calls eagerly instead (the same launches: debugging, A/B test)
+        if state[1] is None and state[0] > self.rollout_eager_calls:
             keep_step = self.step_no
             graph = torch.cuda.CUDAGraph()
             with quiet_gc(), torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):

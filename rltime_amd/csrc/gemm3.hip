@@ -56,7 +56,10 @@ struct G3Args {
   const float* mul; int64_t ldmul; int mul_shift;
   float* pre; int64_t ldpre;
   int vec_ok;            // 16-byte stores possible: N % 4 == 0, every output / bias / multiplier row 16-byte aligned
+  const char* Bps;       // B operand already split (mirl_gemm3_presplit): rows of K/16 blocks of [hi 16 | mid 16 | lo 16] bf16
 };
+
+constexpr int G3_PSBLK = 96;     // bytes of one pre-split 16-k block: three parts x 16 bf16
 
 // One operand's loader state: two rows per thread (r and r + 128 of the 256-row tile), four consecutive k each.
 template <bool KC>
@@ -114,6 +117,49 @@ struct G3Loader {
   }
 };
 
+// The B operand from PRE-SPLIT planes (weights, split once per optimizer step instead of by every one of the M / 256 row
+// tiles that multiply with them): a thread moves 48 contiguous bytes = three 16-byte chunks of row t >> 1 per K-step,
+// chunk c = 3 (t & 1) + i -> part c >> 1, k half c & 1; no VALU work, three 16-byte LDS writes.
+typedef unsigned g3_u32x4 __attribute__((ext_vector_type(4)));     // a native vector: arrays of HIP's uint4 struct stay in scratch
+struct G3LoaderPS {
+  const char* p;
+  int lds_off[3];
+  __device__ __forceinline__ void init(const char* planes, int64_t row0, int64_t rows, int64_t k0, int64_t K, int t) {
+    const int r = t >> 1, half = t & 1;
+    int64_t row = row0 + r; if (row > rows - 1) row = rows - 1;
+    p = planes + (row * (K / 16) + k0 / 16) * G3_PSBLK + half * 48;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int c = 3 * half + i; lds_off[i] = (c >> 1) * G3_PLANE + r * G3_PITCH + (c & 1) * 16; }
+  }
+  __device__ __forceinline__ void load(g3_u32x4 (&v)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const g3_u32x4*>(p + 16 * i);
+    p += G3_PSBLK;
+  }
+  __device__ __forceinline__ void store(char* planes, const g3_u32x4 (&v)[3]) const {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<g3_u32x4*>(planes + lds_off[i]) = v[i];
+  }
+};
+
+// rows x K floats (element (r, k) at W[r * row_stride + k * k_stride]) -> pre-split planes; one thread per four k
+__global__ void __launch_bounds__(256)
+k_g3_presplit(const float* __restrict__ W, int64_t rows, int64_t K, int64_t row_stride, int64_t k_stride, char* __restrict__ planes) {
+  const int64_t kq = K / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * kq; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / kq, q = i - r * kq;
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = W[r * row_stride + (q * 4 + e) * k_stride];
+    uint2 h, m, l;
+    g3_split4(x, h, m, l);
+    char* d = planes + (r * (K / 16) + q / 4) * G3_PSBLK + (q & 3) * 8;
+    *reinterpret_cast<uint2*>(d) = h;
+    *reinterpret_cast<uint2*>(d + 32) = m;
+    *reinterpret_cast<uint2*>(d + 64) = l;
+  }
+}
+
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
 // of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.  (Issuing all 18 fragment reads before the
 // first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.)
@@ -145,7 +191,10 @@ __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4
 }
 
 
-template <bool AKC, bool BKC, int EP, bool VEC>
+template <bool BPS, bool BKC> struct G3BSel { typedef G3Loader<BKC> L; typedef float V[2][4]; };
+template <bool BKC> struct G3BSel<true, BKC> { typedef G3LoaderPS L; typedef g3_u32x4 V[3]; };
+
+template <bool AKC, bool BKC, int EP, bool VEC, bool BPS = false>
 __global__ void __launch_bounds__(512)
 k_gemm3(G3Args g) {
   extern __shared__ __attribute__((aligned(16))) char g3_lds[];
@@ -181,10 +230,11 @@ k_gemm3(G3Args g) {
     if (e >= E) return;
   }
 
-  G3Loader<AKC> la; G3Loader<BKC> lb;
-  float va[2][4], vb[2][4];
+  G3Loader<AKC> la; typename G3BSel<BPS, BKC>::L lb;
+  float va[2][4]; typename G3BSel<BPS, BKC>::V vb;
   la.init(g.A, g.lda, (int64_t)it * 256, g.M, ks0 * 16, t);
-  lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
+  if constexpr (BPS) lb.init(g.Bps, (int64_t)jt * 256, g.N, ks0 * 16, g.K, t);
+  else lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
   if (nk > 0) { la.load(va); lb.load(vb); }
 
   g3_f32x16 acc[4][2];
@@ -226,7 +276,8 @@ k_gemm3(G3Args g) {
       more = e < E;
       if (more) {
         la.init(g.A, g.lda, (int64_t)it * 256, g.M, 0, t);
-        lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, 0, t);
+        if constexpr (BPS) lb.init(g.Bps, (int64_t)jt * 256, g.N, 0, g.K, t);
+        else lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, 0, t);
         la.load(va); lb.load(vb);
       }
     }
@@ -254,6 +305,21 @@ k_gemm3(G3Args g) {
         if (g.bias && col < g.N) {      // N % 4 == 0 on this path
           bv = *reinterpret_cast<const float4*>(g.bias + col);
         }
+        // IQN feature product (iqn.py:84,102): the row group r >> mul_shift (one state's quantile rows) shares one row of
+        // `mul`.  A lane's 16 rows of this half are q * 4 + (lane >> 4): with groups of 2^s >= 4 rows they fall into at most
+        // 64 >> s groups; with s >= 5 (32 quantiles per state, the shipped IQN configs) that is two multiplier vectors per
+        // lane and half, fetched before the first store goes out — one dependent global load per output vector (16 per
+        // half, each an L2 round trip in front of its store) kept the K = 64 product at a third of the HBM rate.
+        float4 mg0 = make_float4(0.f, 0.f, 0.f, 0.f), mg1 = mg0;
+        const bool hoisted = EP == 1 && g.mul_shift >= 5;   // groups of >= 32 rows: at most two per 64-row half
+        if (EP == 1 && hoisted) {
+          // unconditional loads from clamped addresses (rows / columns beyond the edge are never stored)
+          const int64_t rb = m0 + wm * 128 + h * 64 + (lane >> 4);
+          const int64_t r0 = rb < g.M ? rb : g.M - 1, r1 = rb + 32 < g.M ? rb + 32 : g.M - 1;
+          const int64_t cc = col < g.N ? col : 0;
+          mg0 = *reinterpret_cast<const float4*>(g.mul + (r0 >> g.mul_shift) * g.ldmul + cc);
+          mg1 = *reinterpret_cast<const float4*>(g.mul + (r1 >> g.mul_shift) * g.ldmul + cc);
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int rl = q * 4 + (lane >> 4);
@@ -263,9 +329,10 @@ k_gemm3(G3Args g) {
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (g.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
             if (EP == 1) {
-              // IQN feature product (iqn.py:84,102): the row group r >> mul_shift (one state's quantile rows) shares one row of `mul`
               if (g.pre) __builtin_nontemporal_store(g3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<g3_f32x4*>(g.pre + row * g.ldpre + col));
-              const float4 m = *reinterpret_cast<const float4*>(g.mul + (row >> g.mul_shift) * g.ldmul + col);
+              float4 m;
+              if (hoisted) m = q < 8 ? mg0 : mg1;           // q is a compile-time constant of the unrolled loop
+              else m = *reinterpret_cast<const float4*>(g.mul + (row >> g.mul_shift) * g.ldmul + col);
               v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
             }
             __builtin_nontemporal_store(g3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<g3_f32x4*>(C + row * g.ldc + col));
@@ -350,9 +417,15 @@ extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, 
 static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
                      int64_t workspace_bytes, const float* mul, int64_t ldmul, int32_t mul_shift, float* pre, int64_t ldpre,
-                     void* stream) {
+                     void* stream, const void* b_planes = nullptr) {
   using namespace mirl;
   if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
+  if (b_planes) {
+    // pre-split B: planes are [N rows][K / 16 blocks] whatever the weight's own layout was, so NT and NN are ONE kernel
+    if (layout == 2) return fail(MIRL_ERR_ARG, "gemm3: pre-split B exists for NT / NN (a weight operand), not for TN");
+    if ((uintptr_t)b_planes % 16) return fail(MIRL_ERR_ARG, "gemm3: pre-split planes must be 16-byte aligned");
+    B = reinterpret_cast<const float*>(b_planes); ldb = K; layout = 0;
+  }
   if (!A || !B || !C) return fail(MIRL_ERR_ARG, "gemm3: null operand");
   const bool akc = layout != 2, bkc = layout == 0;
   if (akc && ((lda % 4) || ((uintptr_t)A % 16) || lda < K)) return fail(MIRL_ERR_ARG, "gemm3: A must be 16-byte aligned with lda % 4 == 0");
@@ -366,6 +439,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
+  g.Bps = reinterpret_cast<const char*>(b_planes);
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
   g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!bias || !((uintptr_t)bias % 16)) &&
              (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));
@@ -399,13 +473,20 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                            {(const void*)k_gemm3<true, true, 1, false>, (const void*)k_gemm3<true, true, 1, true>}};
   const int which = mul ? 3 : layout;
   const void* fn = fns[which][vec];
+  if (b_planes) {
+    static bool ps_attr[2][2] = {{false, false}, {false, false}};
+    const void* ps[2][2] = {{(const void*)k_gemm3<true, true, 0, false, true>, (const void*)k_gemm3<true, true, 0, true, true>},
+                            {(const void*)k_gemm3<true, true, 1, false, true>, (const void*)k_gemm3<true, true, 1, true, true>}};
+    fn = ps[mul ? 1 : 0][vec];
+    if (!ps_attr[mul ? 1 : 0][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); ps_attr[mul ? 1 : 0][vec] = true; }
+  } else
   if (!attr[which][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[which][vec] = true; }
   {
     const double flop = 2.0 * (double)M * (double)N * (double)K;
     // HBM bytes: both operands read once, the result (and the pre-product embedding / the multiplier rows) written / read once
     double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
     if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N);
-    ProfScope ps(mul ? "k_gemm3_nt_mul" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
+    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
@@ -432,4 +513,38 @@ extern "C" int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A
   if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
     return fail(MIRL_ERR_ARG, "gemm3_nt_mul: bad multiplier / pre-activation arguments");
   return g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream);
+}
+
+// ---- weights split once (per optimizer step) instead of by every row tile ------------------------------------
+extern "C" int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes) {
+  if (!bytes || rows < 1 || K < 16 || (K % 16)) return mirl::fail(MIRL_ERR_ARG, "gemm3_presplit_bytes: rows >= 1, K a multiple of 16");
+  *bytes = rows * (K / 16) * (int64_t)mirl::G3_PSBLK;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes,
+                                   void* stream) {
+  using namespace mirl;
+  if (rows < 1 || K < 16 || (K % 16) || !W || !planes || ((uintptr_t)planes % 16) || row_stride < 1 || k_stride < 1)
+    return fail(MIRL_ERR_ARG, "bad gemm3_presplit arguments");
+  const int64_t n = rows * (K / 4);
+  unsigned grid = (unsigned)((n + 255) / 256); if (grid > 8192) grid = 8192;
+  ProfScope ps("k_g3_presplit", 10.0 * (double)rows * (double)K, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_g3_presplit, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, rows, K, row_stride, k_stride, (char*)planes);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
+                             const float* bias, int32_t relu, void* stream) {
+  return g3_launch(0, M, N, K, A, lda, nullptr, K, C, ldc, bias, relu, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream, b_planes);
+}
+
+extern "C" int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
+                                 const float* bias, int32_t relu, const float* mul, int64_t ldmul, int32_t group_shift, float* pre,
+                                 int64_t ldpre, void* stream) {
+  using namespace mirl;
+  if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
+    return fail(MIRL_ERR_ARG, "gemm3_ps_mul: bad multiplier / pre-activation arguments");
+  return g3_launch(0, M, N, K, A, lda, nullptr, K, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream, b_planes);
 }

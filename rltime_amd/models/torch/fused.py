@@ -355,7 +355,7 @@ class _DuelingTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, wo, bo, wv, bv, wq, bq):
         h1 = w1.shape[0]
-        both = gemm3.linear_fwd(x, torch.cat([w1, wv], 0), torch.cat([b1, bv]), relu=True)
+        both = gemm3.linear_fwd(x, gemm3.joint_rows((w1, wv)), gemm3.joint_rows((b1, bv)), relu=True)
         a = torch.addmm(bo, both[:, :h1], wo.t())
         v = torch.addmm(bq, both[:, h1:], wq.t())
         ctx.h1 = h1
@@ -406,12 +406,12 @@ class _DuelingTail(torch.autograd.Function):
         # (10.3 + 11.5 ms merged vs 4 x 3.55 ms, profiles/r02b)
         g1, g2 = g[:, :h1], g[:, h1:]
         dx = None
-        wj = torch.cat([w1, wv], 0) if gemm3.enabled() else None
+        wj = gemm3.joint_rows((w1, wv)) if gemm3.enabled() else None
         if wj is not None and gemm3.supported(gemm3.NN, g, wj) and gemm3.supported(gemm3.TN, g, x):
             # the split-bf16 kernel takes the joint (rows, H1 + Hv) gradient as ONE K = H1 + Hv data gradient
             # and ONE weight gradient whose row blocks are dW1 | dWv
             if ctx.needs_input_grad[0]:
-                dx = gemm3.gemm(gemm3.NN, g, wj)
+                dx = gemm3.gemm(gemm3.NN, g, wj, weight_b=True)
             dwj = gemm3.gemm(gemm3.TN, g, x)
             dw1, dwv = dwj[:h1], dwj[h1:]
         else:

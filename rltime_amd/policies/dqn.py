@@ -77,6 +77,26 @@ class DQNPolicy(TorchPolicy):
     def _tail_postprocess(self, output, model_output):
         return output
 
+    def predict_selection(self, x, timesteps):
+        """Scores whose arg-max over actions equals predict()'s, for the double-Q ACTION SELECTION only (training/torch/
+        dqn.py:52-71, iqn.py:36-45).  With a dueling head, Q(a) = V + A(a) - mean_a A (dqn.py:74-87): V and the mean
+        are the same for every action of a row — and stay so under IQN's mean over quantile samples — so
+        argmax_a Q(a) = argmax_a A(a) and the value stream (a second 512-wide hidden layer over every quantile row)
+        need not be evaluated for this pass.  Same forward otherwise (same quantile-fraction draw); results can differ
+        from predict()'s arg-max only where two actions tie to the last float32 bit."""
+        if self.value_layer is None:
+            return self.predict(x, timesteps)
+        fc = self._fused_tail_layer()
+        if fc is not None:
+            res = self.model(x, timesteps, skip_last=True)
+            inner = res["output"].reshape(-1, fc.in_features)
+            adv = F.linear(linear_relu(inner, fc.weight, fc.bias), self.out_layer.weight, self.out_layer.bias)
+        else:
+            res = self.model(x, timesteps)
+            adv = self.out_layer(res["output"])
+        adv, _ = self._shape_action_outputs(adv)
+        return self._tail_postprocess(adv, res)
+
     def _samples_per_state(self):
         return 1
 

@@ -18,7 +18,10 @@ class IQN(DQN):
         with torch.no_grad():
             z_t = self.target_policy.predict(target_states, timesteps=timesteps)[0]
             sel = self.policy if self.double_q else self.target_policy
-            z_s = sel.predict(target_states, timesteps=timesteps)[0]
+            # the selection pass only feeds argmax_a mean_N Z: with a dueling head that is the advantage stream's
+            # arg-max (DQNPolicy.predict_selection) — the value-hidden half of the head's widest GEMM is skipped
+            fwd = sel.predict_selection if getattr(self, "selection_advantage_only", True) else sel.predict
+            z_s = fwd(target_states, timesteps=timesteps)[0]
             mk = self.policy.make_tensor
             return qops.q_target_iqn(z_t, z_s, mk(returns), mk(nsteps), mk(target_masks),
                                      self.gamma, self.vf_scale_epsilon)

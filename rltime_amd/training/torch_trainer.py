@@ -9,7 +9,7 @@ from rltime_amd.models.torch.utils import set_lr
 class TorchTrainer(MultiStepTrainer):
     def _train(self, clip_grad=None, clip_grad_dynamic_alpha=None, adam_epsilon=1e-8,
                vf_scale_epsilon=None, apply_initial_lr=False, burn_in_full_forward=False,
-               share_online_cnn=True, share_online_projection=True, **kwargs):
+               share_online_cnn=True, share_online_projection=True, selection_advantage_only=True, **kwargs):
         """torch_trainer.py:9-44.  apply_initial_lr=False mirrors the reference,
         whose train_init ignores `lr` (Adam starts at 1e-3, SURVEY A-14)."""
         self.clip_grad = float(clip_grad) if clip_grad is not None else None
@@ -24,6 +24,9 @@ class TorchTrainer(MultiStepTrainer):
         self.burn_in_full_forward = burn_in_full_forward
         self.share_online_cnn = share_online_cnn
         self.share_online_projection = share_online_projection
+        # double-Q action selection from the dueling head's advantage stream alone (policies/dqn.py predict_selection):
+        # the same arg-max, half of the selection pass's widest GEMM
+        self.selection_advantage_only = selection_advantage_only
         super()._train(**kwargs)
 
     def train_init(self, lr):

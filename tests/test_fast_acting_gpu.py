@@ -217,8 +217,9 @@ def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
     from rltime_amd.history import PrioritizedReplayHistoryBuffer, ReplayHistoryBuffer
     E, calls, iters = 16, 7, 6
     results = []
-    for mode in ("graph", "per-step"):
-        monkeypatch.setenv("MIRL_ROLLOUT_GRAPH", "1" if mode == "graph" else "0")
+    for mode in ("graph", "eager-then-graph", "per-step"):
+        monkeypatch.setenv("MIRL_ROLLOUT_GRAPH", "0" if mode == "per-step" else "1")
+        monkeypatch.setenv("MIRL_ROLLOUT_EAGER_CALLS", "2" if mode == "eager-then-graph" else "0")
         actor, pol, env = _make(kind, E, True, exploration=EXPL)
         if kind == "iqn":
             pol.tau_source = None                                  # quantile fractions drawn in the kernel (Philox, step counter)
@@ -236,7 +237,7 @@ def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
                         p.mul_(1.01)
         fs = actor._fast
         captured = [v[1] is not None for v in fs._rollouts.values()]
-        assert (captured == [True]) if mode == "graph" else (captured == []), (mode, fs._rollouts)
+        assert (captured == []) if mode == "per-step" else (captured == [True]), (mode, fs._rollouts)
         torch.cuda.synchronize()
         episodes = actor._tracker.drain(wait=True)
         counts = actor._tracker.take_action_counts()
@@ -244,16 +245,17 @@ def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
         results.append((batch, hist.stats(), hist.tree_nodes() if per else None, hist.free_slots() if per else None,
                         episodes, counts, int(fs.rng_step.item()), fs.step_no))
         hist.close()
-    (ba, sa, ta, fa, ea, ca, ra, na), (bb, sb, tb, fb, eb, cb, rb, nb) = results
-    assert sa == sb and ea == eb and ca == cb and ra == rb == na == nb
-    assert len(ea) > 0 and sum(ca) == E * calls * iters
     flat = lambda tree: [tree] if isinstance(tree, torch.Tensor) else [x for v in (tree.values() if isinstance(tree, dict) else tree) for x in flat(v)] if tree is not None else []   # noqa: E731
-    for x, y in zip(flat(ba), flat(bb)):
-        assert torch.equal(x, y)
-    if per:
-        assert np.array_equal(fa, fb)
-        for x, y in zip(ta, tb):
-            assert np.array_equal(x, y)
+    (bb, sb, tb, fb, eb, cb, rb, nb) = results[-1]                 # the per-step path
+    for (ba, sa, ta, fa, ea, ca, ra, na) in results[:-1]:
+        assert sa == sb and ea == eb and ca == cb and ra == rb == na == nb
+        assert len(ea) > 0 and sum(ca) == E * calls * iters
+        for x, y in zip(flat(ba), flat(bb)):
+            assert torch.equal(x, y)
+        if per:
+            assert np.array_equal(fa, fb)
+            for x, y in zip(ta, tb):
+                assert np.array_equal(x, y)
 
 
 def test_synthetic_env_steps_are_a_function_of_seed_and_step():

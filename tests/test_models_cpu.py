@@ -83,3 +83,37 @@ def test_burn_in_matches_reference():
     np.testing.assert_allclose(res["states"]["layer1_state"]["hx"].numpy(), d[name + ".burn.hx"], **TOL)
     np.testing.assert_allclose(res["states"]["layer1_state"]["cx"].numpy(), d[name + ".burn.cx"], **TOL)
     assert np.array_equal(res["returns"].numpy(), d[name + ".burn.returns"])
+
+
+def test_selection_scores_pick_the_same_actions_as_the_full_dueling_head():
+    """DQNPolicy.predict_selection (advantage stream only) against predict() (V + A - mean_a A, dqn.py:74-87):
+    the same arg-max over actions, for DQN rows and for IQN's mean over quantile samples (iqn.py:36-45)."""
+    import numpy as np
+    import torch
+    from rltime_amd.policies.dqn import DQNPolicy
+    from rltime_amd.policies.iqn import IQNPolicy
+    from rltime_amd.spaces import Box, Discrete
+    model = {"type": "sequential", "args": {"layer_configs": [
+        {"type": "cnn", "args": {"layers": [{"filters": 4, "kernel": 4, "stride": 2}]}},
+        {"type": "lstm", "args": {"num_units": 8}}, {"type": "fc", "args": {"fc_size": 16}}]}}
+    torch.manual_seed(1)
+    T, B = 3, 40
+    frames = torch.randint(0, 256, (T * B, 2, 12, 12), dtype=torch.uint8)
+    state = {"x": frames, "layer0_state": {}, "layer2_state": {},
+             "layer1_state": {"hx": torch.randn(T * B, 8) * 0.3, "cx": torch.randn(T * B, 8) * 0.3, "initials": (torch.rand(T * B) < 0.2).float()}}
+    kw = dict(model_config=model, observation_space=Box(0, 255, (2, 12, 12), np.uint8), action_space=Discrete(5), cuda=False, dueling=True)
+    dqn = DQNPolicy.create(**kw)
+    with torch.no_grad():
+        assert torch.equal(dqn.predict(state, T).argmax(1), dqn.predict_selection(state, T).argmax(1))
+    iqn = IQNPolicy.create(embedding_dim=8, num_sampling_quantiles=4, **kw)
+    taus = torch.rand(T * B * 4)
+    iqn.tau_source = lambda n: taus
+    with torch.no_grad():
+        z, _ = iqn.predict(state, T)
+        a, _ = iqn.predict_selection(state, T)
+    assert z.shape == a.shape == (T * B, 4, 5)
+    assert torch.equal(z.mean(1).argmax(1), a.mean(1).argmax(1))
+    # and without a dueling head the selection scores ARE the outputs
+    plain = DQNPolicy.create(**dict(kw, dueling=False))
+    with torch.no_grad():
+        assert torch.equal(plain.predict(state, T), plain.predict_selection(state, T))

@@ -23,10 +23,44 @@ def timed(fn, reps):
     return a.elapsed_time(b) / reps
 
 
+def quantile_product_probe(spec, g):
+    """qp:RxNxK:n — out[r] = x[r // n] * relu(phi[r] @ W^T + b) (mirl_gemm3_nt_mul), with and without the stored embedding:
+    checked against float64 on a row slice, timed, priced against its HBM bytes (a K = 64 product is a store kernel)."""
+    _, dims, n = spec.split(":")
+    R, N, K = (int(v) for v in dims.split("x"))
+    n = int(n)
+    x = torch.randn(R // n, N, device="cuda", generator=g)
+    phi = torch.cos(torch.rand(R, K, device="cuda", generator=g) * 3.0)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.125
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    rec = {"layout": "nt_mul", "R": R, "N": N, "K": K, "group": n, "supported": bool(gemm3.quantile_product_supported(x, phi, w, b, n))}
+    if rec["supported"]:
+        rows = torch.unique(torch.cat([torch.arange(0, 96), torch.randint(0, R, (256,)), torch.arange(R - 96, R)])).cuda()
+        ref = x[rows // n].double() * torch.relu(phi[rows].double() @ w.double().t() + b.double())
+        scale = float(ref.abs().max())
+        for keep in (False, True):
+            out, emb = gemm3.quantile_product(x, phi, w, b, n, keep)
+            rec["max_err_keep%d" % keep] = float((out[rows].double() - ref).abs().max()) / scale
+            if keep:
+                e64 = torch.relu(phi[rows].double() @ w.double().t() + b.double())
+                rec["max_err_embedding"] = float((emb[rows].double() - e64).abs().max()) / float(e64.abs().max())
+            t = timed(lambda: gemm3.quantile_product(x, phi, w, b, n, keep), 10)
+            by = 4.0 * (R * K + N * K + R * N * (2 if keep else 1) + (R // n) * N)
+            rec["ms_keep%d" % keep] = round(t, 4)
+            rec["GBps_keep%d" % keep] = round(by / t / 1e6, 1)
+            rec["frac_of_hbm_peak_keep%d" % keep] = round(by / t / 1e6 / 8000.0, 3)
+            del out, emb
+    print(json.dumps(rec), flush=True)
+    torch.cuda.empty_cache()
+
+
 def main():
     specs = sys.argv[1:] or DEFAULT
     g = torch.Generator(device="cuda").manual_seed(0)
     for spec in specs:
+        if spec.startswith("qp:"):
+            quantile_product_probe(spec, g)
+            continue
         lay, dims = spec.split(":")
         M, N, K = (int(v) for v in dims.split("x"))
         layout = {"nt": gemm3.NT, "nn": gemm3.NN, "tn": gemm3.TN}[lay]
@@ -67,6 +101,11 @@ def main():
             reps = 5 if flop > 1e11 else 20
             t3 = timed(lambda: gemm3.gemm(layout, a, b, out=out), reps)
             tl = timed(lib, reps)
+            if layout != gemm3.TN:
+                ps = gemm3.gemm(layout, a, b, weight_b=True)
+                rec["presplit_bit_identical"] = bool(torch.equal(ps, out))
+                tp = timed(lambda: gemm3.gemm(layout, a, b, out=out, weight_b=True), reps)
+                rec.update(ms_presplit_b=round(tp, 4), tflops_presplit_b=round(flop / tp / 1e9, 1))
             rec.update(ms_gemm3=round(t3, 4), ms_lib_f32=round(tl, 4), tflops_gemm3=round(flop / t3 / 1e9, 1),
                        tflops_lib=round(flop / tl / 1e9, 1), frac_of_bf16x6_peak=round(flop / t3 / 1e9 / 416.7, 3))
         print(json.dumps(rec), flush=True)
