@@ -259,8 +259,14 @@ class Actor(ActingInterface):
     def _fast_steps(self, iters):
         """The fused vector step (acting/fast_step.py)."""
         from .fast_step import FastActingStep, IngestedSamples
+        sink0 = self._sink
+        # q-values are only computed when somebody keeps them (DeviceSamples for the caller, or a replay that stores
+        # policy outputs / initialises priorities from them)
+        need_q = sink0 is None or bool(getattr(sink0, "_keep_policy", True)) or bool(getattr(sink0, "_acting_priority_init", False))
+        if self._fast is not None:
+            self._fast.set_need_q(need_q)
         if self._fast is None:
-            self._fast = FastActingStep(self, self._reset_obs)
+            self._fast = FastActingStep(self, self._reset_obs, need_q=need_q)
             if self._tracker is None:
                 from .episode_tracker import EpisodeTracker
                 self._tracker = EpisodeTracker(self._num_envs, self._action_space.n, self._policy.device())

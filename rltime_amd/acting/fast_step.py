@@ -103,8 +103,12 @@ class FastActingStep:
         except Exception:
             return False
 
-    def __init__(self, actor, obs0):
+    def __init__(self, actor, obs0, need_q=True):
+        """need_q=False: nobody reads the step's q-values (a replay that does not keep policy outputs): the dueling
+        head's VALUE stream is then skipped — argmax_a mean_N (V + A - mean_a A) = argmax_a mean_N A (dqn.py:74-87), so the
+        chosen actions are the same while the head's widest GEMM is half as wide."""
         self.actor = actor
+        self.need_q = bool(need_q)
         pol = self.pol = actor._policy
         self.cnn, self.lstm, self.fc_layer = pol.model.layers
         self.fc = pol._fused_tail_layer()
@@ -148,6 +152,7 @@ class FastActingStep:
         assert self.na == A and self.nq == 1
         self.out_w = torch.zeros((self.na + self.nq, h1 + hv), **f32)
         self.out_b = torch.zeros(self.na + self.nq, **f32)
+        self.adv_w = torch.zeros((self.na, h1), **f32)           # advantage stream alone (need_q=False)
         self.freq = (pol.embedding_range * np.pi).contiguous() if self.iqn else None
         self.in_kernel_taus = self.iqn and getattr(pol, "tau_source", None) is None
         expl = actor._exploration
@@ -193,6 +198,7 @@ class FastActingStep:
             self.fc_b[self.h1:].copy_(pol.value_hidden_layer.bias)
             na = self.na
             self.out_w[:na, :self.h1].copy_(pol.out_layer.weight)
+            self.adv_w.copy_(pol.out_layer.weight)
             self.out_w[na:, self.h1:].copy_(pol.value_layer.weight)
             self.out_b[:na].copy_(pol.out_layer.bias)
             self.out_b[na:].copy_(pol.value_layer.bias)
@@ -246,12 +252,17 @@ class FastActingStep:
             emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
             check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(emb), _stream()), "mirl_iqn_mul_fwd")   # in place
             feat = emb
-        both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
-        outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
-        pitch = self.na + self.nq
+        if self.need_q:
+            both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
+            outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
+            pitch, val = self.na + self.nq, C.c_void_p(outs.data_ptr() + 4 * self.na)
+        else:
+            hidden = torch._addmm_activation(self.fc_b[:self.h1], feat, self.fc_w[:self.h1].t(), use_gelu=False)
+            outs = torch.addmm(self.out_b[:self.na], hidden, self.adv_w.t())   # (rows, A): the advantage stream
+            pitch, val = self.na, None
         greedy = self.expo is None
         check(lib.mirl_actor_head_rng(
-            E, N, self.A, _p(outs), pitch, C.c_void_p(outs.data_ptr() + 4 * self.na), pitch, None if greedy else _p(self.eps), None if greedy else _p(self.expo),
+            E, N, self.A, _p(outs), pitch, val, pitch, None if greedy else _p(self.eps), None if greedy else _p(self.expo),
             self.eps_min, self.rng_seed, None if greedy else _p(self.rng_step), _p(self.actions), _p(self.qvalues), None, _stream()),
             "mirl_actor_head_rng")
 
@@ -272,6 +283,13 @@ class FastActingStep:
         self.h.copy_(keep[0])
         self.c.copy_(keep[1])
         self.reselect()
+
+    def set_need_q(self, need_q):
+        """Switch between the full dueling head and the advantage stream alone; the step graphs are re-captured."""
+        if bool(need_q) != self.need_q:
+            self.need_q = bool(need_q)
+            self._rollouts.clear()
+            self._capture()
 
     # -- the acting loop's entry points ---------------------------------------------------------
     def reselect(self):

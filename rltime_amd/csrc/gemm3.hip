@@ -163,7 +163,8 @@ k_g3_presplit(const float* __restrict__ W, int64_t rows, int64_t K, int64_t row_
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
 // of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.  (Issuing all 18 fragment reads before the
 // first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.)
-__device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4][2], int a_off, int b_off) {
+template <int TI>
+__device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[TI][2], int a_off, int b_off) {
   const char* pa = stage + a_off;
   const char* pb = stage + 3 * G3_PLANE + b_off;
   // smallest products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
@@ -174,19 +175,20 @@ __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[p][j] = *reinterpret_cast<const g3_bf16x8*>(pb + p * G3_PLANE + j * 32 * G3_PITCH);
+  constexpr int IW = TI >= 2 ? 2 : 1;              // A tiles per fragment batch
 #pragma unroll
-  for (int ih = 0; ih < 2; ++ih) {
-    g3_bf16x8 a[3][2];
+  for (int ih = 0; ih < TI / IW; ++ih) {
+    g3_bf16x8 a[3][IW];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
+      for (int i = 0; i < IW; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * IW + i) * 32 * G3_PITCH);
 #pragma unroll
     for (int c = 0; c < 6; ++c)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < IW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[ih * 2 + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * 2 + i][j]);
+        for (int j = 0; j < 2; ++j) acc[ih * IW + i][j] = g3_mfma(a[PA[c]][i], b[PB[c]][j], acc[ih * IW + i][j]);
   }
 }
 
@@ -194,9 +196,13 @@ __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[4
 template <bool BPS, bool BKC> struct G3BSel { typedef G3Loader<BKC> L; typedef float V[2][4]; };
 template <bool BKC> struct G3BSel<true, BKC> { typedef G3LoaderPS L; typedef g3_u32x4 V[3]; };
 
-template <bool AKC, bool BKC, int EP, bool VEC, bool BPS = false>
+// NARROW: outputs at most 64 columns wide (the quantile layer's weight gradient, 512 x 64 over K = 1.3 M rows): the
+// eight waves stack along M — 32 rows x 64 columns each, 12 MFMAs per K-step instead of 48 of which 36 multiplied
+// columns that do not exist — so the product is bound by reading its K x M operand, not by the matrix pipe.
+template <bool AKC, bool BKC, int EP, bool VEC, bool BPS = false, bool NARROW = false>
 __global__ void __launch_bounds__(512)
 k_gemm3(G3Args g) {
+  constexpr int TI = NARROW ? 1 : 4;
   extern __shared__ __attribute__((aligned(16))) char g3_lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // workgroup -> (row tile, column tile, K chunk).  Workgroup b runs on XCD b % 8: the column tiles of one row
@@ -211,8 +217,9 @@ k_gemm3(G3Args g) {
   int64_t ks0 = 0, nk = nk_all;
 
   const int wu = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = wu & 1, wn = wu >> 1;
-  const int a_off = (wm * 128 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
+  const int wm = NARROW ? 0 : (wu & 1), wn = NARROW ? 0 : (wu >> 1);
+  const int row_w = NARROW ? wu * 32 : wm * 128;                      // this wave's first row inside the tile
+  const int a_off = (row_w + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
   const int b_off = (wn * 64 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
   const bool stage_first = g.order == 0 ? ((wu >> 2) & 1) : g.order == 1;      // waves w and w + 4 share a SIMD and take opposite orders
 
@@ -237,11 +244,11 @@ k_gemm3(G3Args g) {
   else lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
   if (nk > 0) { la.load(va); lb.load(vb); }
 
-  g3_f32x16 acc[4][2];
+  g3_f32x16 acc[TI][2];
   while (true) {
     const int64_t m0 = (int64_t)it * 256, n0 = (int64_t)jt * 256;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -261,7 +268,7 @@ k_gemm3(G3Args g) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
       }
-      g3_compute(cur, acc, a_off, b_off);
+      g3_compute<TI>(cur, acc, a_off, b_off);
       if (!stage_first) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
@@ -289,15 +296,16 @@ k_gemm3(G3Args g) {
     float* C = g.C + (g.splits > 1 ? (int64_t)split * g.M * g.N : 0);
     if (VEC) {
       float* tl = reinterpret_cast<float*>(g3_lds) + wu * (64 * G3_EPITCH);
+      constexpr int HALVES = NARROW ? 1 : 2, II = NARROW ? 1 : 2, QN = NARROW ? 8 : 16;     // NARROW: one 32-row block per wave
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < II; ++ii)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              tl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * G3_EPITCH + j * 32 + (lane & 31)] = acc[2 * h + ii][j][r];
+              tl[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * G3_EPITCH + j * 32 + (lane & 31)] = acc[II * h + ii][j][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int c4 = lane & 15;
         const int64_t col = n0 + wn * 64 + c4 * 4;
@@ -314,16 +322,16 @@ k_gemm3(G3Args g) {
         const bool hoisted = EP == 1 && g.mul_shift >= 5;   // groups of >= 32 rows: at most two per 64-row half
         if (EP == 1 && hoisted) {
           // unconditional loads from clamped addresses (rows / columns beyond the edge are never stored)
-          const int64_t rb = m0 + wm * 128 + h * 64 + (lane >> 4);
+          const int64_t rb = m0 + row_w + h * 64 + (lane >> 4);
           const int64_t r0 = rb < g.M ? rb : g.M - 1, r1 = rb + 32 < g.M ? rb + 32 : g.M - 1;
           const int64_t cc = col < g.N ? col : 0;
           mg0 = *reinterpret_cast<const float4*>(g.mul + (r0 >> g.mul_shift) * g.ldmul + cc);
           mg1 = *reinterpret_cast<const float4*>(g.mul + (r1 >> g.mul_shift) * g.ldmul + cc);
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < QN; ++q) {
           const int rl = q * 4 + (lane >> 4);
-          const int64_t row = m0 + wm * 128 + h * 64 + rl;
+          const int64_t row = m0 + row_w + h * 64 + rl;
           float4 v = *reinterpret_cast<const float4*>(tl + rl * G3_EPITCH + c4 * 4);
           if (row < g.M && col < g.N) {
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -348,8 +356,8 @@ k_gemm3(G3Args g) {
         const bool col_ok = col < g.N;
         const float bv = (g.bias && col_ok) ? g.bias[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int64_t rb = m0 + wm * 128 + i * 32 + 4 * (lane >> 5);
+        for (int i = 0; i < TI; ++i) {
+          const int64_t rb = m0 + row_w + i * 32 + 4 * (lane >> 5);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t row = rb + (r & 3) + 8 * (r >> 2);
@@ -447,6 +455,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.splits = 1; g.steps_per_split = (int)(K / 16);
   static const int order_env = getenv("MIRL_GEMM3_ORDER") ? atoi(getenv("MIRL_GEMM3_ORDER")) : 0;
   g.order = order_env;
+  static const int narrow_env = getenv("MIRL_GEMM3_NARROW") ? atoi(getenv("MIRL_GEMM3_NARROW")) : 1;
   static const int persist_env = getenv("MIRL_GEMM3_PERSIST") ? atoi(getenv("MIRL_GEMM3_PERSIST")) : 0;   // measured: no gain (7.36 vs 7.32 ms), opt-in
   unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);                 // one tile per workgroup
   if (persist_env || K <= 128) {          // short K: the tile is mostly epilogue — let the next tile's loads fly during the stores
@@ -479,6 +488,12 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                             {(const void*)k_gemm3<true, true, 1, false, true>, (const void*)k_gemm3<true, true, 1, true, true>}};
     fn = ps[mul ? 1 : 0][vec];
     if (!ps_attr[mul ? 1 : 0][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); ps_attr[mul ? 1 : 0][vec] = true; }
+  } else if (layout == 2 && N <= 64 && narrow_env) {
+    // weight gradient of a narrow layer: eight waves stacked along M, 12 MFMAs per K-step (k_gemm3 NARROW)
+    static bool nr_attr[2] = {false, false};
+    const void* nr[2] = {(const void*)k_gemm3<false, false, 0, false, false, true>, (const void*)k_gemm3<false, false, 0, true, false, true>};
+    fn = nr[vec];
+    if (!nr_attr[vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); nr_attr[vec] = true; }
   } else
   if (!attr[which][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); attr[which][vec] = true; }
   {

@@ -66,9 +66,14 @@ def _workspace(device, nbytes):
 
 # ---- weight operands split once per version (csrc/gemm3.hip mirl_gemm3_presplit) ---------------------------------
 # Every NT / NN product here has a WEIGHT as its B operand: 5 120 row tiles of one launch, and 3-5 launches per
-# optimizer step, would each split the same 256 x 16 tile again.  The planes are cached per (storage, version counter,
+# optimizer step, each split the same 256 x 16 tile again.  The planes are cached per (storage, version counter,
 # layout): Adam's in-place update or a target-network copy bumps `_version`, the next product re-splits (one ~5 us launch).
-_PRESPLIT = os.environ.get("MIRL_GEMM3_PRESPLIT", "1") != "0"
+# MEASURED SLOWER and therefore OFF by default (MIRL_GEMM3_PRESPLIT=1 turns it on): bit-identical results, but
+# 8.31 vs 6.87 ms at NT 1 310 720 x 1024 x 512, 8.11 vs 7.04 at NN, 106.3 vs 97.8 ms per learner step
+# (profiles/r04_gemm3_probe_presplit.jsonl) — the split VALU work of the B half was not on the critical
+# path (it overlaps the other wave's MFMAs), while three 16-byte loads per thread and K-step from 96-byte blocks cost
+# more than two from the f32 rows.
+_PRESPLIT = os.environ.get("MIRL_GEMM3_PRESPLIT", "0") != "0"
 _planes = {}
 
 

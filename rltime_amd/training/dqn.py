@@ -30,7 +30,8 @@ class DQN(TorchTrainer):
         forward(s): argmax (double-Q or not), gather, h^-1, discount, mask, h."""
         with torch.no_grad():
             q_t = self.target_policy.predict(target_states, timesteps=timesteps)
-            fwd = self.policy.predict_selection if getattr(self, "selection_advantage_only", True) else self.policy.predict
+            fwd = (getattr(self.policy, "predict_selection", None) if getattr(self, "selection_advantage_only", True) else None) \
+                or self.policy.predict
             q_s = q_t if not self.double_q else fwd(target_states, timesteps=timesteps)
             mk = self.policy.make_tensor
             return qops.q_target_dqn(q_t, q_s, mk(returns), mk(nsteps), mk(target_masks),

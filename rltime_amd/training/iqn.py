@@ -20,7 +20,7 @@ class IQN(DQN):
             sel = self.policy if self.double_q else self.target_policy
             # the selection pass only feeds argmax_a mean_N Z: with a dueling head that is the advantage stream's
             # arg-max (DQNPolicy.predict_selection) — the value-hidden half of the head's widest GEMM is skipped
-            fwd = sel.predict_selection if getattr(self, "selection_advantage_only", True) else sel.predict
+            fwd = (getattr(sel, "predict_selection", None) if getattr(self, "selection_advantage_only", True) else None) or sel.predict
             z_s = fwd(target_states, timesteps=timesteps)[0]
             mk = self.policy.make_tensor
             return qops.q_target_iqn(z_t, z_s, mk(returns), mk(nsteps), mk(target_masks),

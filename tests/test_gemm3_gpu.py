@@ -39,7 +39,10 @@ def _product(lay, a, b):
 SHAPES = [("nt", 256, 256, 16), ("nt", 1000, 300, 64), ("nt", 513, 1024, 512), ("nt", 4096, 2048, 3136),
           ("nn", 256, 256, 16), ("nn", 777, 260, 48), ("nn", 2048, 3136, 2048), ("nn", 5000, 512, 1024),
           ("tn", 256, 256, 128), ("tn", 300, 260, 4112), ("tn", 1024, 512, 40960), ("tn", 2048, 3136, 2064),
-          ("nt", 1, 1, 16), ("tn", 4, 4, 128)]
+          ("nt", 1, 1, 16), ("tn", 4, 4, 128),
+          # N <= 64: the NARROW wave tiling (eight waves along M, csrc/gemm3.hip) — the quantile layer's weight gradient
+          ("tn", 512, 64, 40960), ("tn", 300, 60, 4112), ("tn", 700, 64, 2064), ("tn", 256, 8, 1040)]
+NARROW_SHAPES = SHAPES[-4:]
 
 
 @pytest.mark.parametrize("lay,M,N,K", SHAPES)
@@ -55,7 +58,7 @@ def test_integer_operands_are_bit_exact(lay, M, N, K):
     assert torch.equal(got.double(), want)
 
 
-@pytest.mark.parametrize("lay,M,N,K", SHAPES[:12])
+@pytest.mark.parametrize("lay,M,N,K", SHAPES[:12] + NARROW_SHAPES)
 def test_real_operands_are_an_f32_gemm(lay, M, N, K):
     from rltime_amd.models.torch import gemm3
     gen = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -222,7 +225,7 @@ def test_quantile_product_autograd_with_and_without_the_epilogue(monkeypatch):
 
 @pytest.mark.parametrize("lay,M,N,K", [("nt", 1000, 300, 64), ("nt", 513, 1024, 512), ("nt", 4096, 2048, 3136), ("nt", 1, 1, 16),
                                        ("nn", 777, 260, 48), ("nn", 5000, 512, 1024), ("nn", 2048, 3136, 2048)])
-def test_presplit_weight_operand_is_bit_identical(lay, M, N, K):
+def test_presplit_weight_operand_is_bit_identical(lay, M, N, K, monkeypatch):
     """mirl_gemm3_presplit + mirl_gemm3_ps (the B operand — a weight — split ONCE into its three bf16 planes instead of by
     every row tile) against mirl_gemm3 splitting while staging: the same parts, the same six products in the same order,
     so the results are the same BITS — for the (N, K) weight of a forward (NT), the (K, N) operand of a data gradient
@@ -234,6 +237,7 @@ def test_presplit_weight_operand_is_bit_identical(lay, M, N, K):
     b[::5] *= 0.013
     bias = torch.randn(N, device="cuda", generator=gen)
     L = LAYOUTS[lay]
+    monkeypatch.setattr(gemm3, "_PRESPLIT", True)
     for kw in ({}, {"bias": bias, "relu": True}):
         plain = gemm3.gemm(L, a, b, **kw)
         ps = gemm3.gemm(L, a, b, weight_b=True, **kw)
@@ -250,6 +254,7 @@ def test_presplit_planes_follow_in_place_weight_updates(monkeypatch):
     w = torch.nn.Parameter(torch.randn(320, 128, device="cuda", generator=gen))
     w2 = torch.nn.Parameter(torch.randn(320, 128, device="cuda", generator=gen))
     monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    monkeypatch.setattr(gemm3, "_PRESPLIT", True)              # opt-in (measured slower than splitting while staging)
     gemm3._planes.clear()
     _lib.check(_lib.lib.mirl_profile_reset())
     _lib.check(_lib.lib.mirl_profile_set(2))

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rltime_amd.models.torch import gemm3
 
-DEFAULT = ["nt:655360x1024x512", "nn:655360x512x1024", "tn:1024x512x655360", "nt:40960x2048x3136",
+DEFAULT = ["tn:512x64x1310720", "nt:655360x1024x512", "nn:655360x512x1024", "tn:1024x512x655360", "nt:40960x2048x3136",
            "nn:20480x3136x2048", "tn:2048x3136x20480", "nt:1000x300x64", "nn:777x260x48", "tn:300x260x4112"]
 
 
@@ -102,10 +102,12 @@ def main():
             t3 = timed(lambda: gemm3.gemm(layout, a, b, out=out), reps)
             tl = timed(lib, reps)
             if layout != gemm3.TN:
+                gemm3._PRESPLIT = True
                 ps = gemm3.gemm(layout, a, b, weight_b=True)
                 rec["presplit_bit_identical"] = bool(torch.equal(ps, out))
                 tp = timed(lambda: gemm3.gemm(layout, a, b, out=out, weight_b=True), reps)
                 rec.update(ms_presplit_b=round(tp, 4), tflops_presplit_b=round(flop / tp / 1e9, 1))
+                gemm3._PRESPLIT = False
             rec.update(ms_gemm3=round(t3, 4), ms_lib_f32=round(tl, 4), tflops_gemm3=round(flop / t3 / 1e9, 1),
                        tflops_lib=round(flop / tl / 1e9, 1), frac_of_bf16x6_peak=round(flop / t3 / 1e9 / 416.7, 3))
         print(json.dumps(rec), flush=True)
