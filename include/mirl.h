@@ -531,6 +531,17 @@ int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
  *   mirl_gemm3_ps[_mul]   C = A[M][K] . planes^T (+ bias, ReLU[, x multiplier rows as mirl_gemm3_nt_mul]): the same tiles,
  *                         the same six part products in the same order as mirl_gemm3 — bit-identical results
  *                         (tests/test_gemm3_gpu.py) — minus the B half of the split work in the loop.                  */
+/* A wide layer and the NARROW layer that follows it in one pass over the activation: next to C = relu(A . B^T + bias)
+ * (NT form of mirl_gemm3; C may be NULL when the activation itself is not needed again — the no-grad passes) the launch
+ * produces out2[row][o] = bias2[o] + sum_n C[row][n] * w2[o][n] for o < O <= 8 output units: the dueling head's advantage
+ * and value outputs (policies/torch/dqn.py:101-112,50-66) from the epilogue of the joint hidden layer's product, instead
+ * of two library GEMMs re-reading the (rows, 1024) activation.  w2 is float [8][N] (rows >= O zero-filled), bias2 [O] or
+ * NULL, out2 rows ldo floats apart; workspace = mirl_gemm3_head_workspace_bytes(M, N) bytes, 16-byte aligned (per-row
+ * partial sums of every 64-column block, reduced in a fixed order by a second small launch: deterministic).            */
+int mirl_gemm3_head_workspace_bytes(int64_t M, int64_t N, int64_t* bytes);
+int mirl_gemm3_nt_head(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, const float* bias, int32_t relu, const float* w2, int32_t O,
+                       const float* bias2, float* out2, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
 int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes);
 int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes, void* stream);
 int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,

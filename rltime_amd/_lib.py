@@ -174,6 +174,8 @@ _SIGNATURES = {
     "mirl_gemm3_workspace_bytes": [_i32, _i64, _i64, _i64, _P(_i64)],
     "mirl_gemm3": [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp],
     "mirl_gemm3_nt_mul": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
+    "mirl_gemm3_head_workspace_bytes": [_i64, _i64, _P(_i64)],
+    "mirl_gemm3_nt_head": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp],
     "mirl_gemm3_presplit_bytes": [_i64, _i64, _P(_i64)],
     "mirl_gemm3_presplit": [_i64, _i64, _vp, _i64, _i64, _vp, _vp],
     "mirl_gemm3_ps": [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp],

@@ -56,6 +56,9 @@ struct G3Args {
   const float* mul; int64_t ldmul; int mul_shift;
   float* pre; int64_t ldpre;
   int vec_ok;            // 16-byte stores possible: N % 4 == 0, every output / bias / multiplier row 16-byte aligned
+  // epilogue extension EP == 2 (NT): the O <= 8 output units that FOLLOW this layer, out[row][o] = sum_n f(...)[row][n] * w2[o][n],
+  // as partial sums per 64-column block: part[(col / 64)][row][8]; C may then be null (the activation itself is not stored)
+  const float* w2; float* part;
   const char* Bps;       // B operand already split (mirl_gemm3_presplit): rows of K/16 blocks of [hi 16 | mid 16 | lo 16] bf16
 };
 
@@ -297,6 +300,32 @@ k_gemm3(G3Args g) {
     if (VEC) {
       float* tl = reinterpret_cast<float*>(g3_lds) + wu * (64 * G3_EPITCH);
       constexpr int HALVES = NARROW ? 1 : 2, II = NARROW ? 1 : 2, QN = NARROW ? 8 : 16;     // NARROW: one 32-row block per wave
+      float* w2l = reinterpret_cast<float*>(g3_lds) + 8 * (64 * G3_EPITCH);                 // EP 2: w2[8][256] of this tile's columns, 8 KB
+      float bj[2] = {0.f, 0.f};
+      if (EP == 2) {
+        // the following layer's weights for this tile's 256 columns -> the 8 KB of LDS behind the transposition areas
+        // (one 16-byte vector per thread: o = t >> 6, columns 4 (t & 63) ..); visible after the barrier below
+        const int64_t wc = n0 + (t & 63) * 4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wc < g.N) w = *reinterpret_cast<const float4*>(g.w2 + (int64_t)(t >> 6) * g.N + wc);
+        *reinterpret_cast<float4*>(w2l + (t >> 6) * 256 + (t & 63) * 4) = w;
+        // bias + ReLU go in BEFORE the transposition here (a lane owns columns wn 64 + 32 j + (lane & 31) of its tiles)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t cj = n0 + wn * 64 + j * 32 + (lane & 31);
+          bj[j] = (g.bias && cj < g.N) ? g.bias[cj] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[i][j][r] + bj[j];
+              acc[i][j][r] = (g.relu && !(v > 0.f)) ? 0.f : v;
+            }
+        g3_barrier();
+      }
 #pragma unroll
       for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
@@ -310,14 +339,65 @@ k_gemm3(G3Args g) {
         const int c4 = lane & 15;
         const int64_t col = n0 + wn * 64 + c4 * 4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.bias && col < g.N) {      // N % 4 == 0 on this path
+        if (EP != 2 && g.bias && col < g.N) {      // N % 4 == 0 on this path
           bv = *reinterpret_cast<const float4*>(g.bias + col);
         }
+        if (EP == 2) {
+          // out[row][o] += sum over this wave's 64 columns: lane = (rows rg + 16 i; columns 16 cq ..), two rows at a time
+          // (2 x 8 running sums: the other half's 64 accumulator registers are still live), data rows and weight vectors
+          // as 16-byte LDS reads (conflict-free: row pitch 68 floats puts the 16 lanes of a quarter on 64 different
+          // banks; a weight vector is one address per quarter), then a two-step butterfly over the four column quarters.
+          // 512 FMAs per lane and half: ~4 % of the tile's MFMA time.
+          const int rg = lane & 15, cq = lane >> 4;
+          const int64_t cb = (n0 >> 6) + wn;
+#pragma unroll 1
+          for (int ip = 0; ip < 2; ++ip) {
+            float ps[2][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int o = 0; o < 8; ++o) ps[i][o] = 0.f;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+              asm volatile("" ::: "memory");          // keep this column group's LDS reads inside its iteration (no hoisting:
+              float4 dv[2];                           //  128 invariant weight vectors would not fit the register file)
+#pragma unroll
+              for (int i = 0; i < 2; ++i) dv[i] = *reinterpret_cast<const float4*>(tl + (rg + 16 * (2 * ip + i)) * G3_EPITCH + cq * 16 + c * 4);
+#pragma unroll
+              for (int o = 0; o < 8; ++o) {
+                const float4 w = *reinterpret_cast<const float4*>(w2l + o * 256 + wn * 64 + cq * 16 + c * 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                  ps[i][o] = fmaf(dv[i].w, w.w, fmaf(dv[i].z, w.z, fmaf(dv[i].y, w.y, fmaf(dv[i].x, w.x, ps[i][o]))));
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int o = 0; o < 8; ++o) {
+                float v = ps[i][o];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                ps[i][o] = v;
+              }
+            if (cq == 0) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                const int64_t row = m0 + row_w + h * 64 + rg + 16 * (2 * ip + i);
+                if (row < g.M) {
+                  float* d = g.part + (cb * g.M + row) * 8;
+                  *reinterpret_cast<float4*>(d) = make_float4(ps[i][0], ps[i][1], ps[i][2], ps[i][3]);
+                  *reinterpret_cast<float4*>(d + 4) = make_float4(ps[i][4], ps[i][5], ps[i][6], ps[i][7]);
+                }
+              }
+            }
+          }
+        }
         // IQN feature product (iqn.py:84,102): the row group r >> mul_shift (one state's quantile rows) shares one row of
-        // `mul`.  A lane's 16 rows of this half are q * 4 + (lane >> 4): with groups of 2^s >= 4 rows they fall into at most
-        // 64 >> s groups; with s >= 5 (32 quantiles per state, the shipped IQN configs) that is two multiplier vectors per
-        // lane and half, fetched before the first store goes out — one dependent global load per output vector (16 per
-        // half, each an L2 round trip in front of its store) kept the K = 64 product at a third of the HBM rate.
+        // `mul`.  A lane's 16 rows of this half are q * 4 + (lane >> 4): with groups of 2^s >= 32 rows (32 quantiles per
+        // state, the shipped IQN configs) that is two multiplier vectors per lane and half, fetched before the first store
+        // goes out instead of one dependent global load per output vector (measured: 1.19 -> 1.16 ms only — the K = 64
+        // product is bound by its serialised load -> split -> MFMA -> store phases per tile).
         float4 mg0 = make_float4(0.f, 0.f, 0.f, 0.f), mg1 = mg0;
         const bool hoisted = EP == 1 && g.mul_shift >= 5;   // groups of >= 32 rows: at most two per 64-row half
         if (EP == 1 && hoisted) {
@@ -332,10 +412,13 @@ k_gemm3(G3Args g) {
         for (int q = 0; q < QN; ++q) {
           const int rl = q * 4 + (lane >> 4);
           const int64_t row = m0 + row_w + h * 64 + rl;
+          if (EP == 2 && !g.C) break;               // no-grad pass: only the following layer's outputs leave the kernel
           float4 v = *reinterpret_cast<const float4*>(tl + rl * G3_EPITCH + c4 * 4);
           if (row < g.M && col < g.N) {
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (g.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            if (EP != 2) {
+              v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+              if (g.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            }
             if (EP == 1) {
               if (g.pre) __builtin_nontemporal_store(g3_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<g3_f32x4*>(g.pre + row * g.ldpre + col));
               float4 m;
@@ -393,6 +476,27 @@ k_gemm3_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t
   }
 }
 
+// out[row][o] = bias2[o] + sum over the 64-column blocks of part[cb][row][o], o < O <= 8 (fixed order: deterministic)
+__global__ void __launch_bounds__(256)
+k_g3_head_reduce(const float* __restrict__ part, int ncb, int64_t M, int O, const float* __restrict__ bias2,
+                 float* __restrict__ out, int64_t ldo) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M * 2; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i >> 1;
+    const int half = (int)(i & 1);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = 0; cb < ncb; ++cb) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)cb * M + row) * 8 + half * 4);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const float r[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = half * 4 + e;
+      if (o < O) out[row * ldo + o] = r[e] + (bias2 ? bias2[o] : 0.f);
+    }
+  }
+}
+
 static int g3_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
   int64_t s = 8 * ((256 + 8 * tiles - 1) / (8 * tiles));      // tiles * splits >= 256 workgroups, splits % 8 == 0
@@ -425,7 +529,7 @@ extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, 
 static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
                      int64_t workspace_bytes, const float* mul, int64_t ldmul, int32_t mul_shift, float* pre, int64_t ldpre,
-                     void* stream, const void* b_planes = nullptr) {
+                     void* stream, const void* b_planes = nullptr, const float* w2 = nullptr, float* part = nullptr) {
   using namespace mirl;
   if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
   if (b_planes) {
@@ -434,7 +538,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     if ((uintptr_t)b_planes % 16) return fail(MIRL_ERR_ARG, "gemm3: pre-split planes must be 16-byte aligned");
     B = reinterpret_cast<const float*>(b_planes); ldb = K; layout = 0;
   }
-  if (!A || !B || !C) return fail(MIRL_ERR_ARG, "gemm3: null operand");
+  if (!A || !B || (!C && !w2)) return fail(MIRL_ERR_ARG, "gemm3: null operand");
   const bool akc = layout != 2, bkc = layout == 0;
   if (akc && ((lda % 4) || ((uintptr_t)A % 16) || lda < K)) return fail(MIRL_ERR_ARG, "gemm3: A must be 16-byte aligned with lda % 4 == 0");
   if (bkc && ((ldb % 4) || ((uintptr_t)B % 16) || ldb < K)) return fail(MIRL_ERR_ARG, "gemm3: B must be 16-byte aligned with ldb % 4 == 0");
@@ -448,8 +552,9 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
   g.Bps = reinterpret_cast<const char*>(b_planes);
+  g.w2 = w2; g.part = part;
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
-  g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!bias || !((uintptr_t)bias % 16)) &&
+  g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!w2 || !((uintptr_t)w2 % 16)) && (!bias || !((uintptr_t)bias % 16)) &&
              (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));
   g.mt = (int)((M + 255) / 256); g.nt = (int)((N + 255) / 256);
   g.splits = 1; g.steps_per_split = (int)(K / 16);
@@ -488,6 +593,11 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                             {(const void*)k_gemm3<true, true, 1, false, true>, (const void*)k_gemm3<true, true, 1, true, true>}};
     fn = ps[mul ? 1 : 0][vec];
     if (!ps_attr[mul ? 1 : 0][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); ps_attr[mul ? 1 : 0][vec] = true; }
+  } else if (w2) {
+    if (!vec || layout != 0 || mul || !part) return fail(MIRL_ERR_ARG, "gemm3: the fused following layer needs the NT form with 16-byte aligned rows");
+    static bool hd_attr = false;
+    fn = (const void*)k_gemm3<true, true, 2, true>;
+    if (!hd_attr) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); hd_attr = true; }
   } else if (layout == 2 && N <= 64 && narrow_env) {
     // weight gradient of a narrow layer: eight waves stacked along M, 12 MFMAs per K-step (k_gemm3 NARROW)
     static bool nr_attr[2] = {false, false};
@@ -501,7 +611,8 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     // HBM bytes: both operands read once, the result (and the pre-product embedding / the multiplier rows) written / read once
     double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
     if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N);
-    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
+    if (w2) bytes += 4.0 * (8.0 * (double)N + 8.0 * (double)M * (double)((N + 63) / 64)) - (C ? 0.0 : 4.0 * (double)M * N);
+    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop + (w2 ? 16.0 * (double)M * N : 0.0));
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
@@ -562,4 +673,38 @@ extern "C" int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A
   if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
     return fail(MIRL_ERR_ARG, "gemm3_ps_mul: bad multiplier / pre-activation arguments");
   return g3_launch(0, M, N, K, A, lda, nullptr, K, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream, b_planes);
+}
+
+// ---- a wide layer and the narrow one that follows it, in one pass over the activation ----------------------------
+// out2[row][o] = bias2[o] + sum_n relu(A . B^T + bias)[row][n] * w2[o][n], o < O <= 8: the dueling head's advantage and
+// value OUTPUT layers (policies/torch/dqn.py:101-112, 50-66: A + 1 units) computed in the epilogue of the joint hidden
+// layer's product, so that the (rows, 1024) hidden activation is not read back by two more GEMMs — and, in the no-grad
+// passes (C == NULL), not written at all.  w2 is [8][N] (rows >= O zero); `part` holds 8 floats per row and 64-column
+// block: mirl_gemm3_head_workspace_bytes.
+extern "C" int mirl_gemm3_head_workspace_bytes(int64_t M, int64_t N, int64_t* bytes) {
+  if (!bytes || M < 1 || N < 1) return mirl::fail(MIRL_ERR_ARG, "bad gemm3_head_workspace_bytes arguments");
+  *bytes = 8 * (int64_t)sizeof(float) * M * ((N + 255) / 256 * 4);
+  return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3_nt_head(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                  float* C, int64_t ldc, const float* bias, int32_t relu, const float* w2, int32_t O,
+                                  const float* bias2, float* out2, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  using namespace mirl;
+  int64_t need = 0;
+  if (O < 1 || O > 8 || !w2 || !out2 || ldo < O || !workspace || mirl_gemm3_head_workspace_bytes(M, N, &need) || workspace_bytes < need ||
+      ((uintptr_t)workspace % 16) || (N % 4))
+    return fail(MIRL_ERR_ARG, "bad gemm3_nt_head arguments (1 <= O <= 8, N % 4 == 0, 16-byte aligned workspace of head_workspace_bytes)");
+  if (!C) ldc = N;
+  int rc = g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream, nullptr, w2,
+                     (float*)workspace);
+  if (rc) return rc;
+  const int ncb = (int)((N + 255) / 256 * 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("k_g3_head_reduce", 4.0 * (8.0 * ncb + O) * (double)M, st);
+  unsigned grid = (unsigned)((2 * M + 255) / 256); if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(k_g3_head_reduce, dim3(grid), dim3(256), 0, st, (const float*)workspace, ncb, M, (int)O, bias2, out2, ldo);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
 }

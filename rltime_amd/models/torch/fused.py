@@ -353,11 +353,21 @@ class _DuelingTail(torch.autograd.Function):
     dx with one GEMM instead of two GEMMs and an add."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, wo, bo, wv, bv, wq, bq):
+    def forward(ctx, x, w1, b1, wo, bo, wv, bv, wq, bq, track=True):
         h1 = w1.shape[0]
-        both = gemm3.linear_fwd(x, gemm3.joint_rows((w1, wv)), gemm3.joint_rows((b1, bv)), relu=True)
-        a = torch.addmm(bo, both[:, :h1], wo.t())
-        v = torch.addmm(bq, both[:, h1:], wq.t())
+        wj, bj = gemm3.joint_rows((w1, wv)), gemm3.joint_rows((b1, bv))
+        na, nv = wo.shape[0], wq.shape[0]
+        w2 = gemm3.joint_blockdiag((wo, wq)) if (na + nv <= 8 and wo.shape[1] == h1) else None
+        if w2 is not None and gemm3.head_supported(x, wj, bj, w2):
+            # both output layers in the epilogue of the joint hidden layer's product (csrc/gemm3.hip EP 2): the
+            # (rows, H1 + Hv) activation is not read back by two more GEMMs and, when no backward follows, never stored
+            keep = bool(track) and any(ctx.needs_input_grad)
+            both, out = gemm3.linear_relu_head(x, wj, bj, w2, gemm3.joint_rows((bo, bq)), keep)
+            a, v = out[:, :na], out[:, na:]
+        else:
+            both = gemm3.linear_fwd(x, wj, bj, relu=True)
+            a = torch.addmm(bo, both[:, :h1], wo.t())
+            v = torch.addmm(bq, both[:, h1:], wq.t())
         ctx.h1 = h1
         ctx.save_for_backward(x, w1, wo, wv, wq, both)
         return a, v
@@ -424,13 +434,14 @@ class _DuelingTail(torch.autograd.Function):
         else:
             dwo = ga.t().mm(both[:, :h1])
             dwq = gv.t().mm(both[:, h1:])
-        return dx, dw1, db[:h1], dwo, ga.sum(0), dwv, db[h1:], dwq, gv.sum(0)
+        return dx, dw1, db[:h1], dwo, ga.sum(0), dwv, db[h1:], dwq, gv.sum(0), None
 
 
 def dueling_tail(x, fc, out_layer, value_hidden, value_layer):
     """-> (advantage outputs, value outputs) for nn.Linear modules; x 2-D."""
     if x.dim() == 2 and _fusable(x, fc.weight) and x.is_contiguous():
         return _DuelingTail.apply(x, fc.weight, fc.bias, out_layer.weight, out_layer.bias,
-                                  value_hidden.weight, value_hidden.bias, value_layer.weight, value_layer.bias)
+                                  value_hidden.weight, value_hidden.bias, value_layer.weight, value_layer.bias,
+                                  torch.is_grad_enabled())
     h = F.relu(fc(x))
     return out_layer(h), value_layer(F.relu(value_hidden(x)))

@@ -233,3 +233,68 @@ def quantile_product(x, phi, weight, bias, n, keep_embedding):
                                     _p(bias), 1, _p(x), x.stride(0), n.bit_length() - 1,
                                     _p(emb) if emb is not None else None, N, _stream()), "mirl_gemm3_nt_mul")
     return out, emb
+
+
+# ---- a wide layer + the narrow layer behind it in one pass (csrc/gemm3.hip mirl_gemm3_nt_head) ---------------------
+_HEAD = os.environ.get("MIRL_GEMM3_HEAD", "1") != "0"
+
+
+def head_supported(x, w, bias, w2):
+    """relu(x @ w^T + bias) followed by <= 8 output units w2 (O, N): can both run as ONE NT launch?"""
+    return (_HEAD and enabled() and supported(NT, x, w) and bias is not None and bias.is_contiguous() and bias.dtype == torch.float32
+            and w.shape[0] % 4 == 0 and _rowmajor(w2) and w2.is_contiguous() and w2.shape[1] == w.shape[0] and 1 <= w2.shape[0] <= 8)
+
+
+def linear_relu_head(x, w, bias, w2, bias2, keep_hidden):
+    """-> (hidden = relu(x @ w^T + bias) or None, out = hidden @ w2^T + bias2).  keep_hidden=False: the hidden
+    activation never reaches HBM."""
+    L = _lib()
+    M, K, N, O = x.shape[0], x.shape[1], w.shape[0], w2.shape[0]
+    pad = joint_pad8(w2)
+    hidden = torch.empty((M, N), dtype=torch.float32, device=x.device) if keep_hidden else None
+    out = torch.empty((M, O), dtype=torch.float32, device=x.device)
+    need = C.c_int64()
+    L.check(L.lib.mirl_gemm3_head_workspace_bytes(M, N, C.byref(need)), "mirl_gemm3_head_workspace_bytes")
+    ws = _workspace(x.device, need.value)
+    L.check(L.lib.mirl_gemm3_nt_head(M, N, K, _p(x), x.stride(0), _p(w), w.stride(0), _p(hidden) if hidden is not None else None, N,
+                                     _p(bias), 1, _p(pad), O, _p(bias2) if bias2 is not None else None, _p(out), O,
+                                     _p(ws), need.value, _stream()), "mirl_gemm3_nt_head")
+    return hidden, out
+
+
+_pad8 = {}
+
+
+def joint_pad8(w2):
+    """(O, N) -> persistent zero-padded (8, N) copy, refreshed when w2's version counter moves."""
+    key = (w2.data_ptr(), tuple(w2.shape))
+    hit = _pad8.get(key)
+    if hit is not None and hit[0] == w2._version and hit[2].untyped_storage().data_ptr() == w2.untyped_storage().data_ptr():
+        return hit[1]
+    with torch.no_grad():
+        pad = hit[1] if hit is not None else torch.zeros((8, w2.shape[1]), dtype=torch.float32, device=w2.device)
+        pad[:w2.shape[0]].copy_(w2.detach())
+    if len(_pad8) > 32:
+        _pad8.clear()
+    _pad8[key] = (w2._version, pad, w2.detach())
+    return pad
+
+
+def joint_blockdiag(blocks):
+    """Block-diagonal stack of long-lived weights [(O_i, N_i)] -> persistent (sum O_i, sum N_i) tensor (zeros elsewhere),
+    refreshed when a source's version counter moves: the dueling head's [advantage | value] output weights over the joint
+    [last FC | value-hidden] activation."""
+    key = tuple(t.data_ptr() for t in blocks)
+    vers = tuple(t._version for t in blocks)
+    hit = _joint.get(("bd",) + key)
+    if hit is not None and hit[0] == vers:
+        return hit[1]
+    with torch.no_grad():
+        out = hit[1] if hit is not None else torch.zeros((sum(t.shape[0] for t in blocks), sum(t.shape[1] for t in blocks)),
+                                                          dtype=torch.float32, device=blocks[0].device)
+        r = c = 0
+        for t in blocks:
+            out[r:r + t.shape[0], c:c + t.shape[1]].copy_(t.detach())
+            r, c = r + t.shape[0], c + t.shape[1]
+    _joint[("bd",) + key] = (vers, out, blocks)
+    return out

@@ -280,3 +280,73 @@ def test_presplit_planes_follow_in_place_weight_updates(monkeypatch):
     assert torch.equal(j0[:, :320], y1) and torch.equal(j1[:, :320], y1)
     assert torch.equal(j1[:, 320:], gemm3.gemm(0, x, w2.detach()))
     assert calls.get("k_g3_presplit") == 5, calls              # w, w2, w again, joint, joint again — not one per product
+
+
+@pytest.mark.parametrize("M,N,K,O", [(256, 256, 16, 1), (1000, 512, 64, 7), (777, 1024, 512, 7), (4099, 300, 128, 8), (33, 68, 32, 3)])
+def test_fused_following_layer_matches_two_products(M, N, K, O, monkeypatch):
+    """mirl_gemm3_nt_head: hidden = relu(x W^T + b) and out = hidden W2^T + b2 (O <= 8 units) from ONE launch + a
+    fixed-order reduction — the dueling head's output layers in the epilogue of the joint hidden layer
+    (policies/torch/dqn.py:50-66,101-112).  Integer operands: hidden and out bit-exact; real operands: hidden
+    bit-identical to mirl_gemm3's, out within 1e-5 of the float64 product of that same hidden activation; without the
+    stored activation (the no-grad passes) the same outputs; ragged row / column tiles."""
+    from rltime_amd.models.torch import gemm3
+    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K + O)
+    xi = torch.randint(-4, 5, (M, K), device="cuda", generator=gen).float()
+    wi = torch.randint(-4, 5, (N, K), device="cuda", generator=gen).float()
+    bi = torch.randint(-8, 9, (N,), device="cuda", generator=gen).float()
+    w2i = torch.randint(-2, 3, (O, N), device="cuda", generator=gen).float()
+    b2i = torch.randint(-3, 4, (O,), device="cuda", generator=gen).float()
+    assert gemm3.head_supported(xi, wi, bi, w2i)
+    hid, out = gemm3.linear_relu_head(xi, wi, bi, w2i, b2i, True)
+    want_h = torch.relu(xi.double() @ wi.double().t() + bi.double())
+    want_o = want_h @ w2i.double().t() + b2i.double()
+    assert float(want_o.abs().max()) < 2 ** 24
+    assert torch.equal(hid.double(), want_h) and torch.equal(out.double(), want_o)
+    none, out2 = gemm3.linear_relu_head(xi, wi, bi, w2i, b2i, False)
+    assert none is None and torch.equal(out2, out)
+    # real operands
+    x = torch.randn(M, K, device="cuda", generator=gen)
+    w = torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=gen) * 0.1
+    w2 = torch.randn(O, N, device="cuda", generator=gen) / N ** 0.5
+    b2 = torch.randn(O, device="cuda", generator=gen) * 0.1
+    hid, out = gemm3.linear_relu_head(x, w, b, w2, b2, True)
+    assert torch.equal(hid, gemm3.gemm(gemm3.NT, x, w, b, relu=True))
+    want = hid.double() @ w2.double().t() + b2.double()
+    assert float((out.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    _, out2 = gemm3.linear_relu_head(x, w, b, w2, b2, False)
+    assert torch.equal(out2, out)
+    a, c = gemm3.linear_relu_head(x, w, b, w2, b2, False)[1], gemm3.linear_relu_head(x, w, b, w2, b2, False)[1]
+    assert torch.equal(a, c)                                     # fixed reduction order: bit-reproducible
+
+
+def test_dueling_tail_with_and_without_the_fused_output_layers(monkeypatch):
+    """fused._DuelingTail with its two output layers in the epilogue of the joint hidden product (gemm3._HEAD) against
+    the same op with two library GEMMs over the stored activation: advantage / value outputs within 2e-5 of scale, every
+    gradient bit-identical (the backward reads the same stored activation), and the no-grad form (nothing stored) gives
+    the same outputs."""
+    from rltime_amd.models.torch import fused, gemm3
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    M, Fd, H, A = 8192 + 40, 512, 512, 6
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=gen)       # noqa: E731
+    x = mk(M, Fd)
+    params = [mk(H, Fd) / Fd ** 0.5, mk(H), mk(A, H) / H ** 0.5, mk(A), mk(H, Fd) / Fd ** 0.5, mk(H), mk(1, H) / H ** 0.5, mk(1)]
+    ga, gv = mk(M, A), mk(M, 1)
+    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    out = {}
+    for head in (True, False):
+        monkeypatch.setattr(gemm3, "_HEAD", head)
+        xx = x.clone().requires_grad_(True)
+        pp = [p.clone().requires_grad_(True) for p in params]
+        a, v = fused._DuelingTail.apply(xx, *pp)
+        torch.autograd.backward([a, v], [ga, gv])
+        with torch.no_grad():
+            a0, v0 = fused._DuelingTail.apply(xx, *pp, False)
+        out[head] = [a.detach().clone(), v.detach().clone(), a0.clone(), v0.clone(), xx.grad] + [p.grad for p in pp]
+    for i, (got, ref) in enumerate(zip(out[True], out[False])):
+        if i < 4:
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), i
+        else:
+            assert torch.equal(got, ref), i
+    assert torch.equal(out[True][0], out[True][2]) and torch.equal(out[True][1], out[True][3])
