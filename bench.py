@@ -106,6 +106,8 @@ def parse():
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
+    ap.add_argument("--cpu-linearity-check", action="store_true", help="cpu_baseline: one extra 1-thread learner step at B=64 (~20 s) "
+                    "to check the linear-in-B extrapolation from B=16 that the headline cpu_baseline figure uses")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen benchmarks its solvers "
                     "per conv shape instead of taking the immediate-mode pick (experiment)")
@@ -364,6 +366,13 @@ def cpu_baseline(args, seconds):
         all_s, all_spent = s2, all_spent + sp2
         all_b.update(b2)
     torch.set_num_threads(1)
+    linearity = None
+    if getattr(args, "cpu_linearity_check", False):
+        t1 = time.time()
+        learner_step(64)
+        t64 = time.time() - t1
+        linearity = {"B": 64, "seconds": t64, "B16_median_x4": one_b[16][1] * 4 if 16 in one_b else None,
+                     "ratio_to_linear_extrapolation": (t64 / (one_b[16][1] * 4)) if 16 in one_b else None}
     act_rate = cpu.acting_rate()
     acted_per_step = B_full * T / 4                        # train_frequency=4
     extra = acted_per_step / ingest_rate + acted_per_step / act_rate
@@ -375,6 +384,7 @@ def cpu_baseline(args, seconds):
         "learner_steps_per_sec": 1.0 / (one_s + extra),
         "host_nproc": nproc,
         "runs": {str(b): {"min_s": mn, "median_s": md, "runs": k} for b, (mn, md, k) in sorted(one_b.items())},
+        "linearity_check": linearity,
         "all_cores": {"value": B_full * T / (all_s + extra), "unit": "transitions/s", "cores": many, "usable_cores": usable,
                       "learner_steps_per_sec": 1.0 / (all_s + extra),
                       "sample": "same oracle path with torch.set_num_threads(%d): %s, scaled x%d to B=512; acting/ingest shares as in the 1-thread leg"
@@ -464,7 +474,7 @@ def copy_peak(device, stream_ptr_fn):
 #   bf16x6  six exact-split bf16 MFMAs per f32 product block (csrc/gemm3.hip, conv3.hip)  -> 2.5 PF / 6
 #   bf16x3  uint8 pixel x three-way split weight (csrc/conv_in.hip forward)                 -> 2.5 PF / 3
 #   f32     v_mfma_f32_16x16x4_f32 (input layer's weight gradient, layer 2's data gradient, LSTM sweeps)
-PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
+PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nt_head": "bf16x6", "k_gemm3_ps": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
            "k_conv1_u8_fwd": "bf16x3", "k_conv1_u8_wrw": "f32", "k_conv2_bwd_data": "f32",
            "k_lstm_seq_fwd": "f32", "k_lstm_seq_bwd": "f32", "k_lstm_step_fwd": "f32"}
 # launch / dependency-latency bound by construction (one workgroup of bookkeeping, one tree level per barrier, 256-row

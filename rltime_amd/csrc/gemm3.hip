@@ -612,7 +612,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
     if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N);
     if (w2) bytes += 4.0 * (8.0 * (double)N + 8.0 * (double)M * (double)((N + 63) / 64)) - (C ? 0.0 : 4.0 * (double)M * N);
-    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop + (w2 ? 16.0 * (double)M * N : 0.0));
+    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }

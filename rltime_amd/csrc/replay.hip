@@ -1844,9 +1844,43 @@ extern "C" int mirl_replay_losses_peek(mirl_replay* h, int32_t env_local, int64_
   return MIRL_OK;
 }
 
+// experiment variants of the plain copy (tools/copy_probe.py: where do the ~10 % between this box's 5.7 TB/s and the
+// guide's 6.29 TB/s float4 copy go?): PER 16-byte vectors per lane, all loads issued before the first store;
+// NTL / NTS: non-temporal loads / stores
+template <int PER, bool NTL, bool NTS>
+__global__ void __launch_bounds__(256) k_copy16_v(u32x4* __restrict__ dst, const u32x4* __restrict__ src, int64_t n) {
+  const int64_t base = (int64_t)blockIdx.x * (256 * PER) + threadIdx.x;
+  u32x4 v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t i = base + (int64_t)k * 256;
+    if (i < n) v[k] = NTL ? __builtin_nontemporal_load(src + i) : src[i];
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t i = base + (int64_t)k * 256;
+    if (i < n) { if (NTS) __builtin_nontemporal_store(v[k], dst + i); else dst[i] = v[k]; }
+  }
+}
+
 extern "C" int mirl_copy_bytes_ex(void* dst, const void* src, int64_t bytes, int32_t nt, void* stream) {
   if (!dst || !src || bytes <= 0 || (bytes % 16) || ((uintptr_t)dst % 16) || ((uintptr_t)src % 16)) return fail(MIRL_ERR_ARG, "copy needs 16-byte aligned pointers and size");
   const int64_t n = bytes / 16;
+  hipStream_t cs = (hipStream_t)stream;
+  if (nt >= 2) {
+    const unsigned g8 = (unsigned)((n + 256 * 8 - 1) / (256 * 8)), g4 = (unsigned)((n + 256 * 4 - 1) / (256 * 4)), g2 = (unsigned)((n + 256 * 2 - 1) / (256 * 2));
+    switch (nt) {
+      case 2: hipLaunchKernelGGL((k_copy16_v<8, true, true>), dim3(g8), dim3(256), 0, cs, (u32x4*)dst, (const u32x4*)src, n); break;
+      case 3: MIRL_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, cs)); return MIRL_OK;
+      case 4: hipLaunchKernelGGL((k_copy16_v<4, false, true>), dim3(g4), dim3(256), 0, cs, (u32x4*)dst, (const u32x4*)src, n); break;
+      case 5: hipLaunchKernelGGL((k_copy16_v<4, false, false>), dim3(g4), dim3(256), 0, cs, (u32x4*)dst, (const u32x4*)src, n); break;
+      case 6: hipLaunchKernelGGL((k_copy16_v<2, true, true>), dim3(g2), dim3(256), 0, cs, (u32x4*)dst, (const u32x4*)src, n); break;
+      case 7: hipLaunchKernelGGL((k_copy16_v<8, false, false>), dim3(g8), dim3(256), 0, cs, (u32x4*)dst, (const u32x4*)src, n); break;
+      default: return fail(MIRL_ERR_ARG, "copy: unknown variant");
+    }
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
   if (nt) hipLaunchKernelGGL(k_copy16_nt, dim3((unsigned)((n + 2047) / 2048)), dim3(512), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
   else hipLaunchKernelGGL(k_copy16, dim3(2048), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, n);
   MIRL_LAUNCH_CHECK();
