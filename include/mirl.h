@@ -471,6 +471,13 @@ int mirl_conv1_u8_wrw(int64_t N, int32_t H, int32_t W, const uint8_t* x, const f
 int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, float scale,
                          float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
                          int32_t flags, void* stream);
+/* The same weight gradient straight from the gradient w.r.t. the layer's OUTPUT: dy is masked by the forward output
+ * (y > 0: the layer's ReLU, cnn.py:47-49) while it is loaded and db[32] receives the masked gradient's column sums (the
+ * bias gradient) from the same pass — no separate mask / bias-gradient pass over the (N, OH, OW, 32) block.  dy and y in
+ * the forward's NHWC layout; scratch as for mirl_conv1_u8_wrw.                                                          */
+int mirl_conv1_u8_wrw_masked(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* dy, const float* y, float scale,
+                             float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                             float* db, void* stream);
 
 /* ---- data gradient of the second conv layer (csrc/conv_mid.hip).  For the backward
  * autograd derives for `F.relu(conv(x))` (rltime/models/torch/modules/cnn.py:47-49) at
@@ -662,11 +669,11 @@ int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, co
                    int32_t* action_counts, uint64_t* rng_step, uint64_t step, void* stream);
 /* One step of the synthetic Atari-shaped vector env of the benchmark (i.i.d. uint8 frames from a
  * pre-generated pool, rewards in {-1, 0, 1}, done with a fixed probability) decided entirely on the device:
- * step t = clock[0] + 1, obs [E][frame_bytes] <- pool[t % pool_n] (pool [pool_n][E][frame_bytes]), reward / done from one
- * Philox4x32-10 block per (seed, t, env) with cumulative reward probabilities p_neg <= p_nonpos; the launch's last
- * workgroup stores clock[0] = t.  `clock` is a 16-byte aligned, zero-initialised block of two 64-bit words (step
- * counter, arrival counter).  No host-side state: capturable into a rollout graph.                                  */
-int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock,
+ * step t = clock[slot] + 1, obs [E][frame_bytes] <- pool[t % pool_n] (pool [pool_n][E][frame_bytes]), reward / done from one
+ * Philox4x32-10 block per (seed, t, env) with cumulative reward probabilities p_neg <= p_nonpos; the launch stores
+ * clock[slot ^ 1] = t, so consecutive steps alternate `slot` (0, 1, 0, ...: host-tracked parity, fixed per position of a
+ * captured rollout).  `clock` is a 16-byte aligned block of two 64-bit words.  No host-side state otherwise.          */
+int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock, int32_t slot,
                         uint64_t seed, float p_neg, float p_nonpos, float p_done, uint8_t* obs, float* rewards,
                         uint8_t* dones, void* stream);
 int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,

@@ -165,6 +165,7 @@ _SIGNATURES = {
     "mirl_conv1_u8_fwd_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, C.c_float, _vp, _vp, _i32, _vp],
     "mirl_conv1_u8_wrw_scratch_floats": [_P(_i64)],
     "mirl_conv1_u8_wrw_ex": [_i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp],
+    "mirl_conv1_u8_wrw_masked": [_i64, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp],
     "mirl_conv1_u8_wrw": [_i64, _i32, _i32, _vp, _vp, C.c_float, _vp, _vp, _i64, _i64, _i64, _i64, _vp],
     "mirl_conv2_bwd_data_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv2_bwd_data": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
@@ -192,7 +193,7 @@ _SIGNATURES = {
     "mirl_actor_head": [_i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_stack_shift": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
-    "mirl_synth_env_step": [_i32, _i64, _vp, _i32, _vp, _u64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp],
+    "mirl_synth_env_step": [_i32, _i64, _vp, _i32, _vp, _i32, _u64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp],
     "mirl_actor_pre": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                        _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -344,7 +344,9 @@ class FastActingStep:
         """`iters` vector steps after reselect(): the first call of a shape captures them into ONE HIP graph, every call
         is a plan upload + a graph launch.  Identical results to the same launches issued one by one
         (tests/test_fast_acting_gpu.py)."""
-        key = (iters, bool(keep_policy), bool(clip), id(sink))
+        env = self.actor._vec_env
+        parity = env.clock_parity() if hasattr(env, "clock_parity") else 0
+        key = (iters, bool(keep_policy), bool(clip), id(sink), parity)     # a captured env step reads a fixed clock word
         state = self._rollouts.setdefault(key, [0, None])
         try:
             sink.plan_ingest(iters, self.E)      # refused calls leave the book untouched (checked before any bookkeeping)
@@ -358,7 +360,9 @@ class FastActingStep:
         # capture at the FIRST call of a shape: every kernel of the body has run before (the single-step graph's warm-ups,
         # reselect, the constructor's pre-step), so nothing is left to initialise inside the capture.
         # MIRL_ROLLOUT_EAGER_CALLS=n runs the first n calls eagerly instead (the same launches: debugging, A/B test)
+        captured_now = False
         if state[1] is None and state[0] > self.rollout_eager_calls:
+            captured_now = True
             keep_step = self.step_no
             graph = torch.cuda.CUDAGraph()
             with quiet_gc(), torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -368,6 +372,8 @@ class FastActingStep:
         if state[1] is not None:
             state[1].replay()
             self.step_no += iters
+            if not captured_now and hasattr(env, "skip_host"):
+                env.skip_host(iters)                 # (a capture has already walked the host-side parity through its steps)
         else:
             with torch.no_grad():
                 self._rollout_body(iters, sink, keep_policy, clip)

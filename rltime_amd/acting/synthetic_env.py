@@ -47,8 +47,10 @@ class SyntheticAtariVecEnv:
             if self.frame_stack else None
         cum = np.cumsum(reward_probs)
         self._p_neg, self._p_nonpos = float(cum[0]), float(cum[1])
-        # [step counter, arrival counter of the launch in flight] — device-resident, advanced by the kernel itself
+        # the step counter: a PAIR of device words read / written alternately (a launch reads clock[slot], writes
+        # clock[slot ^ 1]: no workgroup sees the new value, no atomics); the host only tracks the parity
         self._clock = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._slot = 0
 
     def reset(self):
         if self.frame_stack:
@@ -66,8 +68,18 @@ class SyntheticAtariVecEnv:
         """obs_out uint8 [E, ...frame], rewards_out float32 [E], dones_out uint8 [E] <- step t = clock + 1."""
         from rltime_amd._lib import lib, check
         check(lib.mirl_synth_env_step(self.num_envs, self._row_bytes, _p(self._pool), self._pool.shape[0], _p(self._clock),
-                                      self.seed, self._p_neg, self._p_nonpos, self.done_prob, _p(obs_out), _p(rewards_out),
-                                      _p(dones_out), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "mirl_synth_env_step")
+                                      self._slot, self.seed, self._p_neg, self._p_nonpos, self.done_prob, _p(obs_out),
+                                      _p(rewards_out), _p(dones_out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "mirl_synth_env_step")
+        self._slot ^= 1
+
+    def clock_parity(self):
+        """Which word of the clock pair the NEXT step reads: part of the identity of a captured rollout."""
+        return self._slot
+
+    def skip_host(self, steps):
+        """`steps` steps were replayed from a captured graph: advance the host-side parity like step_into would have."""
+        self._slot ^= steps & 1
 
     def step_device(self, actions):
         E = self.num_envs
@@ -86,8 +98,9 @@ class SyntheticAtariVecEnv:
         """Odd frame sizes / CPU: the same process with torch ops (own generator stream; used by host-side tests only)."""
         if not hasattr(self, "_g"):
             self._g = torch.Generator(device=self.device).manual_seed(self.seed + 1)
-        self._clock[0] += 1
-        t = int(self._clock[0])
+        self._clock[self._slot ^ 1] = self._clock[self._slot] + 1
+        self._slot ^= 1
+        t = int(self._clock[self._slot])
         obs = self._pool[t % self._pool.shape[0]]
         u = torch.rand(2, self.num_envs, device=self.device, generator=self._g)
         rewards = torch.where(u[0] < self._p_neg, -1.0, torch.where(u[0] < self._p_nonpos, 0.0, 1.0)).float()
@@ -117,12 +130,13 @@ class SyntheticAtariVecEnv:
         return obs, rewards.double().cpu().numpy(), dones.cpu().numpy(), [dict() for _ in range(self.num_envs)]
 
     def get_state(self):
-        return {"t": int(self._clock[0].item()), "stack": None if self._stack is None else self._stack.cpu(),
+        return {"t": int(self._clock[self._slot].item()), "stack": None if self._stack is None else self._stack.cpu(),
                 "generator": self._g.get_state().cpu() if hasattr(self, "_g") else None}
 
     def set_state(self, state):
         self._clock.zero_()
         self._clock[0] = int(state["t"])
+        self._slot = 0
         if state.get("stack") is not None and self._stack is not None:
             self._stack = state["stack"].to(self.device)
         if state.get("generator") is not None:

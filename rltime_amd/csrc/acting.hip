@@ -155,54 +155,45 @@ k_stack_shift(int P, int plane_q, const uint4* __restrict__ in, uint4* __restric
 }
 
 // One step of the synthetic Atari-shaped vector env (acting/synthetic_env.py) with nothing decided on the host:
-// step number t = *clock + 1 (the env's device step counter, advanced by this launch's last workgroup), observation
+// step number t = clock[slot] + 1 (the env's device step counter: a pair of words read / written alternately), observation
 // = frame batch t % pool_n of a pre-generated pool copied into the env's static output block, reward in {-1, 0, 1} with
 // cumulative probabilities (p_neg, p_nonpos) and done with probability p_done from ONE Philox4x32-10 block per
 // (seed, t, env).  Capturable: every argument is the same for every replay.
 __global__ void __launch_bounds__(256)
-k_synth_env_step(int row_q, const uint4* __restrict__ pool, int pool_n, int64_t pool_stride_q, uint64_t* __restrict__ clock,
-                 unsigned* __restrict__ arrivals, uint64_t seed, float p_neg, float p_nonpos, float p_done,
+k_synth_env_step(int row_q, const uint4* __restrict__ pool, int pool_n, int64_t pool_stride_q, const uint64_t* __restrict__ clock_in,
+                 uint64_t* __restrict__ clock_out, uint64_t seed, float p_neg, float p_nonpos, float p_done,
                  uint4* __restrict__ obs, float* __restrict__ rewards, uint8_t* __restrict__ dones) {
   const int e = blockIdx.y;
-  __shared__ uint64_t t_sh;
-  if (threadIdx.x == 0) t_sh = __hip_atomic_load(clock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-  __syncthreads();
-  const uint64_t t = t_sh;
+  const uint64_t t = *clock_in + 1ull;                 // every workgroup reads the word nobody writes in this launch
   const uint4* src = pool + (int64_t)(t % (uint64_t)pool_n) * pool_stride_q + (int64_t)e * row_q;
   uint4* dst = obs + (int64_t)e * row_q;
   for (int c = blockIdx.x * 256 + threadIdx.x; c < row_q; c += gridDim.x * 256) dst[c] = src[c];
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) {
-      uint32_t r[4];
-      philox_4x32(seed ^ 0xE17ull, t, (uint32_t)e, r);
-      const float u0 = (float)(r[0] >> 8) * (1.0f / 16777216.0f), u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
-      rewards[e] = u0 < p_neg ? -1.0f : (u0 < p_nonpos ? 0.0f : 1.0f);
-      dones[e] = u1 < p_done ? 1 : 0;
-    }
-    // the env's own step counter advances once per launch: by the LAST workgroup to arrive — every workgroup has read
-    // the counter before it arrives, so nobody can see the new value
-    const unsigned total = gridDim.x * gridDim.y;
-    if (atomicAdd(arrivals, 1u) == total - 1u) {
-      *arrivals = 0u;
-      __hip_atomic_store(clock, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t r[4];
+    philox_4x32(seed ^ 0xE17ull, t, (uint32_t)e, r);
+    const float u0 = (float)(r[0] >> 8) * (1.0f / 16777216.0f), u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+    rewards[e] = u0 < p_neg ? -1.0f : (u0 < p_nonpos ? 0.0f : 1.0f);
+    dones[e] = u1 < p_done ? 1 : 0;
+    if (e == 0) *clock_out = t;                        // the OTHER word of the pair: the next launch reads it
   }
 }
 
 }  // namespace mirl
 
-extern "C" int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock,
+extern "C" int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock, int32_t slot,
                                    uint64_t seed, float p_neg, float p_nonpos, float p_done, uint8_t* obs, float* rewards,
                                    uint8_t* dones, void* stream) {
   if (E <= 0 || frame_bytes <= 0 || (frame_bytes % 16) || pool_n <= 0 || !pool || !clock || !obs || !rewards || !dones ||
-      ((uintptr_t)pool % 16) || ((uintptr_t)obs % 16) || ((uintptr_t)clock % 16))
-    return mirl::fail(MIRL_ERR_ARG, "bad synth_env_step arguments (16-byte aligned frame rows)");
+      (slot != 0 && slot != 1) || ((uintptr_t)pool % 16) || ((uintptr_t)obs % 16) || ((uintptr_t)clock % 16))
+    return mirl::fail(MIRL_ERR_ARG, "bad synth_env_step arguments (16-byte aligned frame rows, slot 0 | 1)");
   const int row_q = (int)(frame_bytes / 16);
   int gx = (row_q + 255) / 256; if (gx > 8) gx = 8;
   mirl::ProfScope ps("k_synth_env_step", 2.0 * (double)E * (double)frame_bytes, (hipStream_t)stream);
-  // clock block: [0] the step counter, [1] (as 32-bit word) the arrival counter of the launch in flight
+  // the step counter is a PAIR of words: this launch reads clock[slot] and writes clock[slot ^ 1] — no workgroup can see
+  // the new value, no atomics (a shared arrival counter cost 18 of the kernel's 25 us at 256 envs)
   hipLaunchKernelGGL(mirl::k_synth_env_step, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, row_q, (const uint4*)pool, (int)pool_n,
-                     (int64_t)E * row_q, clock, (unsigned*)(clock + 1), seed, p_neg, p_nonpos, p_done, (uint4*)obs, rewards, dones);
+                     (int64_t)E * row_q, (const uint64_t*)(clock + slot), clock + (slot ^ 1), seed, p_neg, p_nonpos, p_done,
+                     (uint4*)obs, rewards, dones);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

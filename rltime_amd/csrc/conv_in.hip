@@ -370,8 +370,13 @@ constexpr int C1_DW = C1_F * C1_PLANES * C1_TAPS;   // 8192 weight-gradient elem
       const int p_ = (ks0_ + w) * 4 + q;                                                        \
       const bool ok_ = p_ < OHW;                                                                \
       const int pc_ = ok_ ? p_ : OHW - 1;                                                       \
-      const float2 t_ = *reinterpret_cast<const float2*>(gf_ + pc_ * C1_F);                    \
+      float2 t_ = *reinterpret_cast<const float2*>(gf_ + pc_ * C1_F);                          \
+      if (MASK) {     /* g = dy where the forward output is positive (the layer's ReLU), its column sums = the bias gradient */ \
+        const float2 y_ = *reinterpret_cast<const float2*>(yv + (gf_ - g) + pc_ * C1_F);       \
+        t_.x = y_.x > 0.f ? t_.x : 0.f; t_.y = y_.y > 0.f ? t_.y : 0.f;                         \
+      }                                                                                         \
       gv_[w].x = ok_ ? t_.x : 0.f; gv_[w].y = ok_ ? t_.y : 0.f;                                 \
+      if (MASK) { dbx += gv_[w].x; dby += gv_[w].y; }                                           \
       const int oh_ = OW == 1 ? pc_ : (int)__umulhi((unsigned)pc_, ow_magic);                   \
       po_[w] = (oh_ * C1_S) * Wd + (pc_ - oh_ * OW) * C1_S;                                     \
     }                                                                                           \
@@ -392,10 +397,15 @@ constexpr int C1_DW = C1_F * C1_PLANES * C1_TAPS;   // 8192 weight-gradient elem
   }
 
 // WC / PC: frame width and LDS plane pitch as compile-time constants (0 = runtime)
-template <int FPI, int WC, int PC, int BULK = 0>
+// MASK: g is the gradient w.r.t. the layer's OUTPUT (after its ReLU) and yv the forward output: the ReLU mask is applied
+// while the operand is loaded and the bias gradient (column sums of the masked gradient) comes out of the same pass as
+// 32 more floats per slab — the separate mask + bias-gradient pass over the (frames, 20, 20, 32) block (three 2.2 GB
+// streams at config D) is not needed for this layer, whose input takes no gradient.
+template <int FPI, int WC, int PC, int BULK = 0, bool MASK = false>
 __global__ void __launch_bounds__(256, 2)
 k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch, const uint8_t* __restrict__ x,
-               const float* __restrict__ g, float* __restrict__ partial) {
+               const float* __restrict__ g, float* __restrict__ partial, const float* __restrict__ yv = nullptr, int slab = C1_DW) {
+  float dbx = 0.f, dby = 0.f;
   extern __shared__ __align__(16) uint8_t c1_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q = lane >> 4;
@@ -466,8 +476,21 @@ k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
     }
     __syncthreads();
   }
-  float* out = partial + (int64_t)blockIdx.x * C1_DW;
-  for (int k = tid; k < C1_DW; k += 256) out[k] = red[k];
+  if (MASK) {
+    // bias gradient: lane (j, q) summed filters 2j, 2j + 1 over its positions; the four q in a fixed butterfly, the
+    // four waves in wave order behind the slab's 8192 weight-gradient sums
+    dbx += __shfl_xor(dbx, 16); dbx += __shfl_xor(dbx, 32);
+    dby += __shfl_xor(dby, 16); dby += __shfl_xor(dby, 32);
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w && q == 0) {
+        red[C1_DW + 2 * j] = (w ? red[C1_DW + 2 * j] : 0.f) + dbx;
+        red[C1_DW + 2 * j + 1] = (w ? red[C1_DW + 2 * j + 1] : 0.f) + dby;
+      }
+      __syncthreads();
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * slab;
+  for (int k = tid; k < (MASK ? C1_DW + C1_F : C1_DW); k += 256) out[k] = red[k];
 }
 #undef C1_WRW_LOAD
 #undef C1_WRW_COMPUTE
@@ -475,16 +498,17 @@ k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
 // dw[f][c][kh][kw] (element strides so, sc, sh, sw) = scale * sum of the slabs in slab order
 __global__ void __launch_bounds__(256)
 k_conv1_wrw_reduce(const float* __restrict__ partial, int parts, float scale, float* __restrict__ dw, int64_t so, int64_t sc,
-                   int64_t sh, int64_t sw) {
+                   int64_t sh, int64_t sw, int slab = C1_DW, float* __restrict__ db = nullptr) {
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= C1_DW) return;
+  if (t >= C1_DW + (db ? C1_F : 0)) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int p = 0;
   for (; p + 4 <= parts; p += 4) {
-    s0 += partial[(int64_t)p * C1_DW + t]; s1 += partial[(int64_t)(p + 1) * C1_DW + t];
-    s2 += partial[(int64_t)(p + 2) * C1_DW + t]; s3 += partial[(int64_t)(p + 3) * C1_DW + t];
+    s0 += partial[(int64_t)p * slab + t]; s1 += partial[(int64_t)(p + 1) * slab + t];
+    s2 += partial[(int64_t)(p + 2) * slab + t]; s3 += partial[(int64_t)(p + 3) * slab + t];
   }
-  for (; p < parts; ++p) s0 += partial[(int64_t)p * C1_DW + t];
+  for (; p < parts; ++p) s0 += partial[(int64_t)p * slab + t];
+  if (t >= C1_DW) { db[t - C1_DW] = (s0 + s1) + (s2 + s3); return; }      // the bias gradient takes no input scale
   const int f = t >> 8, tap = t & 255;
   dw[f * so + (tap >> 6) * sc + ((tap >> 3) & 7) * sh + (tap & 7) * sw] = ((s0 + s1) + (s2 + s3)) * scale;
 }
@@ -604,7 +628,7 @@ extern "C" int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t*
 
 extern "C" int mirl_conv1_u8_wrw_scratch_floats(int64_t* out) {
   if (!out) return mirl::fail(MIRL_ERR_ARG, "null out");
-  *out = (int64_t)512 * mirl::C1_DW;
+  *out = (int64_t)512 * (mirl::C1_DW + mirl::C1_F);      // per-workgroup slabs: 8192 weight-gradient sums (+ 32 bias-gradient sums, masked form)
   return MIRL_OK;
 }
 
@@ -629,17 +653,56 @@ extern "C" int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8
     ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st,
                  (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
 #define C1_WLAUNCH(FPI_, WC_, PC_) \
-  hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch)
+  hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch, (const float*)nullptr, (int)C1_DW)
     const bool atari = W == 84 && pitch == 7232;
     if (fpi == 2 && atari && !(flags & 1))
-      hipLaunchKernelGGL((k_conv1_u8_wrw<2, 84, 7232, 1>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch);
+      hipLaunchKernelGGL((k_conv1_u8_wrw<2, 84, 7232, 1>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, g, scratch, (const float*)nullptr, (int)C1_DW);
     else if (fpi == 2) { if (atari) C1_WLAUNCH(2, 84, 7232); else C1_WLAUNCH(2, 0, 0); }
     else               { if (atari) C1_WLAUNCH(1, 84, 7232); else C1_WLAUNCH(1, 0, 0); }
 #undef C1_WLAUNCH
     MIRL_LAUNCH_CHECK();
   }
   ProfScope ps("k_conv1_wrw_reduce", (double)grid * C1_DW * 4, st);
-  hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((C1_DW + 255) / 256), dim3(256), 0, st, scratch, (int)grid, scale, dw, ws_o, ws_c, ws_h, ws_w);
+  hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((C1_DW + 255) / 256), dim3(256), 0, st, scratch, (int)grid, scale, dw, ws_o, ws_c, ws_h, ws_w,
+                     (int)C1_DW, (float*)nullptr);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+// Weight AND bias gradient from the gradient w.r.t. the layer's output: dy masked by the forward output y > 0 while it is
+// loaded (the layer's ReLU, cnn.py:47-49), db[f] = the masked gradient's column sums from the same pass.
+extern "C" int mirl_conv1_u8_wrw_masked(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* dy, const float* y, float scale,
+                                        float* scratch, float* dw, int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w,
+                                        float* db, void* stream) {
+  using namespace mirl;
+  if (N <= 0 || N >= (1LL << 30) || !x || !dy || !y || !scratch || !dw || !db) return fail(MIRL_ERR_ARG, "bad conv1_u8_wrw_masked arguments");
+  if (!mirl_conv1_u8_supported(C1_PLANES, H, W, C1_F, C1_K, C1_S)) return fail(MIRL_ERR_ARG, "conv1_u8_wrw: unsupported frame shape");
+  if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)y % 16) || ((uintptr_t)scratch % 16))
+    return fail(MIRL_ERR_ARG, "conv1_u8_wrw: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, pitch = c1_pitch(HW);
+  const int fpi = (N >= 1024 && 2 * C1_PLANES * pitch <= 64 * 1024) ? 2 : 1;
+  const int64_t units = (N + fpi - 1) / fpi;
+  const unsigned grid = (unsigned)(units < 512 ? units : 512);
+  const int slab = C1_DW + C1_F;
+  size_t lds = (size_t)fpi * C1_PLANES * pitch;
+  if (lds < (size_t)slab * 4) lds = (size_t)slab * 4;
+  const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
+  {
+    ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + 2.0 * OH * OW * C1_F * 4), st,
+                 (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
+#define C1_MLAUNCH(FPI_, WC_, PC_, BULK_) \
+  hipLaunchKernelGGL((k_conv1_u8_wrw<FPI_, WC_, PC_, BULK_, true>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, ow_magic, pitch, x, dy, scratch, y, slab)
+    const bool atari = W == 84 && pitch == 7232;
+    if (fpi == 2 && atari) C1_MLAUNCH(2, 84, 7232, 1);
+    else if (fpi == 2) C1_MLAUNCH(2, 0, 0, 0);
+    else if (atari) C1_MLAUNCH(1, 84, 7232, 0);
+    else C1_MLAUNCH(1, 0, 0, 0);
+#undef C1_MLAUNCH
+    MIRL_LAUNCH_CHECK();
+  }
+  ProfScope ps("k_conv1_wrw_reduce", (double)grid * slab * 4, st);
+  hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((slab + 255) / 256), dim3(256), 0, st, scratch, (int)grid, scale, dw, ws_o, ws_c, ws_h, ws_w, slab, db);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

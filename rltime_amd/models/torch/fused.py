@@ -227,6 +227,7 @@ def conv_u8_supported(x, conv):
 
 
 _U8_WRW = os.environ.get("MIRL_CONV1_WRW", "1") != "0"     # 0: MIOpen weight gradient on a converted copy
+_U8_WRW_MASK = os.environ.get("MIRL_CONV1_WRW_MASK", "1") != "0"   # 0: separate ReLU-mask + bias-gradient pass in front of it
 
 
 class _ConvU8BiasReLU(torch.autograd.Function):
@@ -251,6 +252,20 @@ class _ConvU8BiasReLU(torch.autograd.Function):
     def backward(ctx, grad):
         x, weight, y = ctx.saved_tensors
         grad = grad.contiguous(memory_format=torch.channels_last)
+        if ctx.needs_input_grad[1] and _U8_WRW and _U8_WRW_MASK and x.shape[0] and grad.data_ptr() % 16 == 0:
+            # ReLU mask and bias gradient inside the weight-gradient kernel (this layer's input takes no gradient, so the
+            # masked gradient itself is not needed anywhere else): one pass over dy, y and the uint8 frames
+            L = _lib()
+            n, _, h, w = x.shape
+            need = C.c_int64()
+            L.check(L.lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
+            scratch = torch.empty(need.value, dtype=torch.float32, device=x.device)
+            dw = torch.empty_like(weight)
+            db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+            so, sc, sh, sw = dw.stride()
+            L.check(L.lib.mirl_conv1_u8_wrw_masked(n, h, w, _p(x), _p(grad), _p(y), float(ctx.scale), _p(scratch), _p(dw), so, sc, sh, sw,
+                                                   _p(db), _stream()), "mirl_conv1_u8_wrw_masked")
+            return None, dw, (db if ctx.needs_input_grad[2] else None), None, None
         g, db = relu_bwd_bias_rows(grad, y, y.shape[1])
         dw = None
         if ctx.needs_input_grad[1] and _U8_WRW and x.shape[0]:

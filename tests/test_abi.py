@@ -154,5 +154,5 @@ def test_conv_kernel_shape_gates_are_host_logic():
                 (32, 64, 4, 2, 130, 130, 64, 64)]:
         assert lib.mirl_conv2_bwd_data_supported(*bad) == 0, bad
     need = C.c_int64()
-    assert lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)) == 0 and need.value == 512 * 32 * 4 * 8 * 8
+    assert lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)) == 0 and need.value == 512 * (32 * 4 * 8 * 8 + 32)     # 512 slabs of 8192 weight-gradient + 32 bias-gradient sums
     assert lib.mirl_conv1_u8_wrw_scratch_floats(None) < 0                 # null out pointer: error code, no crash

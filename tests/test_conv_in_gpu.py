@@ -183,3 +183,45 @@ def test_weight_gradient_within_tolerance_and_reproducible(n, h, w):
     want = _wrw_reference(x, g, 1.0 / 255.0)
     err = float((a.double() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 84, 84), (3, 36, 36), (1, 8, 8), (1027, 84, 84), (1030, 44, 52)])
+def test_masked_weight_gradient_equals_mask_pass_plus_weight_gradient(n, h, w):
+    """mirl_conv1_u8_wrw_masked: the layer's ReLU mask (y > 0, cnn.py:47-49) applied while dy is loaded and the bias
+    gradient from the same pass, against the two-launch form (k_relu_bwd_bias_rows, then mirl_conv1_u8_wrw on its
+    output): the weight gradient is BIT-identical (the same masked values enter the same sums in the same order), the
+    bias gradient is the masked gradient's column sums (bit-exact on integer-valued dy, 1e-5 of scale on real dy) and
+    both are bit-reproducible."""
+    from rltime_amd._lib import lib, check
+    from rltime_amd.models.torch.fused import relu_bwd_bias_rows
+    g_ = torch.Generator(device="cuda").manual_seed(7 * n + w)
+    x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g_)
+    oh, ow = (h - 8) // 4 + 1, (w - 8) // 4 + 1
+    y = (torch.randn(n, 32, oh, ow, device="cuda", generator=g_).clamp(min=0)).contiguous(memory_format=torch.channels_last)
+    like = torch.empty(32, 4, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    p = lambda t: C.c_void_p(t.data_ptr())                                  # noqa: E731
+    need = C.c_int64()
+    check(lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)))
+
+    def masked(dy, scale):
+        scratch = torch.empty(need.value, device="cuda")
+        dw, db = torch.full_like(like, float("nan")), torch.full((32,), float("nan"), device="cuda")
+        so, sc, sh, sw = dw.stride()
+        check(lib.mirl_conv1_u8_wrw_masked(n, h, w, p(x), p(dy), p(y), scale, p(scratch), p(dw), so, sc, sh, sw, p(db),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv1_wrw_masked")
+        return dw, db
+    for integer in (True, False):
+        dy = (torch.randint(-3, 4, (n, 32, oh, ow), device="cuda", generator=g_).float() if integer
+              else torch.randn(n, 32, oh, ow, device="cuda", generator=g_)).contiguous(memory_format=torch.channels_last)
+        scale = 1.0 if integer else 1.0 / 255.0
+        g, db_ref = relu_bwd_bias_rows(dy, y, 32)
+        dw_ref = _wrw(x, g, scale, like)
+        dw, db = masked(dy, scale)
+        assert torch.equal(dw, dw_ref)
+        want_db = (dy.double() * (y > 0)).sum((0, 2, 3))
+        if integer:
+            assert torch.equal(db.double(), want_db) and torch.equal(db, db_ref)
+        else:
+            assert float((db.double() - want_db).abs().max()) <= 1e-5 * max(float(want_db.abs().max()), 1.0)
+        dw2, db2 = masked(dy, scale)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
