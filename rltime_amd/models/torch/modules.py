@@ -153,8 +153,24 @@ class LSTM(BaseModule):
         self.out_shape = (num_units,)
         self.last_state = None
         self.fused = True          # use the fused HIP sequence op on the GPU
+        # NHWC conv output consumed in memory order with permuted W_ih columns instead of a transposing copy (_flat_input)
+        self.nhwc_input = os.environ.get("MIRL_LSTM_NHWC_INPUT", "1") != "0"
         init_weight(self.lstm_cell.weight_hh)
         init_weight(self.lstm_cell.weight_ih)
+
+    def _flat_input(self, x):
+        """The layer's input rows and the input weights to multiply them with.  The reference flattens the conv stack's
+        (C, H, W) output (lstm.py:60-66: x.view(-1, inp_size)); for an NHWC (channels_last) activation that is a
+        transposing copy of the whole block (62 464 x 3136 floats = 0.8 GB per pass at config D).  The rows are taken in
+        MEMORY order instead — a view — and the columns of W_ih are permuted to match (a 26 MB copy that autograd undoes
+        for the weight gradient): the same products, summed in another column order."""
+        w = self.lstm_cell.weight_ih
+        if (x.dim() == 4 and x.is_cuda and self.nhwc_input and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] * x.shape[2] * x.shape[3] == self.inp_size):
+            n, c, h, wd = x.shape
+            return (x.permute(0, 2, 3, 1).reshape(n, h * wd * c),
+                    w.view(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, h * wd * c))
+        return x.reshape(-1, self.inp_size), w
 
     def project_input(self, x):
         """x W_ih^T + b_ih + b_hh for every row of x: the part of the sequence forward
@@ -164,7 +180,8 @@ class LSTM(BaseModule):
         it once and hands each pass its rows through forward(projected=...)."""
         cell = self.lstm_cell
         from .gemm3 import linear as linear3
-        return linear3(x.reshape(-1, self.inp_size), cell.weight_ih, cell.bias_ih + cell.bias_hh)
+        rows, w_ih = self._flat_input(x)
+        return linear3(rows, w_ih, cell.bias_ih + cell.bias_hh)
 
     def forward(self, x, hx, cx, initials, timesteps, projected=None):
         if projected is not None and projected.is_cuda and self.fused and projected.shape[0] == hx.shape[0]:
@@ -177,7 +194,7 @@ class LSTM(BaseModule):
                 (1 - initials).reshape(timesteps, batch))
             self.last_state = (h_last.detach(), c_last.detach())
             return out.reshape(timesteps * batch, self.num_units)
-        x = x.reshape(-1, self.inp_size)
+        x, w_ih = self._flat_input(x)
         assert hx.shape[1] == self.num_units and cx.shape[1] == self.num_units
         assert x.shape[0] % hx.shape[0] == 0
         multi = x.shape[0] // hx.shape[0]
@@ -192,13 +209,13 @@ class LSTM(BaseModule):
         if x.is_cuda and multi == 1 and self.fused:
             # MI355X path: one GEMM + one fused HIP kernel per step (lstm_seq.py)
             from .lstm_seq import lstm_sequence
-            out, h_last, c_last = lstm_sequence(x, cell.weight_ih, cell.weight_hh, cell.bias_ih + cell.bias_hh,
+            out, h_last, c_last = lstm_sequence(x, w_ih, cell.weight_hh, cell.bias_ih + cell.bias_hh,
                                                 hx, cx, (1 - initials).reshape(timesteps, batch))
             self.last_state = (h_last.detach(), c_last.detach())
             return out.reshape(timesteps * batch, self.num_units)
         keep = (1 - initials).reshape(timesteps, batch, 1)
         # one GEMM for the input projection of every timestep
-        gx = F.linear(x, cell.weight_ih, cell.bias_ih).reshape(timesteps, batch, -1)
+        gx = F.linear(x, w_ih, cell.bias_ih).reshape(timesteps, batch, -1)
         out = []
         inner = self.multi_sample_merge_mode == "inner"
         for t in range(timesteps):

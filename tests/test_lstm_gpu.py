@@ -282,3 +282,34 @@ def test_persistent_backward_sweep_equals_the_per_step_path(T, B, monkeypatch):
     dg = gates.clone()
     lstm_seq._backward_sweep(dg, c_all, cm, d_out, keep, w)
     assert torch.equal(dg, res[0])
+
+
+def test_nhwc_conv_output_is_consumed_in_memory_order():
+    """LSTM._flat_input: an NHWC (channels_last) conv output enters the input projection as a VIEW in memory order with the
+    columns of W_ih permuted to match, instead of the transposing copy the reference's x.view(-1, inp_size) implies
+    (modules/lstm.py:60-66).  Same outputs, same gradients (incl. d W_ih back in the parameter's own column order) as the
+    copying path, through the sequence op and through project_input."""
+    from rltime_amd.models.torch.modules import LSTM
+    torch.manual_seed(3)
+    T, B, C, Hh, Ww, H = 5, 16, 64, 7, 7, 128
+    layer = LSTM((C, Hh, Ww), H).cuda()
+    x0 = torch.randn(T * B, C, Hh, Ww, device="cuda").contiguous(memory_format=torch.channels_last)
+    hx, cx = torch.randn(T * B, H, device="cuda") * 0.3, torch.randn(T * B, H, device="cuda") * 0.3
+    ini = (torch.rand(T * B, device="cuda") < 0.2).float()
+    res = {}
+    for mode in (True, False):
+        layer.nhwc_input = mode
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        out = layer(x, hx, cx, ini, T)
+        proj = layer.project_input(x)
+        (out.square().sum() + proj.sum()).backward()
+        res[mode] = (out.detach(), proj.detach(), x.grad.clone(), layer.lstm_cell.weight_ih.grad.clone(), layer.lstm_cell.weight_hh.grad.clone())
+    rows, w = layer._flat_input(x0)
+    layer.nhwc_input = True
+    rows2, w2 = layer._flat_input(x0)
+    assert rows2.data_ptr() == x0.data_ptr() and rows.data_ptr() != x0.data_ptr()          # a view vs a copy
+    assert torch.equal(rows2 @ w2.t(), rows2 @ w2.t()) and torch.allclose(rows @ w.t(), rows2 @ w2.t(), rtol=1e-4, atol=1e-4)
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
