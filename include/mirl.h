@@ -437,6 +437,10 @@ int mirl_frames_to_f32_nhwc_ex(int64_t N, int32_t C, int32_t HW, const uint8_t* 
  * anything else returns MIRL_ERR_ARG and the caller keeps the generic path
  * (mirl_frames_to_f32_nhwc + library convolution).                              */
 int mirl_conv1_u8_supported(int32_t C, int32_t H, int32_t W, int32_t F, int32_t K, int32_t S);
+/* floats the `wpk` scratch block of mirl_conv1_u8_fwd[_ex] must hold (12288 since the bf16-pipe kernel; 8192 before):
+ * size the block from this query.  A call with flags bit 3 (weights already packed) on a block that was packed by the
+ * OTHER kernel variant (f32 / bf16 pipe) returns MIRL_ERR_STATE instead of reading a mismatched layout.               */
+int mirl_conv1_u8_wpk_floats(int64_t* out);
 /* process-wide choice of the forward's matrix pipe: 1 = bf16 (exact split), 0 = f32 MFMA, < 0 = back to the
  * MIRL_CONV1_BF16 environment default.  For in-process A/B runs (tests/test_network_ab_gpu.py).              */
 int mirl_conv1_bf16_set(int32_t mode);

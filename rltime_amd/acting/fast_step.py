@@ -124,7 +124,9 @@ class FastActingStep:
         _, hh, ww = obs0.shape[1:]
         k, s = c1.kernel_size[0], c1.stride[0]
         self.y1 = torch.empty((E, c1.out_channels, (hh - k) // s + 1, (ww - k) // s + 1), memory_format=torch.channels_last, **f32)
-        self.wpk = torch.empty(12288, **f32)
+        need = C.c_int64()
+        check(lib.mirl_conv1_u8_wpk_floats(C.byref(need)))
+        self.wpk = torch.empty(need.value, **f32)
         self.xh = torch.zeros((E, F + H), **f32)                 # [conv features (NCHW order) | masked h]
         self.c_in = torch.zeros((E, H), **f32)
         self.h = torch.zeros((E, H), **f32)                      # raw carry (outputs of the last cell)

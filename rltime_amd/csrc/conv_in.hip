@@ -38,6 +38,7 @@
 // down in this file) reads the same uint8 frames.  Autograd wiring:
 // rltime_amd/models/torch/fused.py:_ConvU8BiasReLU.
 #include "common.hpp"
+#include <unordered_map>
 
 namespace mirl {
 
@@ -555,6 +556,17 @@ extern "C" int mirl_conv1_u8_fwd_ex(int64_t N, int32_t H, int32_t W, const uint8
   const int bf_env = g_conv1_bf16 >= 0 ? g_conv1_bf16 : bf_env0;
   const int dbg0 = (flags >> 24) & 7;
   const bool bf = bf_env && !dbg0 && !(flags & 32) && !(flags & 4);      // bit 5: force the f32-MFMA kernel (probe / A-B)
+  // which kernel's operand order a scratch block holds is remembered per pointer (host side, one caller thread per the
+  // library's contract): a `packed` call whose kernel choice differs from the packing call's is refused instead of
+  // reading a mismatched layout
+  static std::unordered_map<const void*, int> packed_as;
+  if (flags & 8) {
+    auto it = packed_as.find((const void*)wpk);
+    if (it == packed_as.end() || it->second != (bf ? 2 : 1))
+      return fail(MIRL_ERR_STATE, "conv1_u8_fwd: flags bit 3 (weights already packed) but this scratch block was not packed by the same kernel variant");
+  } else {
+    packed_as[(const void*)wpk] = bf ? 2 : 1;
+  }
   if (!(flags & 8)) {                                     // bit 3: wpk already holds these weights packed (acting steps between updates)
     ProfScope ps("k_conv1_pack_w", 2.0 * C1_WPK * 4, st);
     if (bf) hipLaunchKernelGGL(k_conv1_pack_w3, dim3(4), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w, scale, (uint4*)wpk);
@@ -624,6 +636,14 @@ extern "C" int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t*
                                  float* y, void* stream) {
   static const int flags = getenv("MIRL_CONV1_FLAGS") ? atoi(getenv("MIRL_CONV1_FLAGS")) : 0;
   return mirl_conv1_u8_fwd_ex(N, H, W, x, weight, ws_o, ws_c, ws_h, ws_w, bias, scale, wpk, y, flags, stream);
+}
+
+// floats of `wpk` scratch mirl_conv1_u8_fwd[_ex] needs (the bf16-pipe kernel packs three 16 KB weight parts: more than the
+// f32 kernel's 8192 floats of rounds 2 — callers size the block from this query, not from a constant)
+extern "C" int mirl_conv1_u8_wpk_floats(int64_t* out) {
+  if (!out) return mirl::fail(MIRL_ERR_ARG, "null out");
+  *out = 12288;
+  return MIRL_OK;
 }
 
 extern "C" int mirl_conv1_u8_wrw_scratch_floats(int64_t* out) {

@@ -214,6 +214,13 @@ def frames_to_f32_nhwc(x, scale):
     return out
 
 
+def _wpk_floats():
+    need = C.c_int64()
+    L = _lib()
+    L.check(L.lib.mirl_conv1_u8_wpk_floats(C.byref(need)))
+    return need.value
+
+
 def conv_u8_supported(x, conv):
     """Does the one-pass input layer (mirl_conv1_u8_fwd) cover this conv on this uint8 block?"""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.uint8 and x.dim() == 4 and x.is_contiguous()
@@ -239,7 +246,7 @@ class _ConvU8BiasReLU(torch.autograd.Function):
         oh, ow = (h - k) // stride + 1, (w - k) // stride + 1
         y = torch.empty((n, f, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if n:
-            wpk = torch.empty(12288, dtype=torch.float32, device=x.device)
+            wpk = torch.empty(_wpk_floats(), dtype=torch.float32, device=x.device)
             so, sc, sh, sw = weight.stride()
             b = bias if bias.data_ptr() % 16 == 0 else bias.clone()
             L.check(L.lib.mirl_conv1_u8_fwd(n, h, w, _p(x), _p(weight), so, sc, sh, sw, _p(b), float(scale), _p(wpk), _p(y),

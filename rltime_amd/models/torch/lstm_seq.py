@@ -51,6 +51,21 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
+def check_status(what="a persistent LSTM sweep"):
+    """Raise if a persistent sweep has reported failure (a bounded spin gave up on a peer workgroup, or the recurrent state
+    became non-finite — the tagged exchange cannot carry inf / nan).  The kernels set a host-visible word; the next
+    mirl_lstm_seq_* call also refuses with MIRL_ERR_STATE, but by then the invalid outputs of the failed sweep may have
+    reached the optimizer — the trainers call this where the host is already synchronised (log rows, checkpoints) and,
+    as a cheap unsynchronised look, before every optimizer step.  Shared-GPU runs that starve the sweep's co-residency
+    assumption should set MIRL_LSTM_PERSISTENT=0."""
+    st = C.c_int32()
+    check(lib.mirl_lstm_seq_status(C.byref(st)), "mirl_lstm_seq_status")
+    if st.value:
+        raise RuntimeError("%s reported failure (status %d): its outputs are invalid — non-finite recurrent state, or a "
+                           "workgroup of the sweep was not resident (another process / stream occupying the GPU: "
+                           "MIRL_LSTM_PERSISTENT=0 keeps the per-step kernels)" % (what, st.value))
+
+
 def persistent_supported(T, B, H):
     return _PERSISTENT and T >= 2 and bool(lib.mirl_lstm_seq_supported(T, B, H))
 

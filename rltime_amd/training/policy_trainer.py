@@ -167,6 +167,9 @@ class PolicyTrainer:
     # -- logging / checkpoint ------------------------------------------------------
     def _log_checkpoint(self):
         self._resolve_gpu_spans()
+        if getattr(self.policy, "is_cuda", lambda: False)():
+            from rltime_amd.models.torch import lstm_seq
+            lstm_seq.check_status()          # after the synchronisation above: nothing of a failed sweep gets checkpointed
         rates, total_seconds = self.clock.rates()
         for key, val in rates.items():
             self.value_log.log(key, val, group="this_interval")

@@ -112,6 +112,9 @@ class TorchTrainer(MultiStepTrainer):
             coef = torch.clamp(clip / (norm + 1e-6), max=1.0)     # torch.nn.utils.clip_grad_norm_
             torch._foreach_mul_(grads, coef)
             self.value_log.log("grad_norm_clipped", norm * coef, group="train")
+        if self.policy.is_cuda():
+            from rltime_amd.models.torch import lstm_seq
+            lstm_seq.check_status()          # a failed sweep must not reach the optimizer (host read of a pinned word, no sync)
         self.optimizer.step()
 
     def _reduce_gradients(self):
