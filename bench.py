@@ -233,7 +233,7 @@ class CpuPath:
 
     T, P, n, E, H, A = 80, 40, 2, 8, 512, 6
 
-    def __init__(self, fill_steps=400):
+    def __init__(self, fill_steps=400, size_per_env=500):
         from oracle import replay as orc
         from rltime_amd.general.config import load_config
         from rltime_amd.policies.iqn import IQNPolicy
@@ -246,7 +246,7 @@ class CpuPath:
         self.policy, self.target = mk(), mk()
         self.opt = torch.optim.Adam(self.policy.parameters(), eps=1e-5)
         self.buf = orc.OraclePrioritizedReplay(
-            size=E * 500, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
+            size=E * size_per_env, train_frequency=4, nstep_target=n, nstep_train=T, prefix_steps=P,
             alpha=0.9, beta=0.6, max_weight_factor=0.9, discount_function=orc.make_discount(0.99))
         self.rng = rng = np.random.RandomState(0)
         frame_pool = [rng.randint(0, 256, (4, 84, 84)).astype(np.uint8) for _ in range(64)]
@@ -325,7 +325,8 @@ def cpu_baseline(args, seconds):
     torch.set_num_threads(1)); second leg: more host cores."""
     nproc = os.cpu_count() or 1
     B_full, T = 512, CpuPath.T
-    cpu = CpuPath()
+    # B = 64 needs 64 active sequences in the oracle's buffer: 8 envs x 750 steps at gap 40 behind a 122-step window
+    cpu = CpuPath(fill_steps=750, size_per_env=800) if getattr(args, "cpu_linearity_check", False) else CpuPath()
     learner_step, ingest_rate = cpu.learner_step, cpu.ingest_rate
 
     def leg(threads, plan, budget):

@@ -268,11 +268,14 @@ def test_config_d_learner_evaluation_hip_vs_library_vs_float64(monkeypatch):
     # zero takes the other branch than in float64 and its whole gradient row switches on or off; everywhere else the hip path
     # is CLOSER to float64 than the library path (LSTM 2.0e-4 vs 2.7e-4, conv stack 0.9-1.9e-4 vs 1.5-2.6e-4).  An absolute
     # 1e-4 per entry is therefore not a bar float32 itself meets at T = 80; the bars that mean something:
-    #   * per parameter, hip is no further from float64 than twice the library path's distance (the bar of the per-op tests; measured
-    #     ratios 0.5 - 1.3 over three runs; 1e-5 floor);
+    #   * the worst parameter of the hip path is no further from float64 than 1.5 x the library path's worst (max entry and
+    #     relative L2; measured 0.5 - 1.0 over four runs), and per parameter hip <= 2 x library OR below 1e-3 — the size of one
+    #     flipped ReLU unit in a 512-entry bias gradient, which a per-parameter ratio of two float32 paths cannot exclude
+    #     (one run: value-hidden bias 4.8e-4 vs 2.2e-4 while the last FC layer read 1.1e-3 on both);
     #   * the two float32 paths differ by no more than each differs from float64 (max entry <= 2.5e-3, observed 8.5e-4);
     #   * the global gradient norm — what clipping and the logged series see — agrees to 1e-4.
     for k, v in ah["grad_dev"].items():
-        assert v["max"] <= max(2.0 * al["grad_dev"][k]["max"], 1e-5), (k, v, al["grad_dev"][k])
+        assert v["max"] <= max(2.0 * al["grad_dev"][k]["max"], 1e-3), (k, v, al["grad_dev"][k])
+    assert ah["grad_dev_max"] <= 1.5 * al["grad_dev_max"] and ah["grad_l2_max"] <= 1.5 * al["grad_l2_max"], (ah["grad_dev_max"], al["grad_dev_max"])
     assert facts["grad_dev_max"] <= 2.5e-3, facts["grad_dev_max"]
     assert facts["grad_norm_rel_dev"] <= 1e-4 and ah["grad_norm_rel_dev"] <= max(2.0 * al["grad_norm_rel_dev"], 1e-5), (facts["grad_norm_rel_dev"], ah["grad_norm_rel_dev"], al["grad_norm_rel_dev"])
