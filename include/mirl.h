@@ -553,6 +553,18 @@ int mirl_gemm3_head_workspace_bytes(int64_t M, int64_t N, int64_t* bytes);
 int mirl_gemm3_nt_head(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                        float* C, int64_t ldc, const float* bias, int32_t relu, const float* w2, int32_t O,
                        const float* bias2, float* out2, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream);
+/* The data gradient d = A[M][K] . B[K][N] (NN form) of the layer that FOLLOWS the IQN feature product
+ * out[r] = x[r >> 5] * emb[r] (policies/torch/iqn.py:84,102; 32 quantile rows per state), with that product's backward in
+ * the epilogue — d itself never reaches HBM (at the benchmark shape 2.7 GB written and read back by mirl_iqn_mul_bwd):
+ *   d_pre[r][c] = emb[r][c] > 0 ? d[r][c] * x[r >> 5][c] : 0        (gradient of the embedding layer's pre-activation)
+ *   dx[m][c]    = sum over the state's 32 rows of d[r][c] * emb[r][c]   (fixed order)
+ *   db_partial[p][c], p < mirl_gemm3_nn_qp_partial_rows(M): column sums of d_pre over 128-row blocks; the caller adds
+ *                 the rows (the embedding layer's bias gradient)
+ * M % 32 == 0, N % 4 == 0, all rows 16-byte aligned.  Same six part products as mirl_gemm3.                        */
+int mirl_gemm3_nn_qp_partial_rows(int64_t M, int64_t* rows);
+int mirl_gemm3_nn_qp(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                     const float* emb, int64_t ldemb, const float* x, int64_t ldx, float* d_pre, int64_t ldd,
+                     float* dx, int64_t lddx, float* db_partial, void* stream);
 int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes);
 int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes, void* stream);
 int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
@@ -574,6 +586,20 @@ int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
 int mirl_conv3_fwd_supported(int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S, int32_t H, int32_t W);
 int mirl_conv3_fwd(int64_t N, int32_t H, int32_t W, int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S,
                    const float* x, const float* w, const float* bias, int32_t relu, float* y, void* stream);
+
+/* ---- the backward of a small NHWC convolution as wide GEMMs (csrc/conv_col.hip + mirl_gemm3).
+ * Replaces MIOpen's weight / data gradient kernels behind autograd for the reference's conv layers 2 and 3
+ * (rltime/models/torch/modules/cnn.py:43-50).  With row = (n, oy, ox) one output position:
+ *   mirl_im2col_nhwc:  col[row][(ky, kx, c)] = x[n][oy*S + ky][ox*S + kx][c]          float [N*OH*OW][KH*KW*C]
+ *       -> weight gradient  dW^T[(ky,kx,c)][f] = mirl_gemm3(TN, col, g)   (g = d loss / d conv output, [rows][F])
+ *   mirl_col2im_nhwc:  dx[n][y][x][c] = sum over the windows covering (y, x) of dcol[row][(ky, kx, c)], in fixed
+ *       (ky, kx) order (deterministic), times (relu_mask[n][y][x][c] > 0) when relu_mask is given (the ReLU of the
+ *       layer below)      <- dcol = mirl_gemm3(NN, g, W as [F][KH*KW*C])
+ * C % 4 == 0, 16-byte aligned buffers, fewer than 2^31 positions; no padding, no dilation.  One HBM pass each.   */
+int mirl_im2col_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t S, const float* x,
+                     float* col, void* stream);
+int mirl_col2im_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t S, const float* col,
+                     const float* relu_mask, float* dx, void* stream);
 
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC

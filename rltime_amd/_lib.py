@@ -172,10 +172,14 @@ _SIGNATURES = {
     "mirl_conv2_bwd_data": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "mirl_conv3_fwd_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv3_fwd": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
+    "mirl_im2col_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "mirl_col2im_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_gemm3_supported": [_i32, _i64, _i64, _i64],
     "mirl_gemm3_workspace_bytes": [_i32, _i64, _i64, _i64, _P(_i64)],
     "mirl_gemm3": [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp],
     "mirl_gemm3_nt_mul": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
+    "mirl_gemm3_nn_qp_partial_rows": [_i64, _P(_i64)],
+    "mirl_gemm3_nn_qp": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "mirl_gemm3_head_workspace_bytes": [_i64, _i64, _P(_i64)],
     "mirl_gemm3_nt_head": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp],
     "mirl_gemm3_presplit_bytes": [_i64, _i64, _P(_i64)],

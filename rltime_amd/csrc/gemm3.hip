@@ -60,6 +60,11 @@ struct G3Args {
   // as partial sums per 64-column block: part[(col / 64)][row][8]; C may then be null (the activation itself is not stored)
   const float* w2; float* part;
   const char* Bps;       // B operand already split (mirl_gemm3_presplit): rows of K/16 blocks of [hi 16 | mid 16 | lo 16] bf16
+  // epilogue extension EP == 3 (NN, a data gradient g W that feeds the IQN feature product's backward, iqn.py:84,102): with
+  // d = A B (never stored), e = `pre` (the ReLU'd embedding, READ here), x = mul[row >> 5]:
+  //   C[row][col] = e > 0 ? d * x : 0;   gsum[row >> 5][col] = sum over the group's 32 rows of d * e;
+  //   part[2 it + wm][col] = this wave's 128-row column sum of C   (the embedding layer's bias gradient, summed by the caller)
+  float* gsum; int64_t ldgsum;
 };
 
 constexpr int G3_PSBLK = 96;     // bytes of one pre-split 16-k block: three parts x 16 bf16
@@ -302,6 +307,7 @@ k_gemm3(G3Args g) {
       constexpr int HALVES = NARROW ? 1 : 2, II = NARROW ? 1 : 2, QN = NARROW ? 8 : 16;     // NARROW: one 32-row block per wave
       float* w2l = reinterpret_cast<float*>(g3_lds) + 8 * (64 * G3_EPITCH);                 // EP 2: w2[8][256] of this tile's columns, 8 KB
       float bj[2] = {0.f, 0.f};
+      g3_f32x4 sb = {0.f, 0.f, 0.f, 0.f};                                                   // EP 3: column sums of C over this wave's rows
       if (EP == 2) {
         // the following layer's weights for this tile's 256 columns -> the 8 KB of LDS behind the transposition areas
         // (one 16-byte vector per thread: o = t >> 6, columns 4 (t & 63) ..); visible after the barrier below
@@ -399,8 +405,8 @@ k_gemm3(G3Args g) {
         // goes out instead of one dependent global load per output vector (measured: 1.19 -> 1.16 ms only — the K = 64
         // product is bound by its serialised load -> split -> MFMA -> store phases per tile).
         float4 mg0 = make_float4(0.f, 0.f, 0.f, 0.f), mg1 = mg0;
-        const bool hoisted = EP == 1 && g.mul_shift >= 5;   // groups of >= 32 rows: at most two per 64-row half
-        if (EP == 1 && hoisted) {
+        const bool hoisted = (EP == 1 && g.mul_shift >= 5) || EP == 3;   // groups of >= 32 rows: at most two per 64-row half
+        if ((EP == 1 || EP == 3) && hoisted) {
           // unconditional loads from clamped addresses (rows / columns beyond the edge are never stored)
           const int64_t rb = m0 + row_w + h * 64 + (lane >> 4);
           const int64_t r0 = rb < g.M ? rb : g.M - 1, r1 = rb + 32 < g.M ? rb + 32 : g.M - 1;
@@ -408,10 +414,54 @@ k_gemm3(G3Args g) {
           mg0 = *reinterpret_cast<const float4*>(g.mul + (r0 >> g.mul_shift) * g.ldmul + cc);
           mg1 = *reinterpret_cast<const float4*>(g.mul + (r1 >> g.mul_shift) * g.ldmul + cc);
         }
+        if (EP == 3) {
+          // the feature product's backward on the data gradient while it is still in LDS: the two 32-row groups of this
+          // half (one state's quantile rows each); the group's 8 embedding vectors of a lane are requested together
+          const float4 mgs[2] = {mg0, mg1};
+#pragma unroll
+          for (int gq = 0; gq < 2; ++gq) {
+            g3_f32x4 ev[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int64_t row = m0 + row_w + h * 64 + (gq * 8 + u) * 4 + (lane >> 4);
+              const int64_t rr = row < g.M ? row : g.M - 1, cc = col < g.N ? col : 0;
+              ev[u] = __builtin_nontemporal_load(reinterpret_cast<const g3_f32x4*>(g.pre + rr * g.ldpre + cc));
+            }
+            g3_f32x4 sg = {0.f, 0.f, 0.f, 0.f};
+            const g3_f32x4 xm = {mgs[gq].x, mgs[gq].y, mgs[gq].z, mgs[gq].w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int rl = (gq * 8 + u) * 4 + (lane >> 4);
+              const int64_t row = m0 + row_w + h * 64 + rl;
+              const float4 t4 = *reinterpret_cast<const float4*>(tl + rl * G3_EPITCH + c4 * 4);
+              const g3_f32x4 v = {t4.x, t4.y, t4.z, t4.w};
+              if (row < g.M && col < g.N) {
+                g3_f32x4 d = v * xm;
+                d.x = ev[u].x > 0.f ? d.x : 0.f; d.y = ev[u].y > 0.f ? d.y : 0.f;
+                d.z = ev[u].z > 0.f ? d.z : 0.f; d.w = ev[u].w > 0.f ? d.w : 0.f;
+                __builtin_nontemporal_store(d, reinterpret_cast<g3_f32x4*>(C + row * g.ldc + col));
+                sg += v * ev[u];
+                sb += d;
+              }
+            }
+            // the group's 32 rows sit in the four lane quarters (8 rows each): fixed-order butterfly
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = sg[e];
+              v += __shfl_xor(v, 16);
+              v += __shfl_xor(v, 32);
+              sg[e] = v;
+            }
+            const int64_t row0 = m0 + row_w + h * 64 + gq * 32;
+            if ((lane >> 4) == 0 && row0 < g.M && col < g.N)
+              *reinterpret_cast<g3_f32x4*>(g.gsum + (row0 >> 5) * g.ldgsum + col) = sg;
+          }
+        }
 #pragma unroll
         for (int q = 0; q < QN; ++q) {
           const int rl = q * 4 + (lane >> 4);
           const int64_t row = m0 + row_w + h * 64 + rl;
+          if (EP == 3) break;                       // done above
           if (EP == 2 && !g.C) break;               // no-grad pass: only the following layer's outputs leave the kernel
           float4 v = *reinterpret_cast<const float4*>(tl + rl * G3_EPITCH + c4 * 4);
           if (row < g.M && col < g.N) {
@@ -430,6 +480,18 @@ k_gemm3(G3Args g) {
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this half read before the next one overwrites it
+      }
+      if (EP == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = sb[e];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          sb[e] = v;
+        }
+        const int64_t col = n0 + wn * 64 + (lane & 15) * 4;
+        if ((lane >> 4) == 0 && col < g.N)
+          *reinterpret_cast<g3_f32x4*>(g.part + ((m0 >> 8) * 2 + wm) * g.N + col) = sb;      // (`it` already names the next tile)
       }
       if (more) g3_barrier();          // persistent walk: every wave's transpose done before the next tile is staged
     } else {
@@ -529,7 +591,8 @@ extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, 
 static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
                      int64_t workspace_bytes, const float* mul, int64_t ldmul, int32_t mul_shift, float* pre, int64_t ldpre,
-                     void* stream, const void* b_planes = nullptr, const float* w2 = nullptr, float* part = nullptr) {
+                     void* stream, const void* b_planes = nullptr, const float* w2 = nullptr, float* part = nullptr,
+                     float* gsum = nullptr, int64_t ldgsum = 0) {
   using namespace mirl;
   if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
   if (b_planes) {
@@ -552,7 +615,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
   g.Bps = reinterpret_cast<const char*>(b_planes);
-  g.w2 = w2; g.part = part;
+  g.w2 = w2; g.part = part; g.gsum = gsum; g.ldgsum = ldgsum;
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
   g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!w2 || !((uintptr_t)w2 % 16)) && (!bias || !((uintptr_t)bias % 16)) &&
              (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));
@@ -585,7 +648,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                            {(const void*)k_gemm3<true, false, 0, false>, (const void*)k_gemm3<true, false, 0, true>},
                            {(const void*)k_gemm3<false, false, 0, false>, (const void*)k_gemm3<false, false, 0, true>},
                            {(const void*)k_gemm3<true, true, 1, false>, (const void*)k_gemm3<true, true, 1, true>}};
-  const int which = mul ? 3 : layout;
+  const int which = (mul && !gsum) ? 3 : layout;
   const void* fn = fns[which][vec];
   if (b_planes) {
     static bool ps_attr[2][2] = {{false, false}, {false, false}};
@@ -593,6 +656,12 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                             {(const void*)k_gemm3<true, true, 1, false, true>, (const void*)k_gemm3<true, true, 1, true, true>}};
     fn = ps[mul ? 1 : 0][vec];
     if (!ps_attr[mul ? 1 : 0][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); ps_attr[mul ? 1 : 0][vec] = true; }
+  } else if (gsum) {
+    if (!vec || layout != 1 || !mul || mul_shift != 5 || !pre || !part || (ldgsum % 4) || ((uintptr_t)gsum % 16) || ((uintptr_t)part % 16) || (M % 32))
+      return fail(MIRL_ERR_ARG, "gemm3: the fused feature-product backward needs the NN form, groups of 32 rows and 16-byte aligned rows");
+    static bool qp_attr = false;
+    fn = (const void*)k_gemm3<true, false, 3, true>;
+    if (!qp_attr) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); qp_attr = true; }
   } else if (w2) {
     if (!vec || layout != 0 || mul || !part) return fail(MIRL_ERR_ARG, "gemm3: the fused following layer needs the NT form with 16-byte aligned rows");
     static bool hd_attr = false;
@@ -610,9 +679,9 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     const double flop = 2.0 * (double)M * (double)N * (double)K;
     // HBM bytes: both operands read once, the result (and the pre-product embedding / the multiplier rows) written / read once
     double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
-    if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N);
+    if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N * (gsum ? 2.0 : 1.0));
     if (w2) bytes += 4.0 * (8.0 * (double)N + 8.0 * (double)M * (double)((N + 63) / 64)) - (C ? 0.0 : 4.0 * (double)M * N);
-    ProfScope ps(mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
+    ProfScope ps(gsum ? "k_gemm3_nn_qp" : mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
@@ -639,6 +708,23 @@ extern "C" int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A
   if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
     return fail(MIRL_ERR_ARG, "gemm3_nt_mul: bad multiplier / pre-activation arguments");
   return g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream);
+}
+
+// ---- a data gradient g W whose consumer is the backward of the IQN feature product: that backward in the epilogue ----
+extern "C" int mirl_gemm3_nn_qp_partial_rows(int64_t M, int64_t* rows) {
+  if (!rows || M < 1) return mirl::fail(MIRL_ERR_ARG, "gemm3_nn_qp_partial_rows: M >= 1");
+  *rows = 2 * ((M + 255) / 256);
+  return MIRL_OK;
+}
+
+extern "C" int mirl_gemm3_nn_qp(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                                const float* emb, int64_t ldemb, const float* x, int64_t ldx, float* d_pre, int64_t ldd,
+                                float* dx, int64_t lddx, float* db_partial, void* stream) {
+  using namespace mirl;
+  if (!emb || !x || !d_pre || !dx || !db_partial || ldemb < N || ldx < N || lddx < N || (ldemb % 4) || ((uintptr_t)emb % 16))
+    return fail(MIRL_ERR_ARG, "gemm3_nn_qp: bad embedding / feature / output arguments");
+  return g3_launch(1, M, N, K, A, lda, B, ldb, d_pre, ldd, nullptr, 0, nullptr, 0, x, ldx, 5, const_cast<float*>(emb), ldemb, stream,
+                   nullptr, nullptr, db_partial, dx, lddx);
 }
 
 // ---- weights split once (per optimizer step) instead of by every row tile ------------------------------------

@@ -164,17 +164,93 @@ class _ConvBiasReLU(torch.autograd.Function):
             g = torch.ops.aten.threshold_backward(grad, y, 0.0)
             db = g.sum((0, 2, 3))
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx = None
+        dx = dw = None
+        if (need_x or need_w) and conv_col_supported(x, weight, ctx.stride, g):
+            # both gradients as wide split-bf16 GEMMs over the window matrix (csrc/conv_col.hip + gemm3)
+            if need_w:
+                dw = conv_wgrad_col(g, x, weight, ctx.stride)
+            if need_x:
+                dx = conv_dgrad_col(g, x, weight, ctx.stride)
+            need_x = need_w = False
         if need_x and _CONV2_BWD and g.shape[0] and conv2_bwd_data_supported(x, weight, ctx.stride, g):
             dx = conv2_bwd_data(g, weight, x)          # f32 MFMA, four parity-class GEMMs (csrc/conv_mid.hip)
             need_x = False
-        lib_dx, dw, _ = torch.ops.aten.convolution_backward(
+        lib_dx, lib_dw, _ = torch.ops.aten.convolution_backward(
             g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False]) \
             if (need_x or need_w) else (None, None, None)
-        return (dx if dx is not None else lib_dx), dw, (db if ctx.needs_input_grad[2] else None), None
+        return (dx if dx is not None else lib_dx), (dw if dw is not None else lib_dw), \
+            (db if ctx.needs_input_grad[2] else None), None
 
 
 _CONV2_BWD = os.environ.get("MIRL_CONV2_BWD", "1") != "0"   # 0: MIOpen data gradient for the second conv layer
+# conv layers 2-3 backward as im2col / col2im around the split-bf16 GEMMs.  MEASURED SLOWER and therefore OFF by default
+# (MIRL_CONV_COL=1 turns it on): the explicit window matrix is 4.6 GB (layer 3) + 6.8 GB (layer 2) at the 40 960 frames of
+# a learner step, written once and read once per gradient — 102.7 vs 93.7 ms per step on the same box
+# (profiles/r04_conv_col_probe.jsonl); MIOpen's implicit GEMMs never materialise it.
+# Window-matrix multiply-adds below MIRL_CONV_COL_MIN_WORK stay on the library either way.
+_CONV_COL = os.environ.get("MIRL_CONV_COL", "0") != "0"
+_CONV_COL_MIN_WORK = int(os.environ.get("MIRL_CONV_COL_MIN_WORK", str(1 << 31)))
+
+
+def conv_col_supported(x, weight, stride, g, min_work=None):
+    """Do both gradients of this NHWC conv run as GEMMs over the explicit window matrix?"""
+    if not (_CONV_COL and gemm3.enabled() and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32
+            and x.dim() == 4 and stride[0] == stride[1]
+            and x.is_contiguous(memory_format=torch.channels_last) and g.is_contiguous(memory_format=torch.channels_last)
+            and weight.is_contiguous(memory_format=torch.channels_last)
+            and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
+        return False
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    rows, k = g.shape[0] * g.shape[2] * g.shape[3], kh * kw * c
+    if c % 4 or f % 16 or k % 16 or rows % 16 or rows // 16 < 8 or rows >= (1 << 31) or n * h * w >= (1 << 31):
+        return False
+    return rows * k * f >= (_CONV_COL_MIN_WORK if min_work is None else min_work)
+
+
+def _conv_dims(x, weight, stride):
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    s = int(stride[0])
+    return n, c, h, w, f, kh, kw, s, (h - kh) // s + 1, (w - kw) // s + 1
+
+
+def im2col_nhwc(x, kh, kw, s):
+    """Window matrix [(n, oy, ox)][(ky, kx, c)] of an NHWC activation (one launch, csrc/conv_col.hip)."""
+    L = _lib()
+    n, c, h, w = x.shape
+    oh, ow = (h - kh) // s + 1, (w - kw) // s + 1
+    col = torch.empty((n * oh * ow, kh * kw * c), dtype=torch.float32, device=x.device)
+    L.check(L.lib.mirl_im2col_nhwc(n, h, w, c, kh, kw, s, _p(x), _p(col), _stream()), "mirl_im2col_nhwc")
+    return col
+
+
+def col2im_nhwc(dcol, x_like, kh, kw, s, relu_mask=None):
+    """Sum the window matrix's gradient back onto the NHWC input grid (x_like: shape / memory format of the result)."""
+    L = _lib()
+    n, c, h, w = x_like.shape
+    dx = torch.empty_like(x_like, memory_format=torch.channels_last)
+    L.check(L.lib.mirl_col2im_nhwc(n, h, w, c, kh, kw, s, _p(dcol), _p(relu_mask), _p(dx), _stream()), "mirl_col2im_nhwc")
+    return dx
+
+
+def conv_wgrad_col(g, x, weight, stride):
+    """d loss / d weight of conv2d(x, weight, stride): col(x)^T g as ONE split-K product; returned in the weight's own
+    (channels_last) memory format."""
+    n, c, h, w, f, kh, kw, s, oh, ow = _conv_dims(x, weight, stride)
+    col = im2col_nhwc(x, kh, kw, s)
+    g2 = g.permute(0, 2, 3, 1).reshape(n * oh * ow, f)              # a view of the NHWC gradient
+    dwt = gemm3.gemm(gemm3.TN, col, g2)                             # (kh*kw*c, f)
+    return dwt.t().contiguous().view(f, kh, kw, c).permute(0, 3, 1, 2)
+
+
+def conv_dgrad_col(g, x, weight, stride, relu_mask=None):
+    """d loss / d input: g W as one product onto the window matrix, then col2im."""
+    n, c, h, w, f, kh, kw, s, oh, ow = _conv_dims(x, weight, stride)
+    g2 = g.permute(0, 2, 3, 1).reshape(n * oh * ow, f)
+    wmat = weight.permute(0, 2, 3, 1).reshape(f, kh * kw * c)       # the channels_last weight as stored
+    dcol = gemm3.gemm(gemm3.NN, g2, wmat)
+    return col2im_nhwc(dcol, x, kh, kw, s, relu_mask)
 
 
 def conv2_bwd_data_supported(x, weight, stride, g):
@@ -313,6 +389,40 @@ def cos_embed(taus, freq):
     return torch.cos(freq * taus.unsqueeze(1))
 
 
+class _QPLink:
+    """Hand-over between the feature product and the layer that consumes its (rows, C) output — at the benchmark shape a
+    2.7 GB tensor whose gradient would be written by the consumer's data-gradient GEMM only to be read back by the
+    product's backward.  The product announces its output; a consumer that recognises its input (the dueling tail) runs
+    the product's backward in the epilogue of that GEMM (csrc/gemm3.hip EP 3), leaves the results here and returns an
+    all-zero, zero-stride placeholder as the gradient — autograd adds zeros to whatever other consumers contribute, so
+    the product's backward stays correct for any graph."""
+    __slots__ = ("out", "x", "emb", "n", "done", "placeholder", "__weakref__")
+
+
+_qp_links = {}
+
+
+def _qp_announce(out, x, emb, n):
+    import weakref
+    link = _QPLink()
+    link.out, link.x, link.emb, link.n, link.done, link.placeholder = weakref.ref(out), x, emb, n, None, None
+    if len(_qp_links) > 16:
+        for k in [k for k, v in _qp_links.items() if v() is None or v().out() is None]:
+            del _qp_links[k]
+    _qp_links[out.data_ptr()] = weakref.ref(link)
+    return link
+
+
+def _qp_find(x):
+    """The link of the feature product whose output `x` is (the tensor itself or a same-shape view of it), or None."""
+    ref = _qp_links.get(x.data_ptr())
+    link = ref() if ref is not None else None
+    out = link.out() if link is not None else None
+    if out is None or not (x is out or x._base is out) or x.shape != out.shape or not x.is_contiguous() or x._version != out._version:
+        return None
+    return link
+
+
 class _QuantileProduct(torch.autograd.Function):
     """out[m*N+n] = x[m] * relu(phi[m*N+n] @ Wq^T + bq)."""
 
@@ -333,6 +443,7 @@ class _QuantileProduct(torch.autograd.Function):
             L.check(L.lib.mirl_iqn_mul_fwd(M, n, Cf, _p(x), _p(emb), _p(out), _stream()), "mirl_iqn_mul_fwd")
         ctx.n = n
         ctx.save_for_backward(x, phi, weight, emb)
+        ctx.link = _qp_announce(out, x, emb, n) if need else None
         return out
 
     @staticmethod
@@ -340,14 +451,29 @@ class _QuantileProduct(torch.autograd.Function):
         L = _lib()
         x, phi, weight, emb = ctx.saved_tensors
         M, Cf = x.shape
-        grad = grad.contiguous()
-        blocks = min(M, 2048)
-        d_pre = torch.empty_like(emb)
-        dx = torch.empty_like(x)
-        db = torch.empty(Cf, dtype=torch.float32, device=x.device)
-        partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
-        L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
-                                       blocks, _stream()), "mirl_iqn_mul_bwd")
+        link = getattr(ctx, "link", None)
+        done, fused = (link.done, link.placeholder) if link is not None else (None, None)
+        if link is not None:
+            link.done = link.placeholder = None
+        # the consumer's backward already ran this product's backward in its data-gradient GEMM (see _QPLink): `grad` is
+        # then its all-zero placeholder — or placeholder + the gradients of OTHER consumers of the output, whose share
+        # (the backward is linear in grad) goes through the stand-alone pass and is added
+        only_placeholder = done is not None and grad.data_ptr() == fused.data_ptr() and all(s == 0 for s in grad.stride())
+        if done is None or not only_placeholder:
+            grad = grad.contiguous()
+            blocks = min(M, 2048)
+            d_pre = torch.empty_like(emb)
+            dx = torch.empty_like(x)
+            db = torch.empty(Cf, dtype=torch.float32, device=x.device)
+            partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
+            L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
+                                           blocks, _stream()), "mirl_iqn_mul_bwd")
+            if done is not None:
+                d_pre += done[0]
+                dx += done[1]
+                db += done[2]
+        else:
+            d_pre, dx, db = done
         dw = gemm3.grad_weight(d_pre, phi) if ctx.needs_input_grad[2] else None
         return (dx if ctx.needs_input_grad[0] else None), None, dw, (db if ctx.needs_input_grad[3] else None), None, None
 
@@ -391,6 +517,7 @@ class _DuelingTail(torch.autograd.Function):
             a = torch.addmm(bo, both[:, :h1], wo.t())
             v = torch.addmm(bq, both[:, h1:], wq.t())
         ctx.h1 = h1
+        ctx.link = _qp_find(x) if (track and ctx.needs_input_grad[0]) else None
         ctx.save_for_backward(x, w1, wo, wv, wq, both)
         return a, v
 
@@ -442,7 +569,12 @@ class _DuelingTail(torch.autograd.Function):
         if wj is not None and gemm3.supported(gemm3.NN, g, wj) and gemm3.supported(gemm3.TN, g, x):
             # the split-bf16 kernel takes the joint (rows, H1 + Hv) gradient as ONE K = H1 + Hv data gradient
             # and ONE weight gradient whose row blocks are dW1 | dWv
-            if ctx.needs_input_grad[0]:
+            link = getattr(ctx, "link", None)
+            if ctx.needs_input_grad[0] and link is not None and gemm3.grad_input_qp_supported(g, wj, link.emb, link.x, link.n):
+                # x is the IQN feature product's output: its backward rides in this GEMM's epilogue, dx is never stored
+                link.done = gemm3.grad_input_qp(g, wj, link.emb, link.x)
+                link.placeholder = dx = torch.zeros(1, dtype=x.dtype, device=x.device).expand(x.shape)
+            elif ctx.needs_input_grad[0]:
                 dx = gemm3.gemm(gemm3.NN, g, wj, weight_b=True)
             dwj = gemm3.gemm(gemm3.TN, g, x)
             dw1, dwv = dwj[:h1], dwj[h1:]

@@ -187,6 +187,33 @@ def grad_weight(g, x):
     return g.t().mm(x)
 
 
+_QP_BWD = os.environ.get("MIRL_GEMM3_QP_BWD", "1") != "0"   # 0: data gradient stored, then the separate feature-product backward pass
+
+
+def grad_input_qp_supported(g, w, emb, x, n):
+    """Can g (M,N) @ w (N,K) run with the IQN feature product's backward (out[r] = x[r // n] * emb[r]) in its epilogue?"""
+    return (_QP_BWD and enabled() and n == 32 and supported(NN, g, w) and _rowmajor(emb) and _rowmajor(x)
+            and emb.shape == (g.shape[0], w.shape[1]) and x.shape == (g.shape[0] // 32, w.shape[1]) and g.shape[0] % 32 == 0
+            and w.shape[1] % 4 == 0 and emb.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+            and emb.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def grad_input_qp(g, w, emb, x):
+    """-> (d_pre (M,K), dx (M/32,K), db (K,)) of the feature product for the gradient d = g @ w of its output; d is not stored."""
+    L = _lib()
+    M, N = g.shape
+    K = w.shape[1]
+    rows = C.c_int64()
+    L.check(L.lib.mirl_gemm3_nn_qp_partial_rows(M, C.byref(rows)), "mirl_gemm3_nn_qp_partial_rows")
+    d_pre = torch.empty((M, K), dtype=torch.float32, device=g.device)
+    dx = torch.empty((M // 32, K), dtype=torch.float32, device=g.device)
+    part = torch.empty((rows.value, K), dtype=torch.float32, device=g.device)
+    # NN form: the contraction runs over g's columns, the result is K wide
+    L.check(L.lib.mirl_gemm3_nn_qp(M, K, N, _p(g), g.stride(0), _p(w), w.stride(0), _p(emb), emb.stride(0), _p(x), x.stride(0),
+                                   _p(d_pre), d_pre.stride(0), _p(dx), dx.stride(0), _p(part), _stream()), "mirl_gemm3_nn_qp")
+    return d_pre, dx, part.sum(0)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):

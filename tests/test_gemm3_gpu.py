@@ -350,3 +350,88 @@ def test_dueling_tail_with_and_without_the_fused_output_layers(monkeypatch):
         else:
             assert torch.equal(got, ref), i
     assert torch.equal(out[True][0], out[True][2]) and torch.equal(out[True][1], out[True][3])
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 512), (4096 + 32 * 5, 528, 264), (64, 16, 64)])
+def test_feature_product_backward_in_the_data_gradient_epilogue(M, N, K, monkeypatch):
+    """mirl_gemm3_nn_qp: with d = g @ w (never stored), d_pre = (emb > 0) * d * x[row // 32], dx = group sums of d * emb,
+    db = column sums of d_pre — against the float64 evaluation of the same expressions; integer operands bit-exactly
+    (tile tails: M not a multiple of 256, K = the product's width not a multiple of 64)."""
+    from rltime_amd.models.torch import gemm3
+    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    gen = torch.Generator(device="cuda").manual_seed(M + N)
+    for integer in (True, False):
+        if integer:
+            g = torch.randint(-3, 4, (M, N), device="cuda", generator=gen).float()
+            w = torch.randint(-3, 4, (N, K), device="cuda", generator=gen).float()
+            emb = torch.randint(-2, 5, (M, K), device="cuda", generator=gen).float().clamp_(min=0)
+            x = torch.randint(-4, 5, (M // 32, K), device="cuda", generator=gen).float()
+        else:
+            g = torch.randn(M, N, device="cuda", generator=gen)
+            w = torch.randn(N, K, device="cuda", generator=gen) / N ** 0.5
+            emb = torch.randn(M, K, device="cuda", generator=gen).clamp_(min=0)
+            x = torch.randn(M // 32, K, device="cuda", generator=gen)
+        assert gemm3.grad_input_qp_supported(g, w, emb, x, 32)
+        d_pre, dx, db = gemm3.grad_input_qp(g, w, emb, x)
+        d = g.double() @ w.double()
+        want_pre = (emb > 0) * d * x.double().repeat_interleave(32, dim=0)
+        want_dx = (d * emb.double()).view(M // 32, 32, K).sum(1)
+        want_db = want_pre.sum(0)
+        for got, want, what in ((d_pre, want_pre, "d_pre"), (dx, want_dx, "dx"), (db, want_db, "db")):
+            if integer:
+                assert torch.equal(got.double(), want), what
+            else:
+                assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()), what
+    again = gemm3.grad_input_qp(g, w, emb, x)
+    assert all(torch.equal(a, b) for a, b in zip(again, (d_pre, dx, db)))          # fixed summation orders
+    assert not gemm3.grad_input_qp_supported(g, w, emb, x, 16)                      # groups of 32 rows only
+
+
+def _iqn_head(gen, M, n, D, Fd, H, A):
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=gen)       # noqa: E731
+    x = mk(M, Fd)
+    phi = torch.cos(torch.rand(M * n, 1, device="cuda", generator=gen) * torch.arange(1, D + 1, device="cuda") * 3.14159265)
+    qp = [mk(Fd, D) / D ** 0.5, mk(Fd) * 0.1]
+    tail = [mk(H, Fd) / Fd ** 0.5, mk(H), mk(A, H) / H ** 0.5, mk(A), mk(H, Fd) / Fd ** 0.5, mk(H), mk(1, H) / H ** 0.5, mk(1)]
+    return x, phi, qp, tail, mk(M * n, A), mk(M * n, 1)
+
+
+@pytest.mark.parametrize("second_consumer", [False, True])
+def test_dueling_tail_runs_the_feature_products_backward(monkeypatch, second_consumer):
+    """quantile_product -> (a reshape view) -> dueling tail, the IQN head of policies/torch/iqn.py:82-102 + dqn.py:101-112:
+    with the hand-over (fused._QPLink) the tail's data-gradient GEMM runs the product's backward (k_gemm3_nn_qp), the
+    stand-alone pass k_iqn_mul_bwd does not run, and every gradient equals the separate path's within f32 rounding; with
+    a SECOND consumer of the product's output the stand-alone pass runs on that consumer's gradient alone and the sums
+    are the same."""
+    from rltime_amd import _lib
+    from rltime_amd.models.torch import fused, gemm3
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    M, n, D, Fd, H, A = 256 + 8, 32, 64, 512, 512, 6
+    x, phi, qp, tail, ga, gv = _iqn_head(gen, M, n, D, Fd, H, A)
+    side = torch.randn(M * n, Fd, device="cuda", generator=gen)
+    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    out = {}
+    for mode in (True, False):
+        monkeypatch.setattr(gemm3, "_QP_BWD", mode)
+        xx = x.clone().requires_grad_(True)
+        pq = [p.clone().requires_grad_(True) for p in qp]
+        pt = [p.clone().requires_grad_(True) for p in tail]
+        _lib.check(_lib.lib.mirl_profile_reset())
+        _lib.check(_lib.lib.mirl_profile_set(2))
+        try:
+            prod = fused.quantile_product(xx, phi, pq[0], pq[1], n)
+            a, v = fused._DuelingTail.apply(prod.reshape(-1, Fd), *pt)
+            outs, grads = [a, v], [ga, gv]
+            if second_consumer:
+                outs.append((prod * side).sum())
+                grads.append(torch.ones((), device="cuda"))
+            torch.autograd.backward(outs, grads)
+            torch.cuda.synchronize()
+            ran = {r["name"]: r["calls"] for r in _lib.profile_table()}
+        finally:
+            _lib.check(_lib.lib.mirl_profile_set(0))
+        assert bool(ran.get("k_gemm3_nn_qp")) == mode, ran
+        assert bool(ran.get("k_iqn_mul_bwd")) == (second_consumer or not mode), ran
+        out[mode] = [xx.grad] + [p.grad for p in pq] + [p.grad for p in pt]
+    for i, (got, ref) in enumerate(zip(out[True], out[False])):
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), i
