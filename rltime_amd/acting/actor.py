@@ -278,9 +278,16 @@ class Actor(ActingInterface):
                 self._tracker.set_state(self._tracker_restore)
                 self._tracker_restore = None
         fs, sink = self._fast, self._sink
-        fs.refresh()
-        fs.set_eps(self._eps())
-        fs.reselect()
+        # weight-derived buffers and the pending action selection are functions of (parameters, epsilon, input state): the
+        # selection is idempotent on the carry and redraws the same Philox blocks, so a call that follows another one with NO
+        # learner update in between (two acting calls per optimizer step at the benchmark's train_frequency) keeps them
+        eps = self._eps()
+        stamp = (tuple((p.data_ptr(), p._version) for p in self._policy.parameters()), float(eps), fs.need_q)
+        if getattr(fs, "selected_with", None) != stamp:
+            fs.refresh()
+            fs.set_eps(eps)
+            fs.reselect()
+            fs.selected_with = stamp
         keep_policy = False
         if sink is not None:
             if sink._h is None:

@@ -285,6 +285,7 @@ class FastActingStep:
         self.h.copy_(keep[0])
         self.c.copy_(keep[1])
         self.reselect()
+        self.selected_with = None         # the caller (actor._fast_steps) refreshes the weight buffers and selects again
 
     def set_need_q(self, need_q):
         """Switch between the full dueling head and the advantage stream alone; the step graphs are re-captured."""
@@ -398,6 +399,7 @@ class FastActingStep:
         self.step_no = st["step_no"]
         self.rng_step.fill_(self.step_no)
         self.last_obs = st["last_obs"].to(self.dev)
+        self.selected_with = None
 
 
 def example_input_state(policy, obs, dones):
