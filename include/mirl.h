@@ -502,6 +502,12 @@ int mirl_conv2_bwd_data_supported(int32_t C, int32_t F, int32_t K, int32_t S, in
 int mirl_conv2_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight,
                         int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx,
                         void* stream);
+/* The same gradient on either matrix pipe: pipe 0 = f32 MFMA (the call above), pipe 1 = bf16 MFMA with mirl_gemm3's exact
+ * three-way split of both operands (six part products, f32 accumulation: f32 results, 2.65 x the f32 pipe's rate; bit-exact
+ * on small-integer operands, tests/test_conv_mid_gpu.py).  wpk: *floats of mirl_conv2_bwd_data_wpk_floats() for either pipe.    */
+int mirl_conv2_bwd_data_wpk_floats(int64_t* floats);
+int mirl_conv2_bwd_data_ex(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
+                           int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, int32_t pipe, void* stream);
 
 /* ---- f32 GEMMs of the wide layers on the bf16 matrix pipe (csrc/gemm3.hip).  Replaces the
  * library f32 GEMMs behind the nn.Linear layers of the reference's recurrent IQN model

@@ -261,14 +261,24 @@ def conv2_bwd_data_supported(x, weight, stride, g):
                                                          x.shape[3], g.shape[2], g.shape[3]))
 
 
-def conv2_bwd_data(g, weight, x_like):
+# which matrix pipe the layer-2 data gradient runs on: "bf16" = exact three-way split, f32 results (default), "f32" = f32 MFMA
+_CONV2_BWD_PIPE = 0 if os.environ.get("MIRL_CONV2_BWD_PIPE", "bf16") == "f32" else 1
+_c2_wpk_floats = None
+
+
+def conv2_bwd_data(g, weight, x_like, pipe=None):
     """d loss / d input of conv2d(x, weight, stride 2) for the (32 -> 64, k 4) layer; g is NHWC."""
+    global _c2_wpk_floats
     L = _lib()
+    if _c2_wpk_floats is None:
+        n = C.c_int64()
+        L.check(L.lib.mirl_conv2_bwd_data_wpk_floats(C.byref(n)), "mirl_conv2_bwd_data_wpk_floats")
+        _c2_wpk_floats = n.value
     dx = torch.empty_like(x_like, memory_format=torch.channels_last)
-    wpk = torch.empty(32768, dtype=torch.float32, device=g.device)
+    wpk = torch.empty(_c2_wpk_floats, dtype=torch.float32, device=g.device)
     so, sc, sh, sw = weight.stride()
-    L.check(L.lib.mirl_conv2_bwd_data(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
-                                      _stream()), "mirl_conv2_bwd_data")
+    L.check(L.lib.mirl_conv2_bwd_data_ex(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
+                                         _CONV2_BWD_PIPE if pipe is None else pipe, _stream()), "mirl_conv2_bwd_data_ex")
     return dx
 
 

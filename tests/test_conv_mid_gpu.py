@@ -1,5 +1,5 @@
-"""GPU: the second conv layer's data gradient on the f32 MFMA pipe (csrc/conv_mid.hip,
-mirl_conv2_bwd_data) against what autograd derives for conv2d(x, W, stride 2)
+"""GPU: the second conv layer's data gradient on either matrix pipe (csrc/conv_mid.hip, mirl_conv2_bwd_data_ex:
+f32 MFMA, or bf16 MFMA with the exact three-way split = the default) against what autograd derives for conv2d(x, W, stride 2)
 (rltime/models/torch/modules/cnn.py:47-49 at Conv2d(32 -> 64, k 4, s 2)).  Integer-
 valued operands make every partial sum exact in fp32: indexing is checked bit-exactly;
 real operands to the north-star 1e-4."""
@@ -13,15 +13,21 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _call(g, w):
+PIPES = [0, 1]      # 0: f32 MFMA, 1: bf16 MFMA, three-way split
+
+
+def _call(g, w, pipe):
     from rltime_amd._lib import lib, check
     n, _, oh, ow = g.shape
     dx = torch.full((n, 32, 2 * oh + 2, 2 * ow + 2), float("nan"), device="cuda").contiguous(memory_format=torch.channels_last)
-    wpk = torch.empty(32768, device="cuda")
+    floats = C.c_int64()
+    check(lib.mirl_conv2_bwd_data_wpk_floats(C.byref(floats)))
+    assert floats.value >= 32768
+    wpk = torch.empty(floats.value, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     so, sc, sh, sw = w.stride()
-    check(lib.mirl_conv2_bwd_data(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), p(dx),
-                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv2_bwd_data")
+    check(lib.mirl_conv2_bwd_data_ex(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), p(dx), pipe,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv2_bwd_data_ex")
     return dx
 
 
@@ -32,25 +38,31 @@ def _reference(g, w):
     return x.grad
 
 
+@pytest.mark.parametrize("pipe", PIPES)
 @pytest.mark.parametrize("n,oh,ow", [(1, 9, 9), (2, 9, 9), (3, 9, 9), (1025, 9, 9), (2, 1, 1), (3, 4, 7), (5, 12, 3), (1027, 5, 6)])
-def test_integer_operands_are_bit_exact(n, oh, ow):
+def test_integer_operands_are_bit_exact(n, oh, ow, pipe):
     gen = torch.Generator(device="cuda").manual_seed(n * 31 + oh)
     g = torch.randint(-3, 4, (n, 64, oh, ow), device="cuda", generator=gen).float().contiguous(memory_format=torch.channels_last)
     w = torch.randint(-2, 3, (64, 32, 4, 4), device="cuda", generator=gen).float()
     want = _reference(g, w).float()
-    got = _call(g, w)
+    got = _call(g, w, pipe)
     assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, want)
-    assert torch.equal(_call(g, w.contiguous(memory_format=torch.channels_last)), want)
+    assert torch.equal(_call(g, w.contiguous(memory_format=torch.channels_last), pipe), want)
 
 
+@pytest.mark.parametrize("pipe", PIPES)
 @pytest.mark.parametrize("n,oh,ow", [(4, 9, 9), (1031, 9, 9)])
-def test_real_operands_within_tolerance(n, oh, ow):
+def test_real_operands_within_tolerance(n, oh, ow, pipe):
     gen = torch.Generator(device="cuda").manual_seed(n)
     g = torch.randn(n, 64, oh, ow, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
     w = torch.randn(64, 32, 4, 4, device="cuda", generator=gen) * 0.05
     want = _reference(g, w)
-    got = _call(g, w)
-    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    got = _call(g, w, pipe)
+    err = float((got.double() - want).abs().max()) / float(want.abs().max())
+    assert err <= 1e-5
+    if pipe == 1:          # the split products are held to the f32 pipe's own distance from float64
+        err32 = float((_call(g, w, 0).double() - want).abs().max()) / float(want.abs().max())
+        assert err <= max(2.0 * err32, 2e-6), (err, err32)
 
 
 def test_layer_backward_uses_it_and_matches_the_library_path(monkeypatch):
@@ -65,6 +77,7 @@ def test_layer_backward_uses_it_and_matches_the_library_path(monkeypatch):
     x = torch.randn(37, 32, 20, 20, device="cuda").contiguous(memory_format=torch.channels_last)
     up = None
     res = []
+    assert fused._CONV2_BWD_PIPE == 1                       # the split-bf16 kernel is the default
     for on in (True, False):
         monkeypatch.setattr(fused, "_CONV2_BWD", on)
         conv.zero_grad(set_to_none=True)
