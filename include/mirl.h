@@ -444,6 +444,10 @@ int mirl_conv1_u8_wpk_floats(int64_t* out);
 /* process-wide choice of the forward's matrix pipe: 1 = bf16 (exact split), 0 = f32 MFMA, < 0 = back to the
  * MIRL_CONV1_BF16 environment default.  For in-process A/B runs (tests/test_network_ab_gpu.py).              */
 int mirl_conv1_bf16_set(int32_t mode);
+/* Same switch for the layer's WEIGHT gradient (mirl_conv1_u8_wrw / _wrw_ex / _wrw_masked): 1 = bf16 MFMA with the exact
+ * three-way split of the gradient operand (pixels are exact in bf16; the default, MIRL_CONV1_WRW_BF16), 0 = f32 MFMA,
+ * negative = back to the environment's choice.  In-process A/B tests.                                                  */
+int mirl_conv1_wrw_bf16_set(int32_t mode);
 int mirl_conv1_u8_fwd(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* weight,
                       int64_t ws_o, int64_t ws_c, int64_t ws_h, int64_t ws_w, const float* bias,
                       float scale, float* wpk, float* y, void* stream);

@@ -161,6 +161,7 @@ _SIGNATURES = {
     "mirl_frames_to_f32_nhwc_ex": [_i64, _i32, _i32, _vp, C.c_float, _vp, _i32, _i32, _vp],
     "mirl_conv1_u8_supported": [_i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv1_bf16_set": [_i32],
+    "mirl_conv1_wrw_bf16_set": [_i32],
     "mirl_conv1_u8_wpk_floats": [_P(_i64)],
     "mirl_conv1_u8_fwd": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, C.c_float, _vp, _vp, _vp],
     "mirl_conv1_u8_fwd_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, C.c_float, _vp, _vp, _i32, _vp],

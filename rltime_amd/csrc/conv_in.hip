@@ -38,6 +38,8 @@
 // down in this file) reads the same uint8 frames.  Autograd wiring:
 // rltime_amd/models/torch/fused.py:_ConvU8BiasReLU.
 #include "common.hpp"
+#include "split3.hpp"
+#include <stdlib.h>
 #include <unordered_map>
 
 namespace mirl {
@@ -496,6 +498,190 @@ k_conv1_u8_wrw(int N, int H, int W, int OH, int OW, unsigned ow_magic, int pitch
 #undef C1_WRW_LOAD
 #undef C1_WRW_COMPUTE
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient on the bf16 matrix pipe, still an f32 result (the forward's argument turned around): a uint8
+// pixel is EXACT in bf16, so only g needs the three-way split of csrc/gemm3.hip (g = hi + mid + lo exactly) and
+// g * x is the sum of THREE bf16 products, each exact in the MFMA's f32 accumulator: v_mfma_f32_16x16x32_bf16, rows =
+// 16 filters, columns = 16 taps, K = 32 output positions per instruction — 2.5 PFLOP/s / 3 against the f32 pipe's 157.
+//   * positions are walked in OCTETS of 8 consecutive ow of one output row (a row of OW positions = ceil(OW / 8) octets, the
+//     tail octet's positions beyond OW carry g = 0): lane quarter kq of a K-step owns octet 4 ks + kq, so a lane's 8
+//     A values are g[oh][ow0 .. ow0 + 7][filter] (8 strided loads, split in registers) and its 8 B values for tap
+//     (c, kh, kw) are the pixels x[c][4 oh + kh][4 (ow0 + e) + kw], e < 8: a stride-4 run of one frame row;
+//   * the frame is staged ONCE per workgroup as bf16 (two bytes per pixel, converted while staging: 24 VALU ops per 16
+//     pixels instead of 12 per fragment), so a B fragment is eight 2-byte LDS reads and no conversion; 56.7 KB per
+//     84 x 84 x 4 frame: two workgroups per CU;
+//   * per K-step a wave issues 96 MFMAs (16 tap groups x 2 filter halves x 3 parts of g) on 32 independent accumulator
+//     tiles (the WHOLE 32 x 256 result stays in registers as in the f32 kernel), smallest part first;
+//   * partials, the masked form and the bias gradient exactly as above (same slabs, same k_conv1_wrw_reduce).
+template <bool MASK>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_conv1_u8_wrw_b3(int N, int H, int W, int OH, int OW, int Pd, const uint8_t* __restrict__ x, const float* __restrict__ g,
+                  float* __restrict__ partial, const float* __restrict__ yv, int slab) {
+  extern __shared__ __align__(16) uint8_t c1_lds[];
+  uint16_t* px = reinterpret_cast<uint16_t*>(c1_lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kq = lane >> 4;
+  const int HW = H * W, OHW = OH * OW, hw16 = HW >> 4;
+  const int no = (OW + 7) >> 3, octets = OH * no, ksteps = (octets + 3) >> 2;
+  const int tap_off = (j >> 3) * W + (j & 7);
+  float dbs[2] = {0.f, 0.f};
+  g3_f32x4 acc0[16], acc1[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) { acc0[t] = g3_f32x4{0.f, 0.f, 0.f, 0.f}; acc1[t] = g3_f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // the slack behind each plane is read (tail octets) but never staged: zero it once — any finite value would do, times g = 0
+  for (int i = tid; i < C1_PLANES * (Pd - HW); i += 256) { const int pl = i / (Pd - HW); px[pl * Pd + HW + (i - pl * (Pd - HW))] = 0; }
+  bool first = true;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    if (!first) __syncthreads();                  // every wave is done reading the previous frame
+    first = false;
+    {
+      // the frame's 4 planes are one contiguous run of 16 B vectors in HBM; 16 pixels -> 16 bf16 = two 16 B LDS stores
+      const int vecs = C1_PLANES * hw16;
+      const uint4* s4 = reinterpret_cast<const uint4*>(x + (int64_t)n * (C1_PLANES * HW));
+      for (int o0 = tid; o0 < vecs; o0 += 256 * C1_LD) {
+        uint4 v[C1_LD];
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) { const int o = o0 + k * 256; v[k] = s4[o < vecs ? o : vecs - 1]; }
+#pragma unroll
+        for (int k = 0; k < C1_LD; ++k) {
+          const int o = o0 + k * 256;
+          if (o < vecs) {
+            const int pl = o / hw16;
+            const uint32_t wv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            uint32_t h[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              // float(byte) has at most 8 significant bits: its top 16 bits ARE the bf16 value
+              const uint32_t f0 = __float_as_uint(c1_byte(wv[d], 0)), f1 = __float_as_uint(c1_byte(wv[d], 1));
+              const uint32_t f2 = __float_as_uint(c1_byte(wv[d], 2)), f3 = __float_as_uint(c1_byte(wv[d], 3));
+              h[2 * d] = (f0 >> 16) | (f1 & 0xffff0000u);
+              h[2 * d + 1] = (f2 >> 16) | (f3 & 0xffff0000u);
+            }
+            uint4* d4 = reinterpret_cast<uint4*>(px + pl * Pd + (o - pl * hw16) * 16);
+            d4[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            d4[1] = make_uint4(h[4], h[5], h[6], h[7]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const float* gf = g + (int64_t)n * OHW * C1_F + j;
+    // the NEXT K-step's g (and y) values are requested before this K-step's split and MFMAs: with two waves per SIMD
+    // nothing else covers a global load's latency
+    float gn[2][8], yn[2][8];
+    auto request = [&](int ks) {
+      const int o = ks * 4 + kq;
+      const int ohr = o / no, ow0 = (o - ohr * no) * 8;
+      const int oh = ohr < OH ? ohr : OH - 1;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ow = ow0 + e;
+          const int64_t off = (int64_t)(oh * OW + (ow < OW ? ow : OW - 1)) * C1_F + 16 * m;
+          gn[m][e] = gf[off];
+          if (MASK) yn[m][e] = yv[(gf - g) + off];
+        }
+    };
+    if (wave < ksteps) request(wave);
+    for (int ks = wave; ks < ksteps; ks += 4) {
+      // this lane's octet: 8 consecutive ow of output row oh
+      const int o = ks * 4 + kq;
+      const int ohr = o / no, ow0 = (o - ohr * no) * 8;
+      const bool row_ok = ohr < OH;
+      const int oh = row_ok ? ohr : OH - 1;
+      float gc[2][8];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = gn[m][e];
+          if (MASK) t = yn[m][e] > 0.f ? t : 0.f;                 // the layer's ReLU
+          gc[m][e] = (row_ok && ow0 + e < OW) ? t : 0.f;
+        }
+      if (ks + 4 < ksteps) request(ks + 4);
+      uint4 ap[2][3];                               // [filter half][part] = 8 bf16 along k
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float gv[2][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          gv[e >> 2][e & 3] = gc[m][e];
+          if (MASK) dbs[m] += gc[m][e];
+        }
+        uint2 h0, m0, l0, h1, m1, l1;
+        g3_split4(gv[0], h0, m0, l0);
+        g3_split4(gv[1], h1, m1, l1);
+        ap[m][0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        ap[m][1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        ap[m][2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      }
+      const uint16_t* pb = px + (oh * C1_S) * W + ow0 * C1_S + tap_off;
+      // tap group t: plane t >> 2, rows kh = 2 (t & 3) + (j >> 3) (in tap_off), 8 positions 4 pixels apart.  The NEXT
+      // group's eight halfwords are requested before this group's six MFMAs (left alone the compiler reads, waits,
+      // multiplies, reads ...: the LDS latency of every group exposed)
+      uint32_t raw[2][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[0][e] = pb[4 * e];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t + 1 < 16) {
+          const uint16_t* pt = pb + ((t + 1) >> 2) * Pd + ((t + 1) & 3) * 2 * W;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) raw[(t + 1) & 1][e] = pt[4 * e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t* rw = raw[t & 1];
+        const g3_bf16x8 bv = __builtin_bit_cast(g3_bf16x8, make_uint4(rw[0] | (rw[1] << 16), rw[2] | (rw[3] << 16),
+                                                                     rw[4] | (rw[5] << 16), rw[6] | (rw[7] << 16)));
+#pragma unroll
+        for (int p = 2; p >= 0; --p) {              // smallest part of g first
+          acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g3_bf16x8, ap[0][p]), bv, acc0[t], 0, 0, 0);
+          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g3_bf16x8, ap[1][p]), bv, acc1[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // workgroup partial: waves add up in LDS in wave order.  Accumulator tile (half m, tap group t): row 4 kq + r <-> filter
+  // 16 m + 4 kq + r, column j <-> tap t * 16 + j
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(c1_lds);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i0 = (4 * kq + r) * (C1_PLANES * C1_TAPS) + t * 16 + j, i1 = i0 + 16 * C1_PLANES * C1_TAPS;
+          red[i0] = (w ? red[i0] : 0.f) + acc0[t][r];
+          red[i1] = (w ? red[i1] : 0.f) + acc1[t][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (MASK) {
+    // bias gradient: lane (j, kq) summed filters j and 16 + j over its octets; the four kq in a fixed butterfly, the four
+    // waves in wave order behind the slab's 8192 weight-gradient sums
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { dbs[m] += __shfl_xor(dbs[m], 16); dbs[m] += __shfl_xor(dbs[m], 32); }
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w && kq == 0) {
+        red[C1_DW + j] = (w ? red[C1_DW + j] : 0.f) + dbs[0];
+        red[C1_DW + 16 + j] = (w ? red[C1_DW + 16 + j] : 0.f) + dbs[1];
+      }
+      __syncthreads();
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * slab;
+  for (int k = tid; k < (MASK ? C1_DW + C1_F : C1_DW); k += 256) out[k] = red[k];
+}
+
+// LDS halfwords per plane of the bf16 frame: the frame, the over-read of a row's tail octet (its positions beyond OW carry
+// g = 0 but are still read), rounded to 16 bytes
+static int c1b_pitch(int HW, int OW) { return (HW + 4 * (8 * ((OW + 7) / 8) - OW) + 8 + 7) / 8 * 8; }
+
 // dw[f][c][kh][kw] (element strides so, sc, sh, sw) = scale * sum of the slabs in slab order
 __global__ void __launch_bounds__(256)
 k_conv1_wrw_reduce(const float* __restrict__ partial, int parts, float scale, float* __restrict__ dw, int64_t so, int64_t sc,
@@ -521,6 +707,38 @@ static int c1_pitch(int HW) {
   return dw * 4;
 }
 
+}  // namespace mirl
+
+static int g_conv1_wrw_bf16 = -1;  // -1: MIRL_CONV1_WRW_BF16 (default on); 0 / 1: set by mirl_conv1_wrw_bf16_set (in-process A/B tests)
+extern "C" int mirl_conv1_wrw_bf16_set(int32_t mode) {
+  g_conv1_wrw_bf16 = mode < 0 ? -1 : (mode ? 1 : 0);
+  return MIRL_OK;
+}
+
+namespace mirl {
+// the weight gradient on the bf16 pipe (k_conv1_u8_wrw_b3) when the bf16 frame fits the LDS, else / when switched off: false
+template <bool MASK>
+static int c1_wrw_b3(int64_t N, int32_t H, int32_t W, const uint8_t* x, const float* g, const float* y, float* scratch, int slab,
+                     unsigned* grid_out, hipStream_t st, bool* ran) {
+  static const int env = getenv("MIRL_CONV1_WRW_BF16") ? atoi(getenv("MIRL_CONV1_WRW_BF16")) : 1;
+  *ran = false;
+  if (!(g_conv1_wrw_bf16 >= 0 ? g_conv1_wrw_bf16 : env)) return MIRL_OK;
+  const int OH = (H - C1_K) / C1_S + 1, OW = (W - C1_K) / C1_S + 1, HW = H * W, Pd = c1b_pitch(HW, OW);
+  size_t lds = (size_t)C1_PLANES * Pd * 2;
+  if (lds > 80 * 1024) return MIRL_OK;                             // two workgroups per CU or the f32-pipe kernel
+  if (lds < (size_t)slab * 4) lds = (size_t)slab * 4;              // the workgroup's partial is reduced there
+  const unsigned grid = (unsigned)(N < 512 ? N : 512);
+  static bool attr[2] = {false, false};
+  const void* fn = (const void*)k_conv1_u8_wrw_b3<MASK>;
+  if (!attr[MASK]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr[MASK] = true; }
+  ProfScope ps("k_conv1_u8_wrw_b3", (double)N * (C1_PLANES * HW + (MASK ? 2.0 : 1.0) * OH * OW * C1_F * 4), st,
+               (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
+  hipLaunchKernelGGL((k_conv1_u8_wrw_b3<MASK>), dim3(grid), dim3(256), lds, st, (int)N, H, W, OH, OW, Pd, x, g, scratch, y, slab);
+  MIRL_LAUNCH_CHECK();
+  *grid_out = grid;
+  *ran = true;
+  return MIRL_OK;
+}
 }  // namespace mirl
 
 static int g_conv1_bf16 = -1;      // -1: MIRL_CONV1_BF16 (default on); 0 / 1: set by mirl_conv1_bf16_set (in-process A/B tests)
@@ -669,6 +887,18 @@ extern "C" int mirl_conv1_u8_wrw_ex(int64_t N, int32_t H, int32_t W, const uint8
   size_t lds = (size_t)fpi * C1_PLANES * pitch;
   if (lds < (size_t)C1_DW * 4) lds = (size_t)C1_DW * 4;          // the workgroup's 32 KB partial is reduced there
   const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
+  bool b3 = false;
+  unsigned b3_grid = 0;
+  if (!(flags & 2)) {                                               // flags bit 1: force the f32-pipe kernel
+    if (int rc = c1_wrw_b3<false>(N, H, W, x, g, nullptr, scratch, (int)C1_DW, &b3_grid, st, &b3)) return rc;
+  }
+  if (b3) {
+    ProfScope ps("k_conv1_wrw_reduce", (double)b3_grid * C1_DW * 4, st);
+    hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((C1_DW + 255) / 256), dim3(256), 0, st, scratch, (int)b3_grid, scale, dw, ws_o, ws_c, ws_h, ws_w,
+                       (int)C1_DW, (float*)nullptr);
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
   {
     ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + (double)OH * OW * C1_F * 4), st,
                  (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);
@@ -708,6 +938,15 @@ extern "C" int mirl_conv1_u8_wrw_masked(int64_t N, int32_t H, int32_t W, const u
   size_t lds = (size_t)fpi * C1_PLANES * pitch;
   if (lds < (size_t)slab * 4) lds = (size_t)slab * 4;
   const unsigned ow_magic = OW > 1 ? (unsigned)(((1ULL << 32) + OW - 1) / OW) : 0u;
+  bool b3 = false;
+  unsigned b3_grid = 0;
+  if (int rc = c1_wrw_b3<true>(N, H, W, x, dy, y, scratch, slab, &b3_grid, st, &b3)) return rc;
+  if (b3) {
+    ProfScope ps("k_conv1_wrw_reduce", (double)b3_grid * slab * 4, st);
+    hipLaunchKernelGGL(k_conv1_wrw_reduce, dim3((slab + 255) / 256), dim3(256), 0, st, scratch, (int)b3_grid, scale, dw, ws_o, ws_c, ws_h, ws_w, slab, db);
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
   {
     ProfScope ps("k_conv1_u8_wrw", (double)N * (C1_PLANES * HW + 2.0 * OH * OW * C1_F * 4), st,
                  (double)N * OH * OW * 2.0 * C1_PLANES * C1_K * C1_K * C1_F);

@@ -148,6 +148,16 @@ def _wrw(x, g, scale, like, flags=None):
     return dw
 
 
+@pytest.fixture(params=[1, 0], ids=["wrw-bf16-pipe", "wrw-f32-pipe"])
+def wrw_pipe(request):
+    """Both matrix pipes of the weight gradient (k_conv1_u8_wrw_b3: exact three-way split of g on the bf16 pipe, the
+    default; k_conv1_u8_wrw: f32 MFMA) through the same entry points."""
+    from rltime_amd._lib import lib, check
+    check(lib.mirl_conv1_wrw_bf16_set(request.param))
+    yield request.param
+    check(lib.mirl_conv1_wrw_bf16_set(-1))
+
+
 def _wrw_reference(x, g, scale):
     # d/dW of sum(conv2d(x*scale, W) * g) in float64
     w = torch.zeros(32, 4, 8, 8, dtype=torch.float64, device="cuda", requires_grad=True)
@@ -156,7 +166,7 @@ def _wrw_reference(x, g, scale):
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 84, 84), (2, 84, 84), (3, 36, 36), (2, 44, 52), (4, 12, 16), (3, 8, 8), (1, 100, 100)])
-def test_weight_gradient_integer_case_is_bit_exact(n, h, w):
+def test_weight_gradient_integer_case_is_bit_exact(n, h, w, wrw_pipe):
     g_ = torch.Generator(device="cuda").manual_seed(n * 100 + w)
     x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g_)
     oh, ow = (h - 8) // 4 + 1, (w - 8) // 4 + 1
@@ -169,7 +179,7 @@ def test_weight_gradient_integer_case_is_bit_exact(n, h, w):
 
 
 @pytest.mark.parametrize("n,h,w", [(5, 84, 84), (1025, 84, 84), (2051, 84, 84), (1030, 44, 52)])
-def test_weight_gradient_within_tolerance_and_reproducible(n, h, w):
+def test_weight_gradient_within_tolerance_and_reproducible(n, h, w, wrw_pipe):
     g_ = torch.Generator(device="cuda").manual_seed(n)
     x = torch.randint(0, 256, (n, 4, h, w), dtype=torch.uint8, device="cuda", generator=g_)
     oh, ow = (h - 8) // 4 + 1, (w - 8) // 4 + 1
@@ -183,10 +193,14 @@ def test_weight_gradient_within_tolerance_and_reproducible(n, h, w):
     want = _wrw_reference(x, g, 1.0 / 255.0)
     err = float((a.double() - want).abs().max()) / float(want.abs().max())
     assert err <= 1e-4, err
+    if wrw_pipe == 1:       # the split products are held to the f32 pipe's own distance from float64 (flags bit 1: that kernel)
+        f32 = _wrw(x, g, 1.0 / 255.0, like, flags=2)
+        err32 = float((f32.double() - want).abs().max()) / float(want.abs().max())
+        assert err <= max(2.0 * err32, 2e-6), (err, err32)
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 84, 84), (3, 36, 36), (1, 8, 8), (1027, 84, 84), (1030, 44, 52)])
-def test_masked_weight_gradient_equals_mask_pass_plus_weight_gradient(n, h, w):
+def test_masked_weight_gradient_equals_mask_pass_plus_weight_gradient(n, h, w, wrw_pipe):
     """mirl_conv1_u8_wrw_masked: the layer's ReLU mask (y > 0, cnn.py:47-49) applied while dy is loaded and the bias
     gradient from the same pass, against the two-launch form (k_relu_bwd_bias_rows, then mirl_conv1_u8_wrw on its
     output): the weight gradient is BIT-identical (the same masked values enter the same sums in the same order), the

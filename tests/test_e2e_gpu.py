@@ -250,7 +250,7 @@ def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
 
 # kernels of rounds 2-3 the wide trajectory must have gone through (names as mirl_profile_* records them)
 ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd", "k_conv1_u8_fwd",
-                  "k_conv1_u8_wrw", "k_conv2_bwd_data_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
+                  "k_conv1_u8_wrw_b3", "k_conv2_bwd_data_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
 
 
 @pytest.mark.parametrize("forced,nhwc", [(True, True), ("gemm3", True), ("conv", True), ("lstm", True), (False, True), (False, False)],
