@@ -611,6 +611,21 @@ int mirl_im2col_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int
 int mirl_col2im_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t S, const float* col,
                      const float* relu_mask, float* dx, void* stream);
 
+/* ---- weight gradient of the middle conv layers on the bf16 matrix pipe, f32 results (csrc/conv_wrw.hip).
+ * Replaces MIOpen's igemm_wrw kernels behind autograd for conv layers 2 and 3
+ * (rltime/models/torch/modules/cnn.py:43-50):
+ *   dw[f][kh][kw][c] = sum over (n, oh, ow) of g[n][oh][ow][f] * x[n][S oh + kh][S ow + kw][c]
+ *   x float [N][H][W][C], g float [N][OH][OW][F] (NHWC memory), dw float [F][KH][KW][C] (channels_last weight memory);
+ *   no padding, no dilation.  Both operands split exactly into three bf16 parts, six part products, f32 accumulation
+ *   (mirl_gemm3's method): bit-exact on small-integer operands, fp32 tolerance otherwise (tests/test_conv_wrw_gpu.py).
+ * mirl_conv_wrw_b3_supported(): F == 64, C % 4 == 0, (KH * KW * C) % 16 == 0 and <= 640, one frame's operands inside
+ * the LDS; otherwise 0 and the caller keeps the library path.  scratch: mirl_conv_wrw_b3_scratch_bytes() bytes, 16-byte
+ * aligned (one [F][KH*KW*C] slab per workgroup, summed in a fixed order: bit-identical reruns).                      */
+int mirl_conv_wrw_b3_supported(int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S, int32_t H, int32_t W);
+int mirl_conv_wrw_b3_scratch_bytes(int32_t C, int32_t F, int32_t KH, int32_t KW, int64_t* bytes);
+int mirl_conv_wrw_b3(int64_t N, int32_t H, int32_t W, int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S,
+                     const float* x, const float* g, void* scratch, int64_t scratch_bytes, float* dw, void* stream);
+
 /* ---- non-contraction glue around the network's GEMMs / convolutions (csrc/nnops.hip).
  * All tensors row-major (rows, C), channel / feature index fastest (NHWC
  * activations, (M, features) matrices).  One HBM pass each; column sums are

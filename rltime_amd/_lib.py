@@ -175,6 +175,9 @@ _SIGNATURES = {
     "mirl_conv2_bwd_data_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "mirl_conv3_fwd_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv3_fwd": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
+    "mirl_conv_wrw_b3_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "mirl_conv_wrw_b3_scratch_bytes": [_i32, _i32, _i32, _i32, _P(_i64)],
+    "mirl_conv_wrw_b3": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp],
     "mirl_im2col_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "mirl_col2im_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_gemm3_supported": [_i32, _i64, _i64, _i64],

@@ -172,6 +172,9 @@ class _ConvBiasReLU(torch.autograd.Function):
             if need_x:
                 dx = conv_dgrad_col(g, x, weight, ctx.stride)
             need_x = need_w = False
+        if need_w and conv_wrw_supported(x, weight, ctx.stride, g):
+            dw = conv_wgrad_b3(g, x, weight, ctx.stride)      # split-bf16 implicit GEMM, reduction over positions (csrc/conv_wrw.hip)
+            need_w = False
         if need_x and _CONV2_BWD and g.shape[0] and conv2_bwd_data_supported(x, weight, ctx.stride, g):
             dx = conv2_bwd_data(g, weight, x)          # f32 MFMA, four parity-class GEMMs (csrc/conv_mid.hip)
             need_x = False
@@ -183,6 +186,43 @@ class _ConvBiasReLU(torch.autograd.Function):
 
 
 _CONV2_BWD = os.environ.get("MIRL_CONV2_BWD", "1") != "0"   # 0: MIOpen data gradient for the second conv layer
+# weight gradient of conv layers 2-3 on the bf16 pipe (csrc/conv_wrw.hip); 0: MIOpen.  Frame counts whose multiply-adds stay
+# below MIRL_CONV_WRW_MIN_WORK keep the library either way (launch-bound shapes)
+_CONV_WRW = os.environ.get("MIRL_CONV_WRW", "1") != "0"
+_CONV_WRW_MIN_WORK = int(os.environ.get("MIRL_CONV_WRW_MIN_WORK", str(1 << 31)))
+_wrw_scratch = {}
+
+
+def conv_wrw_supported(x, weight, stride, g, min_work=None):
+    """Does csrc/conv_wrw.hip take this NHWC conv's weight gradient?"""
+    if not (_CONV_WRW and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.dim() == 4 and stride[0] == stride[1] and g.shape[0] > 0
+            and x.is_contiguous(memory_format=torch.channels_last) and g.is_contiguous(memory_format=torch.channels_last)
+            and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and not torch.is_autocast_enabled()):
+        return False
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    work = g.shape[0] * g.shape[2] * g.shape[3] * f * c * kh * kw
+    if work < (_CONV_WRW_MIN_WORK if min_work is None else min_work):
+        return False
+    return bool(_lib().lib.mirl_conv_wrw_b3_supported(c, f, kh, kw, int(stride[0]), h, w))
+
+
+def conv_wgrad_b3(g, x, weight, stride):
+    """d loss / d weight of conv2d(x, weight, stride) in the weight's channels_last memory format."""
+    L = _lib()
+    n, c, h, w = x.shape
+    f, _, kh, kw = weight.shape
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, c, f, kh, kw)
+    scratch = _wrw_scratch.get(key)
+    if scratch is None:
+        nbytes = C.c_int64()
+        L.check(L.lib.mirl_conv_wrw_b3_scratch_bytes(c, f, kh, kw, C.byref(nbytes)), "mirl_conv_wrw_b3_scratch_bytes")
+        scratch = _wrw_scratch[key] = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((f, kh, kw, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib.mirl_conv_wrw_b3(n, h, w, c, f, kh, kw, int(stride[0]), _p(x), _p(g), _p(scratch), scratch.numel(), _p(dw),
+                                   _stream()), "mirl_conv_wrw_b3")
+    return dw.permute(0, 3, 1, 2)                     # logical (F, C, KH, KW) with channels_last strides
 # conv layers 2-3 backward as im2col / col2im around the split-bf16 GEMMs.  MEASURED SLOWER and therefore OFF by default
 # (MIRL_CONV_COL=1 turns it on): the explicit window matrix is 4.6 GB (layer 3) + 6.8 GB (layer 2) at the 40 960 frames of
 # a learner step, written once and read once per gradient — 102.7 vs 93.7 ms per step on the same box

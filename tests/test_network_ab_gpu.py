@@ -88,11 +88,14 @@ def _set_mode(monkeypatch, mode):
         monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
         monkeypatch.setattr(fused, "_CONV3", True)
         monkeypatch.setattr(fused, "_CONV3_MIN_WORK", 0)
+        monkeypatch.setattr(fused, "_CONV_WRW", True)
+        monkeypatch.setattr(fused, "_CONV_WRW_MIN_WORK", 0)
         monkeypatch.setattr(lstm_seq, "_PERSISTENT", True)
         _lib.check(_lib.lib.mirl_conv1_bf16_set(1))
     else:
         monkeypatch.setenv("MIRL_GEMM3", "0")
         monkeypatch.setattr(fused, "_CONV3", False)
+        monkeypatch.setattr(fused, "_CONV_WRW", False)
         monkeypatch.setattr(lstm_seq, "_PERSISTENT", False)
         _lib.check(_lib.lib.mirl_conv1_bf16_set(0))
 
