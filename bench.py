@@ -476,13 +476,13 @@ def copy_peak(device, stream_ptr_fn):
 #   bf16x3  uint8 pixel x three-way split weight (csrc/conv_in.hip forward)                 -> 2.5 PF / 3
 #   f32     v_mfma_f32_16x16x4_f32 (input layer's weight gradient, layer 2's data gradient, LSTM sweeps)
 PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nt_head": "bf16x6", "k_gemm3_ps": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
-           "k_conv1_u8_fwd": "bf16x3", "k_conv1_u8_wrw": "f32", "k_conv1_u8_wrw_b3": "bf16x3", "k_conv2_bwd_data": "f32", "k_conv2_bwd_data_b3": "bf16x6", "k_conv_wrw_b3": "bf16x6", "k_gemm3_nn_qp": "bf16x6",
+           "k_conv1_u8_fwd": "bf16x3", "k_conv1_u8_wrw": "f32", "k_conv1_u8_wrw_b3": "bf16x3", "k_conv2_bwd_data": "f32", "k_conv2_bwd_data_b3": "bf16x6", "k_conv3_bwd_data_b3": "bf16x6", "k_conv_wrw_b3": "bf16x6", "k_gemm3_nn_qp": "bf16x6",
            "k_lstm_seq_fwd": "f32", "k_lstm_seq_bwd": "f32", "k_lstm_step_fwd": "f32"}
 # launch / dependency-latency bound by construction (one workgroup of bookkeeping, one tree level per barrier, 256-row
 # acting batches, one LSTM step per launch): microseconds per call is the figure, an HBM fraction would be noise
 LATENCY_KERNELS = {"k_ingest_fused", "k_ingest_scalars", "k_plan_apply", "k_actor_pre", "k_actor_head", "k_lstm_cell_fwd", "k_lstm_cell_bwd",
                    "k_tree_fix", "k_tree_fix(ingest)", "k_per_sample", "k_per_sample_global", "k_uniform_sample", "k_loss_stamp",
-                   "k_loss_write", "k_recalc_flagged", "k_recalc_flagged_wave", "k_gather_scalars", "k_conv1_pack_w", "k_conv2_pack_w", "k_conv2_pack_w3b",
+                   "k_loss_write", "k_recalc_flagged", "k_recalc_flagged_wave", "k_gather_scalars", "k_conv1_pack_w", "k_conv2_pack_w", "k_conv2_pack_w3b", "k_conv3_pack_w3b",
                    "k_colsum_partials", "k_episode_track", "k_acting_td", "k_dedup_depth", "k_gemm3_reduce", "k_conv1_wrw_reduce", "k_conv_wrw_reduce"}
 
 

@@ -314,6 +314,164 @@ k_conv2_bwd_data_b3(int N, int OH, int OW, unsigned v_magic, const float* __rest
 
 static size_t c2b_lds_bytes(int fpi, int OH, int OW) { return (size_t)3 * 2 * c2b_half_plane((fpi * (OH + 1) + 1) * (OW + 2)); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Layer 3's data gradient (64 -> 64 filters, kernel 3, stride 1: autograd of cnn.py:47-49 at the Atari models' third conv
+// layer; MIOpen's igemm_bwd ran it at 2.1 ms per learner step on the f32 pipe) with the machinery above:
+//   dx[y][x][c] = sum over kh, kw < 3, f < 64 of g[y - kh][x - kw][f] * W[f][c][kh][kw]        (g zero outside the frame)
+// One GEMM per frame — rows = 16 of the 64 channels, columns = 16 pixels, K = 9 taps x 64 filters = 18 K-steps of 32 — but
+// 16 channels x 576 are 216 VGPRs as three bf16 parts, so the 8 waves are 4 channel tiles x 2 K HALVES (9 K-steps, 108
+// VGPRs of weights each): a wave multiplies its half for ALL pixel tiles of the fill (<= 11 accumulator tiles), then the
+// upper halves leave their partial tiles in LDS (the g planes are dead by then) and the lower halves add and store.
+// g is staged exactly as above (three bf16 parts, the conflict-free chunk layout) inside a TWO-position zero border.
+constexpr int C3B_C = 64, C3B_F = 64, C3B_K = 3;
+constexpr int C3B_HS = 9;                      // K-steps per K half (18 in all: tap s >> 1, filters 32 (s & 1) ..)
+constexpr int C3B_SLOTS = 4 * 2 * C3B_HS;      // (channel tile, K half, step)
+constexpr int C3B_WPK_BYTES = C3B_SLOTS * 3 * 64 * 16;
+constexpr int C3B_MAXT = 11;                   // pixel tiles per fill: two 9 x 9 frames
+
+__global__ void __launch_bounds__(256)
+k_conv3_pack_w3b(const float* __restrict__ w, int64_t so, int64_t sc, int64_t sh, int64_t sw, uint4* __restrict__ wpk3) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C3B_SLOTS * 64) return;
+  const int lane = t & 63, slot = t >> 6, q = slot % C3B_HS, kh2 = (slot / C3B_HS) & 1, ct = slot / (2 * C3B_HS);
+  const int st = kh2 * C3B_HS + q, tap = st >> 1, kh = tap / C3B_K, kw = tap - kh * C3B_K;
+  const int c = 16 * ct + (lane & 15), f0 = 32 * (st & 1) + 8 * (lane >> 4);
+  float x[2][4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e >> 2][e & 3] = w[(f0 + e) * so + c * sc + kh * sh + kw * sw];
+  uint2 h0, m0, l0, h1, m1, l1;
+  g3_split4(x[0], h0, m0, l0);
+  g3_split4(x[1], h1, m1, l1);
+  wpk3[(slot * 3 + 0) * 64 + lane] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  wpk3[(slot * 3 + 1) * 64 + lane] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  wpk3[(slot * 3 + 2) * 64 + lane] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// g: float [N][OH][OW][64]; dx: float [N][OH + 2][OW + 2][64] (NHWC memory)
+template <int FPI>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_conv3_bwd_data_b3(int N, int OH, int OW, unsigned iw_magic, const float* __restrict__ g, const uint4* __restrict__ wpk3,
+                    float* __restrict__ dx) {
+  extern __shared__ __align__(16) char c3b_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave >> 1, kh2 = wave & 1;
+  const int j = lane & 15, kq = lane >> 4;
+  g3_bf16x8 wr[C3B_HS][3];
+#pragma unroll
+  for (int q = 0; q < C3B_HS; ++q)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      wr[q][p] = __builtin_bit_cast(g3_bf16x8, wpk3[((((ct * 2 + kh2) * C3B_HS + q) * 3) + p) * 64 + lane]);
+  const int IH = OH + 2, IW = OW + 2, IHW = IH * IW, PW = OW + 4, rows = FPI * (OH + 2) + 2;
+  const int pos16 = OH * OW * 16;               // 16 B vectors per frame of g
+  const int S = c2b_chunk_stride(rows * PW), HP = c2b_half_plane(rows * PW), plane = 2 * HP;
+  // this wave's nine K-steps: byte offset of the tap's position shift and of the 32-filter half
+  int tsh[C3B_HS], fsh[C3B_HS];
+#pragma unroll
+  for (int q = 0; q < C3B_HS; ++q) {
+    const int st = kh2 * C3B_HS + q, tap = st >> 1, kh = tap / C3B_K, kw = tap - kh * C3B_K;
+    tsh[q] = (kh * PW + kw) * 16;
+    fsh[q] = (st & 1) * 2 * S;
+  }
+  for (int o = tid; o < 3 * plane / 16; o += 512) reinterpret_cast<uint4*>(c3b_lds)[o] = make_uint4(0u, 0u, 0u, 0u);
+  const int units = (N + FPI - 1) / FPI;
+  bool first = true;
+  for (int u0 = blockIdx.x; u0 < units; u0 += gridDim.x) {
+    const int n0 = u0 * FPI;
+    const int frames = N - n0 < FPI ? N - n0 : FPI;
+    __syncthreads();                            // zeroing / the lower halves are done with the exchange blocks
+    if (!first) {
+      // the exchange blocks of the previous fill overwrote part of the planes, border included: zero that part again
+      for (int o = tid; o < 4 * C3B_MAXT * 64; o += 512) reinterpret_cast<uint4*>(c3b_lds)[o] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
+    first = false;
+    {
+      const int vecs = frames * pos16;
+      const cm_f4* s4 = reinterpret_cast<const cm_f4*>(g + (int64_t)n0 * OH * OW * C3B_F);
+      constexpr int LD = 4;
+      for (int o0 = tid; o0 < vecs; o0 += 512 * LD) {
+        cm_f4 v[LD];
+#pragma unroll
+        for (int k = 0; k < LD; ++k) { const int o = o0 + k * 512; v[k] = s4[o < vecs ? o : vecs - 1]; }
+#pragma unroll
+        for (int k = 0; k < LD; ++k) {
+          const int o = o0 + k * 512;
+          if (o < vecs) {
+            const int f = o / pos16, r = o - f * pos16, pos = r >> 4, sub = r & 15;
+            const int oh2 = pos / OW, ow2 = pos - oh2 * OW;
+            const float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+            uint2 hh, mm, ll;
+            g3_split4(x, hh, mm, ll);
+            const int chunk = sub >> 1, kqw = chunk & 3;
+            char* d = c3b_lds + (kqw & 1) * HP + (2 * (chunk >> 2) + (kqw >> 1)) * S + ((f * (OH + 2) + 2 + oh2) * PW + 2 + ow2) * 16 + (sub & 1) * 8;
+            *reinterpret_cast<uint2*>(d) = hh;
+            *reinterpret_cast<uint2*>(d + plane) = mm;
+            *reinterpret_cast<uint2*>(d + 2 * plane) = ll;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int pend = frames * IHW;
+    g3_f32x4 acc[C3B_MAXT];
+#pragma unroll
+    for (int t = 0; t < C3B_MAXT; ++t) {
+      acc[t] = g3_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t * 16 < pend) {                       // workgroup-uniform
+        const int p = t * 16 + j, pc = p < pend ? p : pend - 1;
+        const int f = pc / IHW, r = pc - f * IHW;
+        const int y = (int)__umulhi((unsigned)r, iw_magic), x = r - y * IW;
+        const char* base = c3b_lds + (kq & 1) * HP + (kq >> 1) * S + ((f * (OH + 2) + 2 + y) * PW + 2 + x) * 16;
+        g3_bf16x8 b[C3B_HS][3];
+#pragma unroll
+        for (int q = 0; q < C3B_HS; ++q) {
+          const char* pb = base - tsh[q] + fsh[q];
+          b[q][0] = *reinterpret_cast<const g3_bf16x8*>(pb);
+          b[q][1] = *reinterpret_cast<const g3_bf16x8*>(pb + plane);
+          b[q][2] = *reinterpret_cast<const g3_bf16x8*>(pb + 2 * plane);
+        }
+        g3_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < C3B_HS; ++q) {
+          // smallest products first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][2], b[q][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][0], b[q][2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][1], b[q][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][1], b[q][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][0], b[q][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[q][0], b[q][0], a, 0, 0, 0);
+        }
+        acc[t] = a;
+      }
+    }
+    // the two K halves of a channel tile meet in LDS: block (ct, t) = one 16-byte vector per lane
+    __syncthreads();                            // every wave is done reading the planes
+    g3_f32x4* xb = reinterpret_cast<g3_f32x4*>(c3b_lds) + (ct * C3B_MAXT) * 64 + lane;
+    if (kh2 == 1) {
+#pragma unroll
+      for (int t = 0; t < C3B_MAXT; ++t) if (t * 16 < pend) xb[t * 64] = acc[t];
+    }
+    __syncthreads();
+    if (kh2 == 0) {
+#pragma unroll
+      for (int t = 0; t < C3B_MAXT; ++t) {
+        const int p = t * 16 + j;
+        if (p < pend) {
+          const int f = p / IHW, r = p - f * IHW;
+          *reinterpret_cast<g3_f32x4*>(dx + ((int64_t)(n0 + f) * IHW + r) * C3B_C + 16 * ct + 4 * kq) = acc[t] + xb[t * 64];
+        }
+      }
+    }
+  }
+}
+
+// the planes, and at least the exchange blocks that reuse their space (4 channel tiles x C3B_MAXT pixel tiles x 1 KB)
+static size_t c3b_lds_bytes(int fpi, int OH, int OW) {
+  const size_t planes = (size_t)3 * 2 * c2b_half_plane((fpi * (OH + 2) + 2) * (OW + 4)), xchg = (size_t)4 * C3B_MAXT * 1024;
+  return planes > xchg ? planes : xchg;
+}
+
 }  // namespace mirl
 
 extern "C" int mirl_conv2_bwd_data_supported(int32_t C, int32_t F, int32_t K, int32_t S, int32_t IH, int32_t IW, int32_t OH, int32_t OW) {
@@ -400,3 +558,49 @@ extern "C" int mirl_conv2_bwd_data_ex(int64_t N, int32_t OH, int32_t OW, const f
 // in lockstep, so the phases add up instead of overlapping; conflict-free fragment reads, half-tile software pipelining
 // and a second accumulator chain each moved the total by less than 0.05 ms.  Next step: two staging buffers (FPI = 1) so
 // the next frame's split runs under this frame's MFMAs.
+
+extern "C" int mirl_conv3_bwd_data_supported(int32_t C, int32_t F, int32_t K, int32_t S, int32_t IH, int32_t IW, int32_t OH, int32_t OW) {
+  using namespace mirl;
+  if (C != C3B_C || F != C3B_F || K != C3B_K || S != 1 || OH < 1 || OW < 1) return 0;
+  if (IH != OH + 2 || IW != OW + 2) return 0;                 // no forward rows / columns left uncovered
+  if (IH * IW > 16 * C3B_MAXT) return 0;                      // a frame's pixel tiles fit the accumulator array
+  return c3b_lds_bytes(1, OH, OW) <= 150 * 1024 ? 1 : 0;
+}
+
+extern "C" int mirl_conv3_bwd_data_wpk_floats(int64_t* floats) {
+  if (!floats) return mirl::fail(MIRL_ERR_ARG, "conv3_bwd_data_wpk_floats: null out");
+  *floats = mirl::C3B_WPK_BYTES / 4;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_conv3_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
+                                   int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, void* stream) {
+  using namespace mirl;
+  if (N <= 0 || N >= (1LL << 30) || !g || !weight || !wpk || !dx) return fail(MIRL_ERR_ARG, "bad conv3_bwd_data arguments");
+  if (!mirl_conv3_bwd_data_supported(C3B_C, C3B_F, C3B_K, 1, OH + 2, OW + 2, OH, OW)) return fail(MIRL_ERR_ARG, "conv3_bwd_data: unsupported shape");
+  if (((uintptr_t)g % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)wpk % 16))
+    return fail(MIRL_ERR_ARG, "conv3_bwd_data: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope ps("k_conv3_pack_w3b", 4.0 * C3B_F * C3B_C * 9 + C3B_WPK_BYTES, st);
+    hipLaunchKernelGGL(k_conv3_pack_w3b, dim3((C3B_SLOTS * 64 + 255) / 256), dim3(256), 0, st, weight, ws_o, ws_c, ws_h, ws_w,
+                       reinterpret_cast<uint4*>(wpk));
+    MIRL_LAUNCH_CHECK();
+  }
+  const int IHW = (OH + 2) * (OW + 2);
+  const int fpi = (N >= 512 && 2 * IHW <= 16 * C3B_MAXT && c3b_lds_bytes(2, OH, OW) <= 150 * 1024) ? 2 : 1;
+  const size_t lds = c3b_lds_bytes(fpi, OH, OW);
+  const int64_t units = (N + fpi - 1) / fpi;
+  const unsigned grid = (unsigned)(units < 256 ? units : 256);
+  const int IW = OW + 2;
+  const unsigned iw_magic = (unsigned)(((1ULL << 32) + IW - 1) / IW);
+  static bool attr[2] = {false, false};
+  const void* fn = fpi == 2 ? (const void*)k_conv3_bwd_data_b3<2> : (const void*)k_conv3_bwd_data_b3<1>;
+  if (!attr[fpi - 1]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr[fpi - 1] = true; }
+  ProfScope ps("k_conv3_bwd_data_b3", (double)N * 4.0 * C3B_F * ((double)OH * OW + (double)IHW), st,
+               (double)N * OH * OW * 2.0 * C3B_K * C3B_K * C3B_C * C3B_F);
+  if (fpi == 2) hipLaunchKernelGGL((k_conv3_bwd_data_b3<2>), dim3(grid), dim3(512), lds, st, (int)N, OH, OW, iw_magic, g, reinterpret_cast<const uint4*>(wpk), dx);
+  else          hipLaunchKernelGGL((k_conv3_bwd_data_b3<1>), dim3(grid), dim3(512), lds, st, (int)N, OH, OW, iw_magic, g, reinterpret_cast<const uint4*>(wpk), dx);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}

@@ -178,6 +178,9 @@ class _ConvBiasReLU(torch.autograd.Function):
         if need_x and _CONV2_BWD and g.shape[0] and conv2_bwd_data_supported(x, weight, ctx.stride, g):
             dx = conv2_bwd_data(g, weight, x)          # f32 MFMA, four parity-class GEMMs (csrc/conv_mid.hip)
             need_x = False
+        if need_x and _CONV3_BWD and g.shape[0] and conv3_bwd_data_supported(x, weight, ctx.stride, g):
+            dx = conv3_bwd_data(g, weight, x)          # the same on the bf16 pipe for the stride-1 3 x 3 layer
+            need_x = False
         lib_dx, lib_dw, _ = torch.ops.aten.convolution_backward(
             g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False]) \
             if (need_x or need_w) else (None, None, None)
@@ -299,6 +302,34 @@ def conv2_bwd_data_supported(x, weight, stride, g):
         return False
     return bool(_lib().lib.mirl_conv2_bwd_data_supported(weight.shape[1], weight.shape[0], weight.shape[2], 2, x.shape[2],
                                                          x.shape[3], g.shape[2], g.shape[3]))
+
+
+_CONV3_BWD = os.environ.get("MIRL_CONV3_BWD", "1") != "0"   # 0: MIOpen data gradient for the third conv layer
+_c3_wpk_floats = None
+
+
+def conv3_bwd_data_supported(x, weight, stride, g):
+    if not (g.is_contiguous(memory_format=torch.channels_last) and g.data_ptr() % 16 == 0 and g.dtype == torch.float32
+            and tuple(stride) == (1, 1) and weight.shape[2] == weight.shape[3] and not torch.is_autocast_enabled()):
+        return False
+    return bool(_lib().lib.mirl_conv3_bwd_data_supported(weight.shape[1], weight.shape[0], weight.shape[2], 1, x.shape[2],
+                                                         x.shape[3], g.shape[2], g.shape[3]))
+
+
+def conv3_bwd_data(g, weight, x_like):
+    """d loss / d input of conv2d(x, weight, stride 1) for the (64 -> 64, k 3) layer; g is NHWC."""
+    global _c3_wpk_floats
+    L = _lib()
+    if _c3_wpk_floats is None:
+        n = C.c_int64()
+        L.check(L.lib.mirl_conv3_bwd_data_wpk_floats(C.byref(n)), "mirl_conv3_bwd_data_wpk_floats")
+        _c3_wpk_floats = n.value
+    dx = torch.empty_like(x_like, memory_format=torch.channels_last)
+    wpk = torch.empty(_c3_wpk_floats, dtype=torch.float32, device=g.device)
+    so, sc, sh, sw = weight.stride()
+    L.check(L.lib.mirl_conv3_bwd_data(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
+                                      _stream()), "mirl_conv3_bwd_data")
+    return dx
 
 
 # which matrix pipe the layer-2 data gradient runs on: "bf16" = exact three-way split, f32 results (default), "f32" = f32 MFMA

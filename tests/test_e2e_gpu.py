@@ -250,7 +250,7 @@ def test_iqn_lstm_training_series_follows_reference_with_replayed_taus():
 
 # kernels of rounds 2-3 the wide trajectory must have gone through (names as mirl_profile_* records them)
 ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k_conv3_fwd", "k_conv1_u8_fwd",
-                  "k_conv1_u8_wrw_b3", "k_conv2_bwd_data_b3", "k_conv_wrw_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
+                  "k_conv1_u8_wrw_b3", "k_conv2_bwd_data_b3", "k_conv3_bwd_data_b3", "k_conv_wrw_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
 
 
 @pytest.mark.parametrize("forced,nhwc", [(True, True), ("gemm3", True), ("conv", True), ("lstm", True), (False, True), (False, False)],
@@ -273,6 +273,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     monkeypatch.setattr(gemm3, "_MIN_WORK", 0 if on("gemm3") else 1 << 62)
     monkeypatch.setattr(fused, "_CONV3_MIN_WORK", 0 if on("conv") else 1 << 62)
     monkeypatch.setattr(fused, "_CONV_WRW_MIN_WORK", 0 if on("conv") else 1 << 62)
+    monkeypatch.setattr(fused, "_CONV3_BWD", on("conv"))
     monkeypatch.setattr(lstm_seq, "_PERSISTENT", on("lstm"))
     _lib.check(_lib.lib.mirl_conv1_bf16_set(1 if on("conv") else 0))
     _lib.check(_lib.lib.mirl_profile_reset())
