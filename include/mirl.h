@@ -508,18 +508,19 @@ int mirl_conv2_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const
                         void* stream);
 /* The same gradient on either matrix pipe: pipe 0 = f32 MFMA (the call above), pipe 1 = bf16 MFMA with mirl_gemm3's exact
  * three-way split of both operands (six part products, f32 accumulation: f32 results, 2.65 x the f32 pipe's rate; bit-exact
- * on small-integer operands, tests/test_conv_mid_gpu.py).  wpk: *floats of mirl_conv2_bwd_data_wpk_floats() for either pipe.    */
+ * on small-integer operands, tests/test_conv_mid_gpu.py).  wpk: wpk_floats >= *floats of mirl_conv2_bwd_data_wpk_floats() (checked), either pipe. */
 int mirl_conv2_bwd_data_wpk_floats(int64_t* floats);
 int mirl_conv2_bwd_data_ex(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
-                           int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, int32_t pipe, void* stream);
+                           int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, int64_t wpk_floats, float* dx, int32_t pipe,
+                           void* stream);
 /* Data gradient of the THIRD conv layer (64 -> 64 filters, kernel 3, stride 1; autograd of cnn.py:47-49) on the bf16 pipe,
  * same method and layouts: g float [N][OH][OW][64], dx float [N][OH + 2][OW + 2][64] (NHWC memory), weight (64, 64, 3, 3) by
- * element strides.  wpk: *floats of mirl_conv3_bwd_data_wpk_floats().  mirl_conv3_bwd_data_supported() gates it (no
+ * element strides.  wpk: wpk_floats >= *floats of mirl_conv3_bwd_data_wpk_floats() (checked).  mirl_conv3_bwd_data_supported() gates it (no
  * uncovered input rows / columns, (OH + 2)(OW + 2) <= 176).  Replaces MIOpen's igemm_bwd for this layer.                */
 int mirl_conv3_bwd_data_supported(int32_t C, int32_t F, int32_t K, int32_t S, int32_t IH, int32_t IW, int32_t OH, int32_t OW);
 int mirl_conv3_bwd_data_wpk_floats(int64_t* floats);
 int mirl_conv3_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
-                        int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, void* stream);
+                        int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, int64_t wpk_floats, float* dx, void* stream);
 
 /* ---- f32 GEMMs of the wide layers on the bf16 matrix pipe (csrc/gemm3.hip).  Replaces the
  * library f32 GEMMs behind the nn.Linear layers of the reference's recurrent IQN model

@@ -174,8 +174,8 @@ _SIGNATURES = {
     "mirl_conv2_bwd_data_wpk_floats": [_P(_i64)],
     "mirl_conv3_bwd_data_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv3_bwd_data_wpk_floats": [_P(_i64)],
-    "mirl_conv3_bwd_data": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
-    "mirl_conv2_bwd_data_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
+    "mirl_conv3_bwd_data": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _vp],
+    "mirl_conv2_bwd_data_ex": [_i64, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i32, _vp],
     "mirl_conv3_fwd_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv3_fwd": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "mirl_conv_wrw_b3_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],

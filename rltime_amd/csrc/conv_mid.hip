@@ -518,8 +518,9 @@ extern "C" int mirl_conv2_bwd_data_wpk_floats(int64_t* floats) {
 
 // pipe: 0 = f32 MFMA (mirl_conv2_bwd_data above), 1 = bf16 MFMA with the exact three-way split (f32 results)
 extern "C" int mirl_conv2_bwd_data_ex(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
-                                      int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, int32_t pipe, void* stream) {
+                                      int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, int64_t wpk_floats, float* dx, int32_t pipe, void* stream) {
   using namespace mirl;
+  if (wpk_floats < (pipe == 1 ? C2B_WPK_BYTES / 4 : C2_WPK)) return fail(MIRL_ERR_ARG, "conv2_bwd_data_ex: wpk smaller than mirl_conv2_bwd_data_wpk_floats()");
   if (pipe == 0) return mirl_conv2_bwd_data(N, OH, OW, g, weight, ws_o, ws_c, ws_h, ws_w, wpk, dx, stream);
   if (pipe != 1) return fail(MIRL_ERR_ARG, "conv2_bwd_data_ex: pipe is 0 (f32) or 1 (split bf16)");
   if (N <= 0 || N >= (1LL << 30) || !g || !weight || !wpk || !dx) return fail(MIRL_ERR_ARG, "bad conv2_bwd_data arguments");
@@ -574,9 +575,10 @@ extern "C" int mirl_conv3_bwd_data_wpk_floats(int64_t* floats) {
 }
 
 extern "C" int mirl_conv3_bwd_data(int64_t N, int32_t OH, int32_t OW, const float* g, const float* weight, int64_t ws_o,
-                                   int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, float* dx, void* stream) {
+                                   int64_t ws_c, int64_t ws_h, int64_t ws_w, float* wpk, int64_t wpk_floats, float* dx, void* stream) {
   using namespace mirl;
   if (N <= 0 || N >= (1LL << 30) || !g || !weight || !wpk || !dx) return fail(MIRL_ERR_ARG, "bad conv3_bwd_data arguments");
+  if (wpk_floats < C3B_WPK_BYTES / 4) return fail(MIRL_ERR_ARG, "conv3_bwd_data: wpk smaller than mirl_conv3_bwd_data_wpk_floats()");
   if (!mirl_conv3_bwd_data_supported(C3B_C, C3B_F, C3B_K, 1, OH + 2, OW + 2, OH, OW)) return fail(MIRL_ERR_ARG, "conv3_bwd_data: unsupported shape");
   if (((uintptr_t)g % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)wpk % 16))
     return fail(MIRL_ERR_ARG, "conv3_bwd_data: pointers must be 16-byte aligned");

@@ -327,8 +327,8 @@ def conv3_bwd_data(g, weight, x_like):
     dx = torch.empty_like(x_like, memory_format=torch.channels_last)
     wpk = torch.empty(_c3_wpk_floats, dtype=torch.float32, device=g.device)
     so, sc, sh, sw = weight.stride()
-    L.check(L.lib.mirl_conv3_bwd_data(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
-                                      _stream()), "mirl_conv3_bwd_data")
+    L.check(L.lib.mirl_conv3_bwd_data(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), wpk.numel(),
+                                      _p(dx), _stream()), "mirl_conv3_bwd_data")
     return dx
 
 
@@ -348,8 +348,8 @@ def conv2_bwd_data(g, weight, x_like, pipe=None):
     dx = torch.empty_like(x_like, memory_format=torch.channels_last)
     wpk = torch.empty(_c2_wpk_floats, dtype=torch.float32, device=g.device)
     so, sc, sh, sw = weight.stride()
-    L.check(L.lib.mirl_conv2_bwd_data_ex(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), _p(dx),
-                                         _CONV2_BWD_PIPE if pipe is None else pipe, _stream()), "mirl_conv2_bwd_data_ex")
+    L.check(L.lib.mirl_conv2_bwd_data_ex(g.shape[0], g.shape[2], g.shape[3], _p(g), _p(weight), so, sc, sh, sw, _p(wpk), wpk.numel(),
+                                         _p(dx), _CONV2_BWD_PIPE if pipe is None else pipe, _stream()), "mirl_conv2_bwd_data_ex")
     return dx
 
 

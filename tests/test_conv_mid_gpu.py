@@ -26,7 +26,8 @@ def _call(g, w, pipe):
     wpk = torch.empty(floats.value, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     so, sc, sh, sw = w.stride()
-    check(lib.mirl_conv2_bwd_data_ex(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), p(dx), pipe,
+    assert lib.mirl_conv2_bwd_data_ex(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), 1024, p(dx), pipe, None) != 0      # scratch too small: refused
+    check(lib.mirl_conv2_bwd_data_ex(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), wpk.numel(), p(dx), pipe,
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv2_bwd_data_ex")
     return dx
 
@@ -106,7 +107,8 @@ def _call3(g, w):
     wpk = torch.empty(floats.value, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
     so, sc, sh, sw = w.stride()
-    check(lib.mirl_conv3_bwd_data(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), p(dx),
+    assert lib.mirl_conv3_bwd_data(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), 1024, p(dx), None) != 0               # scratch too small: refused
+    check(lib.mirl_conv3_bwd_data(n, oh, ow, p(g), p(w), so, sc, sh, sw, p(wpk), wpk.numel(), p(dx),
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv3_bwd_data")
     return dx
 
