@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, final evidence session: suite, smoke, the judged bench line, rocprofv3 split, rank shares, other configs
 set -u
-OUT=gpurun_out/r04final3; mkdir -p $OUT
+OUT=gpurun_out/r04final4; mkdir -p $OUT
 export MIRL_TEST_ARTIFACTS=$OUT
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_all.log 2>&1; echo "suite rc=$?"; grep -E "passed|failed|^E  |^FAILED" $OUT/pytest_all.log | head -20
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
