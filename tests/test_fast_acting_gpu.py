@@ -217,7 +217,10 @@ def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
     from rltime_amd.history import PrioritizedReplayHistoryBuffer, ReplayHistoryBuffer
     E, calls, iters = 16, 7, 6
     results = []
-    for mode in ("graph", "eager-then-graph", "per-step"):
+    # "graph, selection redone every call": the weight buffers and the pending selection are rebuilt before every call
+    # instead of only after a learner update (actor._fast_steps keeps them while the parameters' version counters stand
+    # still) — the re-selection is idempotent, so nothing may change
+    for mode in ("graph", "eager-then-graph", "graph, selection redone every call", "per-step"):
         monkeypatch.setenv("MIRL_ROLLOUT_GRAPH", "0" if mode == "per-step" else "1")
         monkeypatch.setenv("MIRL_ROLLOUT_EAGER_CALLS", "2" if mode == "eager-then-graph" else "0")
         actor, pol, env = _make(kind, E, True, exploration=EXPL)
@@ -228,6 +231,8 @@ def test_rollout_graph_equals_the_per_step_path(kind, per, monkeypatch):
         hist = PrioritizedReplayHistoryBuffer(alpha=0.9, beta=0.6, **kw) if per else ReplayHistoryBuffer(**kw)
         actor.set_sink(hist)
         for c in range(calls):                                     # E * 30 slots, 42 steps per env: evictions included
+            if mode.endswith("every call") and actor._fast:
+                actor._fast.selected_with = None
             s = actor.get_samples(E * iters)
             assert getattr(s, "ingested", False)
             hist.update(s)
