@@ -815,10 +815,12 @@ def main():
                 "acting_overlapped_on_second_stream": res["overlap"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2),
-                "f32_products_on": ("bf16 matrix pipe for the wide GEMMs and conv layers 2-3 forward (6 exact-split bf16 MFMAs per f32 product "
-                                    "block, csrc/gemm3.hip, conv3.hip) and the input layer's forward (uint8 pixels are exact bf16, weights split "
-                                    "three ways, csrc/conv_in.hip); f32 accumulation, results within the library f32 GEMM's own "
-                                    "distance from float64 (tests/test_gemm3_gpu.py, DESIGN 3.6); everything else f32 pipe"
+                "f32_products_on": ("bf16 matrix pipe for the wide GEMMs, conv layers 2-3 forward and the conv stack's backward (6 exact-split "
+                                    "bf16 MFMAs per f32 product block: csrc/gemm3.hip, conv3.hip, conv_mid.hip, conv_wrw.hip) and the input "
+                                    "layer's forward and weight gradient (uint8 pixels are exact bf16, the f32 operand split three ways: 3 "
+                                    "MFMAs per block, csrc/conv_in.hip); f32 accumulation, results within the library f32 kernels' own "
+                                    "distance from float64 (tests/test_gemm3_gpu.py, test_conv*_gpu.py, DESIGN 3.6-3.8); LSTM sweeps and "
+                                    "the small / acting-batch products on the f32 pipe (own kernels, hipBLASLt, MIOpen)"
                                     if (os.environ.get("MIRL_GEMM3", "1") != "0" or os.environ.get("MIRL_CONV1_BF16", "1") != "0"
                                         or os.environ.get("MIRL_CONV3", "1") != "0")
                                     else "f32 MFMA pipe only (MIRL_GEMM3=0 MIRL_CONV1_BF16=0 MIRL_CONV3=0)")},
