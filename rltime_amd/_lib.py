@@ -21,8 +21,12 @@ MODE_PER = 1
 INT32_MIN = -2 ** 31
 
 
+MIRL_OK, MIRL_ERR_ARG, MIRL_ERR_HIP, MIRL_ERR_STATE, MIRL_ERR_NOGPU = 0, -1, -2, -3, -4     # include/mirl.h:33-38
+
+
 class MirlError(RuntimeError):
-    pass
+    """`code` is the library's return value (MIRL_ERR_*), None when raised on the Python side."""
+    code = None
 
 
 class ReplayConfig(C.Structure):
@@ -195,6 +199,14 @@ _SIGNATURES = {
     "mirl_gemm3_presplit": [_i64, _i64, _vp, _i64, _i64, _vp, _vp],
     "mirl_gemm3_ps": [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp],
     "mirl_gemm3_ps_mul": [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
+    "mirl_act_conv_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
+    "mirl_act_conv_fwd": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
+    "mirl_act_lstm_supported": [_i32, _i32, _i32],
+    "mirl_act_lstm_fwd": [_i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_act_head_supported": [_i32, _i32, _i32, _i32, _i32, _i32],
+    "mirl_act_head_parts": [_i32, _i32, _P(_i32), _P(_i32)],
+    "mirl_act_head_hidden": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_act_head_select": [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp],
     "mirl_bias_relu_rows": [_i64, _i32, _vp, _vp, _vp],
     "mirl_colsum_blocks": [_i64, _i32, _P(_i32)],
     "mirl_relu_bwd_bias_rows": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
@@ -242,7 +254,9 @@ def last_error():
 def check(rc, what=""):
     """Raise on error codes; pass MIRL_OK / MIRL_NEED_MORE through."""
     if rc < 0:
-        raise MirlError("%s failed (%d): %s" % (what or "mirl call", rc, last_error()))
+        err = MirlError("%s failed (%d): %s" % (what or "mirl call", rc, last_error()))
+        err.code = int(rc)
+        raise err
     return rc
 
 

@@ -134,7 +134,10 @@ class Actor(ActingInterface):
         """Let the device actor write its vector steps straight into `history` (a device
         replay with update_batch): get_samples then returns an already-ingested summary
         (fast_step.IngestedSamples) and History.update is a no-op for it."""
-        self._sink = history if hasattr(history, "update_batch") else None
+        new = history if hasattr(history, "update_batch") else None
+        if new is not getattr(self, "_sink", None) and self._fast:
+            self._fast.forget_rollouts()     # captured rollouts hold the previous sink's device structures
+        self._sink = new
         self.clip_rewards = bool(clip_rewards)
 
     def close(self):

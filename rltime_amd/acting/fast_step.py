@@ -330,6 +330,15 @@ class FastActingStep:
         return self.obs_buf, self.env_rewards, self.env_dones
 
     # -- a whole get_samples call as one graph launch --------------------------------------------------
+    @staticmethod
+    def _sink_key(sink):
+        h = getattr(sink, "_h", None)
+        return ("replay", int(getattr(h, "value", None) or id(sink)))
+
+    def forget_rollouts(self):
+        """Drop every captured rollout (the sink was reconfigured or destroyed: its device structures are gone)."""
+        self._rollouts.clear()
+
     def can_rollout(self, iters, sink):
         return (self.rollout_graphs and self.env_into and sink is not None and iters >= 2 and self.tracker is not None
                 and iters <= self.tracker.ROWS and getattr(sink, "supports_planned_ingest", lambda: False)())
@@ -349,11 +358,19 @@ class FastActingStep:
         (tests/test_fast_acting_gpu.py)."""
         env = self.actor._vec_env
         parity = env.clock_parity() if hasattr(env, "clock_parity") else 0
-        key = (iters, bool(keep_policy), bool(clip), id(sink), parity)     # a captured env step reads a fixed clock word
+        # a captured env step reads a fixed clock word; the sink is keyed by its replay HANDLE (the Dev struct and plan
+        # buffer baked into the graph belong to it — id() of a destroyed sink can be recycled)
+        key = (iters, bool(keep_policy), bool(clip), self._sink_key(sink), parity)
         state = self._rollouts.setdefault(key, [0, None])
+        from rltime_amd._lib import MirlError, MIRL_ERR_ARG
         try:
-            sink.plan_ingest(iters, self.E)      # refused calls leave the book untouched (checked before any bookkeeping)
-        except Exception as e:
+            sink.plan_ingest(iters, self.E)
+        except MirlError as e:
+            # mirl_replay_ingest_plan is transactional: MIRL_ERR_ARG is returned BEFORE any bookkeeping (book, rings and
+            # plan buffer untouched), so acting can go on per step.  Anything else (a failure after the book moved: the
+            # shard is marked broken in the library) must not be papered over.
+            if getattr(e, "code", None) != MIRL_ERR_ARG:
+                raise
             import logging
             logging.getLogger().warning("rollout plan refused (%s); acting per step", e)
             self.rollout_graphs = False

@@ -123,6 +123,10 @@ struct ProfScope {
   ProfScope(const char* name, double bytes, hipStream_t s, double flop = 0.0) : st(s) {
     Profiler& p = profiler();
     if (p.level < 2) return;
+    // never inside a stream capture: an event-record node on a pooled timing event would be baked into the graph and
+    // re-recorded on every replay, and the elapsed-time query of the pair would read whatever replay came last
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     idx = p.index_of(name);
     p.entries[(size_t)idx].bytes += bytes;
     p.entries[(size_t)idx].flop += flop;

@@ -1002,7 +1002,8 @@ struct mirl_replay {
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   // rollout plan (mirl_replay_ingest_plan / _planned): ONE device buffer at a fixed address — captured graphs hold it
-  char* roll_plan = nullptr; size_t roll_cap = 0; int roll_steps = 0, roll_count = 0, roll_cap_steps = 0;
+  char* roll_plan = nullptr; size_t roll_cap = 0; int roll_steps = 0, roll_count = 0, roll_cap_steps = 0, roll_cap_count = 0;
+  bool book_broken = false;            // a rollout plan failed after the book had moved: host and device disagree
   std::vector<char> roll_host;
 };
 
@@ -1181,6 +1182,7 @@ static int g_ingest_fused = -1;     // -1: take MIRL_INGEST_FUSED (default on) a
 extern "C" int mirl_ingest_fused_set(int32_t on) { g_ingest_fused = on ? 1 : 0; return MIRL_OK; }
 
 extern "C" int mirl_replay_ingest(mirl_replay* h, const mirl_ingest* in, void* stream) {
+  if (h && h->book_broken) return fail(MIRL_ERR_STATE, "this shard's host bookkeeping ran ahead of its device rows (an ingest_plan failed half-way); the shard is unusable");
   if (!h || !in || in->count <= 0) return fail(MIRL_ERR_ARG, "bad ingest arguments");
   hipStream_t st = (hipStream_t)stream;
   Dev& d = h->d;
@@ -1297,22 +1299,44 @@ static bool planned_ingest_ok(mirl_replay* h) {
 
 extern "C" int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t count, const int32_t* env_ids_host, void* stream) {
   if (!h || steps <= 0 || steps > 4096 || count <= 0 || count > 65535) return fail(MIRL_ERR_ARG, "bad ingest_plan arguments");
+  if (h->book_broken) return fail(MIRL_ERR_STATE, "this shard's host bookkeeping ran ahead of its device rows (an earlier ingest_plan failed half-way); the shard is unusable");
   if (!planned_ingest_ok(h)) return fail(MIRL_ERR_ARG, "planned ingest needs the fused ingest kernel (no de-duplicated storage, no acting_priority_init)");
   hipStream_t st = (hipStream_t)stream;
   const int K = count;
-  if (!h->roll_plan) {
-    // sized once (the address is baked into captured graphs): at least 64 steps, op lists bounded by 4 ops per transition
-    const int cap_steps = steps > 64 ? steps : 64;
-    const size_t per_step = align_up(sizeof(int32_t) * K, 16) + align_up(sizeof(int64_t) * K, 16) +
-                            4 * (size_t)K * (sizeof(TableOp) + sizeof(EnvOp) + sizeof(LeafOp)) + 64;
-    h->roll_cap = align_up(sizeof(PlanHdr) * (size_t)cap_steps, 256) + per_step * (size_t)cap_steps;
-    MIRL_HIP(hipMalloc((void**)&h->roll_plan, h->roll_cap));
-    h->allocs.push_back(h->roll_plan);
-    h->roll_cap_steps = cap_steps;
+  // Transactional: EVERYTHING that can refuse the call — arguments, buffer sizes, the staging block — is settled before
+  // the book moves, so a refused call (MIRL_ERR_ARG / MIRL_ERR_HIP from here) leaves the book, the rings and the plan
+  // buffer exactly where they were and the caller may fall back to per-step ingest.  A failure AFTER the book has moved
+  // marks the shard broken (every later ingest / sample call returns MIRL_ERR_STATE): the host would otherwise count
+  // transitions whose device rows were never written.
+  // worst case per transition: table ops <= 2 (one deactivation, one activation), leaf ops <= 2, env ops <= 2
+  auto per_step_bytes = [](int k) -> size_t {
+    return align_up(sizeof(int32_t) * (size_t)k, 16) + align_up(sizeof(int64_t) * (size_t)k, 16) +
+           align_up(2 * (size_t)k * sizeof(TableOp), 16) + align_up(2 * (size_t)k * sizeof(EnvOp), 16) +
+           align_up(2 * (size_t)k * sizeof(LeafOp), 16) + 64;
+  };
+  if (h->roll_plan && (steps > h->roll_cap_steps || K > h->roll_cap_count))
+    return fail(MIRL_ERR_ARG, "ingest_plan: more steps / transitions per step than the rollout-plan buffer was sized for at its first call");
+  for (int32_t k = 0; env_ids_host && k < K; ++k) {
+    const int32_t e = env_ids_host[k] - h->book.cfg.env_base;
+    if (e < 0 || e >= h->book.E) return fail(MIRL_ERR_ARG, "env id outside this shard");
+    for (int32_t j = 0; j < k; ++j) if (env_ids_host[j] == env_ids_host[k]) return fail(MIRL_ERR_ARG, "an env may appear once per ingest call (split the vector steps)");
   }
-  if (steps > h->roll_cap_steps) return fail(MIRL_ERR_ARG, "ingest_plan: more steps than the rollout-plan buffer was sized for");
-  std::vector<char>& buf = h->roll_host;
+  if (!env_ids_host && K > h->book.E) return fail(MIRL_ERR_ARG, "env id outside this shard");
+  if (!h->roll_plan) {
+    // sized once (the address is baked into captured graphs): at least 64 steps of this call's transition count
+    const int cap_steps = steps > 64 ? steps : 64;
+    const size_t cap = align_up(sizeof(PlanHdr) * (size_t)cap_steps, 256) + per_step_bytes(K) * (size_t)cap_steps;
+    char* buf = nullptr;
+    MIRL_HIP(hipMalloc((void**)&buf, cap));
+    h->roll_plan = buf; h->roll_cap = cap;
+    h->allocs.push_back(h->roll_plan);
+    h->roll_cap_steps = cap_steps; h->roll_cap_count = K;
+  }
   const size_t hdr_bytes = align_up(sizeof(PlanHdr) * (size_t)h->roll_cap_steps, 256);
+  const size_t worst = hdr_bytes + per_step_bytes(K) * (size_t)steps;      // <= roll_cap by construction
+  char *hb, *db;
+  int rc = h->staging.acquire(worst, &hb, &db); if (rc) return rc;
+  std::vector<char>& buf = h->roll_host;
   buf.assign(hdr_bytes, 0);
   auto put = [&buf](const void* src, size_t bytes) -> int64_t {
     const size_t at = align_up(buf.size(), 16);
@@ -1320,9 +1344,10 @@ extern "C" int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t co
     if (bytes) memcpy(buf.data() + at, src, bytes);
     return (int64_t)at;
   };
+  auto broken = [h](int code) -> int { h->book_broken = true; return code; };
   for (int s = 0; s < steps; ++s) {
-    int rc = h->book.ingest(K, env_ids_host, h->plan);
-    if (rc) { last_error_ref() = h->book.err; return rc; }
+    rc = h->book.ingest(K, env_ids_host, h->plan);
+    if (rc) { last_error_ref() = h->book.err; return broken(rc); }     // a reference assert (ring overflow, no free index): fatal anyway
     const Plan& p = h->plan;
     PlanHdr hd;
     hd.n_table = h->d.per ? (int32_t)p.table_ops.size() : 0;
@@ -1337,17 +1362,18 @@ extern "C" int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t co
     memcpy(buf.data() + sizeof(PlanHdr) * (size_t)s, &hd, sizeof(PlanHdr));
   }
   const size_t total = align_up(buf.size(), 16);
-  if (total > h->roll_cap) return fail(MIRL_ERR_STATE, "ingest_plan: the rollout's op lists exceed the plan buffer");
-  char *hb, *db;
-  int rc = h->staging.acquire(total, &hb, &db); if (rc) return rc;
+  if (total > worst || total > h->roll_cap) return broken(fail(MIRL_ERR_STATE, "ingest_plan: the rollout's op lists exceed their worst-case bound (library bug)"));
   memcpy(hb, buf.data(), buf.size());
-  rc = h->staging.upload(total, st); if (rc) return rc;
-  MIRL_HIP(hipMemcpyAsync(h->roll_plan, db, total, hipMemcpyDeviceToDevice, st));     // stream order: after the last rollout that read it
+  rc = h->staging.upload(total, st); if (rc) return broken(rc);
+  if (hipMemcpyAsync(h->roll_plan, db, total, hipMemcpyDeviceToDevice, st) != hipSuccess)     // stream order: after the last rollout that read it
+    return broken(fail(MIRL_ERR_HIP, "ingest_plan: copy into the rollout-plan buffer failed"));
   h->roll_steps = steps; h->roll_count = K;
-  return h->staging.mark(st);
+  rc = h->staging.mark(st);
+  return rc ? broken(rc) : MIRL_OK;
 }
 
 extern "C" int mirl_replay_ingest_planned(mirl_replay* h, int32_t step, const mirl_ingest* in, void* stream) {
+  if (h && h->book_broken) return fail(MIRL_ERR_STATE, "this shard's host bookkeeping ran ahead of its device rows (an ingest_plan failed half-way); the shard is unusable");
   if (!h || !in || in->count <= 0 || step < 0) return fail(MIRL_ERR_ARG, "bad ingest_planned arguments");
   if (!h->roll_plan || step >= h->roll_cap_steps) return fail(MIRL_ERR_STATE, "ingest_planned: no rollout plan covers this step (call mirl_replay_ingest_plan first)");
   if (!planned_ingest_ok(h) || in->newest_plane_only) return fail(MIRL_ERR_ARG, "planned ingest needs the fused ingest kernel (no de-duplicated storage, no acting_priority_init)");
@@ -1402,6 +1428,7 @@ static double anneal_beta(const mirl_replay_config& c, double progress) {
 extern "C" int mirl_replay_sample(mirl_replay* h, int32_t B, double train_progress, const void* rng_host, uint64_t seed,
                                   int32_t* slot, int32_t* env, int64_t* start, int64_t* loss_start, float* weight,
                                   double* stats, void* stream) {
+  if (h && h->book_broken) return fail(MIRL_ERR_STATE, "this shard's host bookkeeping ran ahead of its device rows (an ingest_plan failed half-way); the shard is unusable");
   if (!h || B <= 0 || !slot || !env || !start || !weight) return fail(MIRL_ERR_ARG, "bad sample arguments");
   hipStream_t st = (hipStream_t)stream;
   Book& bk = h->book;

@@ -155,6 +155,7 @@ class LSTM(BaseModule):
         self.fused = True          # use the fused HIP sequence op on the GPU
         # NHWC conv output consumed in memory order with permuted W_ih columns instead of a transposing copy (_flat_input)
         self.nhwc_input = os.environ.get("MIRL_LSTM_NHWC_INPUT", "1") != "0"
+        self._w_ih_nhwc = None     # (key, permuted W_ih) of the last no-grad pass
         init_weight(self.lstm_cell.weight_hh)
         init_weight(self.lstm_cell.weight_ih)
 
@@ -168,8 +169,17 @@ class LSTM(BaseModule):
         if (x.dim() == 4 and x.is_cuda and self.nhwc_input and not x.is_contiguous()
                 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] * x.shape[2] * x.shape[3] == self.inp_size):
             n, c, h, wd = x.shape
-            return (x.permute(0, 2, 3, 1).reshape(n, h * wd * c),
-                    w.view(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, h * wd * c))
+            rows = x.permute(0, 2, 3, 1).reshape(n, h * wd * c)
+            if torch.is_grad_enabled() and w.requires_grad:
+                # the pass the weight gradient flows through: autograd undoes the permutation (once per learner step)
+                return rows, w.view(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, h * wd * c)
+            # no-grad passes (target net, double-Q selection, burn-in, acting): the permuted copy is a pure function of
+            # the weights — kept per (storage address, version counter), rebuilt after an optimizer step / weight copy
+            key = (w.data_ptr(), w._version, c, h, wd)
+            if self._w_ih_nhwc is None or self._w_ih_nhwc[0] != key:
+                with torch.no_grad():
+                    self._w_ih_nhwc = (key, w.detach().view(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, h * wd * c).contiguous())
+            return rows, self._w_ih_nhwc[1]
         return x.reshape(-1, self.inp_size), w
 
     def project_input(self, x):

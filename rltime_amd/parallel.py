@@ -133,12 +133,16 @@ class DataParallel:
             return
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
+                # through the tensor itself, not `.data`: the version counter must move — the weight-derived caches
+                # (gemm3.joint_rows / weight_planes, the actor's selection stamp) are keyed on it
                 if self._backend != "nccl" and t.is_cuda:
-                    host = t.data.cpu()
+                    host = t.detach().cpu()
                     dist.broadcast(host, src, group=self.group)
-                    t.data.copy_(host)
+                    t.copy_(host)
                 else:
-                    dist.broadcast(t.data, src, group=self.group)
+                    got = t.detach().clone()
+                    dist.broadcast(got, src, group=self.group)
+                    t.copy_(got)
 
     def attach(self, module, buckets="auto"):
         """Make every parameter's .grad a view of one flat buffer.  Autograd then
@@ -162,6 +166,8 @@ class DataParallel:
         n = sum(p.numel() for p in params)
         flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         at = 0
+        for hook in self._hooks:
+            hook.remove()                      # a second attach() must not leave the first one's hooks firing twice
         self._buckets, self._bucket_of, self._hooks = [], {}, []
         for gi, group in enumerate(groups):
             lo = at
@@ -220,6 +226,10 @@ class DataParallel:
             return
         b = self._buckets[self._bucket_of[id(p)]]
         b["left"] -= 1
+        if b["done"] or b["left"] < 0:
+            # a second backward before zero_grad(): the bucket already went out, these gradients would never be reduced
+            raise RuntimeError("DataParallel: a gradient arrived for a bucket that was already reduced "
+                               "(one backward per zero_grad(); call zero_grad() before the next backward)")
         # buckets go out strictly in index order (the same order on every rank): a bucket whose gradients complete
         # before an earlier bucket's (a parameter unused this step) waits for all_reduce_gradients()
         while True:

@@ -113,9 +113,29 @@ class TorchTrainer(MultiStepTrainer):
             torch._foreach_mul_(grads, coef)
             self.value_log.log("grad_norm_clipped", norm * coef, group="train")
         if self.policy.is_cuda():
-            from rltime_amd.models.torch import lstm_seq
-            lstm_seq.check_status()          # a failed sweep must not reach the optimizer (host read of a pinned word, no sync)
+            self._check_sweeps()
         self.optimizer.step()
+
+    def _check_sweeps(self):
+        """A persistent LSTM sweep that gave up (csrc/lstm_seq.hip: bounded spin, non-finite state) sets a pinned host
+        word.  Reading it only means something at a point the host is SYNCHRONISED with the sweeps it covers — the host
+        enqueues about a step ahead of the GPU.  Default: wait for the event recorded after the PREVIOUS step's backward
+        (the GPU still holds a whole step of queued work, so it never idles), then read: a failed step k raises before
+        step k+1's optimizer is enqueued and before anything of it is logged or checkpointed (policy_trainer.py checks
+        again behind its own synchronisation).  MIRL_STRICT_SWEEP_CHECK=1 waits for THIS step's backward instead — no
+        invalid gradient can reach the optimizer at all, at the price of a drained launch queue per step."""
+        import os
+        from rltime_amd.models.torch import lstm_seq
+        if os.environ.get("MIRL_STRICT_SWEEP_CHECK", "0") == "1":
+            torch.cuda.current_stream().synchronize()
+            lstm_seq.check_status()
+            return
+        prev = getattr(self, "_backward_done", None)
+        if prev is not None:
+            prev.synchronize()
+            lstm_seq.check_status()
+        self._backward_done = torch.cuda.Event()
+        self._backward_done.record()
 
     def _reduce_gradients(self):
         """Data-parallel hook: all-reduce the gradients across ranks (RCCL) when

@@ -223,7 +223,24 @@ def _bucket_worker_all_used(rank, world, port, out):
     ref(x).pow(2).mean().backward()
     grads = dict(ref.named_parameters())
     local = torch.cat([grads[names[id(p)]].grad.reshape(-1) for p in dp._params])
-    out[rank] = dict(issued=issued, reduced=flat.clone(), overlapped=dp.buckets_overlapped, local=local)
+    reduced = flat.clone()
+    # a second backward before zero_grad() must not slip through un-reduced, and a second attach() must replace the
+    # hooks of the first (not add a second set that would fire every bucket early)
+    try:
+        net(x).pow(2).mean().backward()
+        twice = "no error"
+    except RuntimeError as e:
+        twice = str(e)
+    versions = [p._version for p in net.parameters()]
+    dp.broadcast_parameters(net)                             # must move the version counters (caches key on them)
+    moved = all(p._version > v for p, v in zip(net.parameters(), versions))
+    flat2 = dp.attach(net)
+    dp.zero_grad()
+    net(x).pow(2).mean().backward()
+    issued2 = [b["done"] for b in dp._buckets]
+    dp.all_reduce_gradients(net)
+    out[rank] = dict(issued=issued, reduced=reduced, overlapped=dp.buckets_overlapped, local=local, twice=twice, moved=moved,
+                     hooks=len(dp._hooks), params=len(dp._params), issued2=issued2, reduced2=flat2.clone())
     dist.destroy_process_group()
 
 
@@ -234,6 +251,11 @@ def test_every_bucket_goes_out_from_the_hooks_when_all_parameters_get_gradients(
     out = mgr.dict()
     mp.spawn(_bucket_worker_all_used, args=(world, port, out), nprocs=world, join=True)
     assert out[0]["issued"] == out[1]["issued"] == [True, True, True]
-    assert out[0]["overlapped"] == 3
     assert torch.equal(out[0]["reduced"], out[1]["reduced"])
     assert torch.allclose(out[0]["reduced"], (out[0]["local"] + out[1]["local"]) / 2, atol=1e-7)
+    for r in (out[0], out[1]):
+        assert "already reduced" in r["twice"]
+        assert r["moved"] and r["hooks"] == r["params"]
+        assert r["issued2"] == [True, True, True] and r["overlapped"] == 6
+    assert torch.equal(out[0]["reduced2"], out[1]["reduced2"])
+    assert torch.allclose(out[0]["reduced2"], out[0]["reduced"], atol=1e-7)      # same weights, same inputs
