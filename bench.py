@@ -102,6 +102,9 @@ def parse():
                          "rltime/acting/actor.py:108-147; at N > 1 the overlapped schedule is measured as the `overlapped_acting` "
                          "sub-record when a rank trains at most 8192 rows per step (where it pays).  auto: on for such ranks "
                          "(the round-3 headline at N = 8); on: always")
+    ap.add_argument("--no-policy-outputs", action="store_true", help="replay without the actor's q-values (keep_policy_outputs=False: "
+                    "the acting head then skips the dueling value stream).  Default: stored with every transition like the "
+                    "reference (acting_interface.py:58-90, policies/torch/dqn.py:143-148), although training never reads them")
     ap.add_argument("--no-acting-graph", action="store_true", help="run the acting forward eagerly instead of replaying it from a HIP graph")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,7 +128,8 @@ def build_config(args, rank, world, scaling, overlap=None):
     spec = CONFIGS[args.config]
     config = load_config(spec["file"])
     targs = {"warmup_steps": 0, "total_steps": 10 ** 12, "log_freq": 10 ** 12,
-             "history_mode": {"args": {"size": args.replay_size, "device_rng": True, "keep_policy_outputs": False}}}
+             "history_mode": {"args": {"size": args.replay_size, "device_rng": True,
+                                      "keep_policy_outputs": not getattr(args, "no_policy_outputs", False)}}}
     for key, val in (("mbatch_size", args.mbatch), ("nstep_train", args.nstep_train),
                      ("burn_in_timesteps", args.burn_in), ("nstep_target", args.nstep_target)):
         if val is not None:
@@ -815,6 +819,13 @@ def main():
                 "acting_overlapped_on_second_stream": res["overlap"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2),
+                # switches that differ from what a reference json config would select on its own
+                "keep_policy_outputs": not args.no_policy_outputs,
+                "device_rng": "Philox4x32-10 on the device for replay sampling, epsilon-greedy and acting-time quantile fractions "
+                              "(the reference draws them with random / np.random / torch.rand on the host: same distributions, other streams; "
+                              "sum-tree indices are bit-exact under the reference's RNG in tests/)",
+                "selection_advantage_only": "double-Q action selection from the advantage stream alone (arg-max unchanged: V and "
+                                            "mean_a A are constant over actions, policies/dqn.py predict_selection)",
                 "f32_products_on": ("bf16 matrix pipe for the wide GEMMs, conv layers 2-3 forward and the conv stack's backward (6 exact-split "
                                     "bf16 MFMAs per f32 product block: csrc/gemm3.hip, conv3.hip, conv_mid.hip, conv_wrw.hip) and the input "
                                     "layer's forward and weight gradient (uint8 pixels are exact bf16, the f32 operand split three ways: 3 "

@@ -14,9 +14,12 @@ weight concatenations, rand / randint, fills).  Here one step is
     mirl_replay_ingest        1 copy + 1 launch  frames + state + scalars + plan + tree, straight
                                                from the static buffers (no clones)
     mirl_conv1_u8_fwd         2 launches       input layer from the env's uint8 frames
-    HIP graph                 ~17 launches     conv 2-3, [features | h] x [W_ih | W_hh]^T in ONE GEMM,
-                                               cell, quantile embedding, joint FC, outputs, head with
-                                               in-kernel Philox draws
+    network                   5 launches       csrc/actnet.hip: conv 2, conv 3 (bias + ReLU in the epilogue, layer 3
+                                               writes the LSTM product's input rows), [features | h] x [W_ih | W_hh]^T
+                                               with the cell in its epilogue, quantile embedding -> feature product ->
+                                               hidden layers -> output shares in one launch, head with in-kernel
+                                               Philox draws.  (Shapes those kernels do not cover keep the round-3 graph
+                                               of library calls, ~15 launches: MIRL_ACT_FUSED=0 forces it.)
 
 Everything that only depends on the weights (b_ih + b_hh, [W_ih | W_hh], the joint
 [last FC | dueling value-hidden] weights) is rebuilt once per get_samples call
@@ -156,6 +159,33 @@ class FastActingStep:
         self.out_b = torch.zeros(self.na + self.nq, **f32)
         self.adv_w = torch.zeros((self.na, h1), **f32)           # advantage stream alone (need_q=False)
         self.freq = (pol.embedding_range * np.pi).contiguous() if self.iqn else None
+        # the network's own kernels (csrc/actnet.hip), piece by piece where the shape is covered
+        fused = os.environ.get("MIRL_ACT_FUSED", "1") != "0"
+        convs = list(self.cnn.layers)
+        self.f_conv = False
+        if fused and len(convs) == 3:
+            c2, c3 = convs[1], convs[2]
+            h1o, w1o = self.y1.shape[2], self.y1.shape[3]
+            k2, s2 = c2.kernel_size[0], c2.stride[0]
+            h2o, w2o = (h1o - k2) // s2 + 1, (w1o - k2) // s2 + 1
+            ok2 = lib.mirl_act_conv_supported(2, c2.in_channels, c2.out_channels, k2, s2, h1o, w1o) and c2.kernel_size[0] == c2.kernel_size[1]
+            k3, s3 = c3.kernel_size[0], c3.stride[0]
+            ok3 = lib.mirl_act_conv_supported(3, c3.in_channels, c3.out_channels, k3, s3, h2o, w2o) and c3.kernel_size[0] == c3.kernel_size[1]
+            h3o, w3o = (h2o - k3) // s3 + 1, (w2o - k3) // s3 + 1
+            if ok2 and ok3 and c2.bias is not None and c3.bias is not None and h3o * w3o * 64 == F and tuple(c2.padding) == (0, 0) == tuple(c3.padding):
+                self.f_conv = True
+                self.y2 = torch.empty((E, h2o, w2o, 64), **f32)
+                self.w2p = torch.empty((64, k2 * k2 * c2.in_channels), **f32)
+                self.w3p = torch.empty((64, k3 * k3 * c3.in_channels), **f32)
+                self.conv_dims = (h1o, w1o, h2o, w2o, h3o, w3o)
+        self.f_lstm = fused and bool(lib.mirl_act_lstm_supported(E, H, F + H))
+        D = int(self.freq.shape[0]) if self.iqn else 0
+        self.f_head = fused and bool(lib.mirl_act_head_supported(E, self.N, H, D, h1 + hv, self.na + self.nq)) \
+            and self.fc.in_features == H
+        if self.f_head:
+            parts, pitch = C.c_int32(), C.c_int32()
+            check(lib.mirl_act_head_parts(h1 + hv, self.na + self.nq, C.byref(parts), C.byref(pitch)))
+            self.part = torch.zeros(parts.value * E * self.N * pitch.value, **f32)
         self.in_kernel_taus = self.iqn and getattr(pol, "tau_source", None) is None
         expl = actor._exploration
         self.expo = expl._device_exponents(actor._env_ids, dev) if expl is not None else None
@@ -192,7 +222,15 @@ class FastActingStep:
         pol, cell, F = self.pol, self.lstm.lstm_cell, self.F
         with torch.no_grad():
             torch.add(cell.bias_ih, cell.bias_hh, out=self.bias_sum)
-            self.wcat[:, :F].copy_(cell.weight_ih)
+            if self.f_conv:
+                # layer 3 writes its NHWC rows straight into xh: W_ih's columns follow (same products, modules.LSTM._flat_input)
+                c2, c3 = self.cnn.layers[1], self.cnn.layers[2]
+                h3o, w3o = self.conv_dims[4], self.conv_dims[5]
+                self.wcat[:, :F].view(-1, h3o, w3o, 64).copy_(cell.weight_ih.view(-1, 64, h3o, w3o).permute(0, 2, 3, 1))
+                self.w2p.view(64, c2.kernel_size[0], c2.kernel_size[1], c2.in_channels).copy_(c2.weight.permute(0, 2, 3, 1))
+                self.w3p.view(64, c3.kernel_size[0], c3.kernel_size[1], c3.in_channels).copy_(c3.weight.permute(0, 2, 3, 1))
+            else:
+                self.wcat[:, :F].copy_(cell.weight_ih)
             self.wcat[:, F:].copy_(cell.weight_hh)
             self.fc_w[:self.h1].copy_(self.fc.weight)
             self.fc_w[self.h1:].copy_(pol.value_hidden_layer.weight)
@@ -235,14 +273,47 @@ class FastActingStep:
     def _body(self):
         """conv 2.. -> LSTM step -> head; reads y1 / xh tail / c_in, writes h, c, actions, qvalues."""
         pol, E, H, F, N = self.pol, self.E, self.H, self.F, self.N
-        x = self.y1
-        for layer in self.cnn.layers[1:]:
-            x = conv_bias_relu(x, layer)
-        ch, hh, ww = x.shape[1:]
-        torch.as_strided(self.xh, (E, ch, hh, ww), (F + H, hh * ww, ww, 1)).copy_(x)       # NHWC -> the reference's (C, H, W) flatten
-        torch.addmm(self.bias_sum, self.xh, self.wcat.t(), out=self.gates)
-        check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
-              "mirl_lstm_cell_fwd")
+        if self.f_conv:
+            c2, c3 = self.cnn.layers[1], self.cnn.layers[2]
+            h1o, w1o, h2o, w2o, h3o, w3o = self.conv_dims
+            check(lib.mirl_act_conv_fwd(2, E, h1o, w1o, _p(self.y1), _p(self.w2p), _p(c2.bias), _p(self.y2), h2o * w2o * 64, _stream()),
+                  "mirl_act_conv_fwd")
+            check(lib.mirl_act_conv_fwd(3, E, h2o, w2o, _p(self.y2), _p(self.w3p), _p(c3.bias), _p(self.xh), F + H, _stream()),
+                  "mirl_act_conv_fwd")
+        else:
+            x = self.y1
+            for layer in self.cnn.layers[1:]:
+                x = conv_bias_relu(x, layer)
+            ch, hh, ww = x.shape[1:]
+            torch.as_strided(self.xh, (E, ch, hh, ww), (F + H, hh * ww, ww, 1)).copy_(x)   # NHWC -> the reference's (C, H, W) flatten
+        if self.f_lstm:
+            check(lib.mirl_act_lstm_fwd(E, H, F + H, _p(self.xh), F + H, _p(self.wcat), _p(self.bias_sum), _p(self.c_in), _p(self.h),
+                                        _p(self.c), _stream()), "mirl_act_lstm_fwd")
+        else:
+            torch.addmm(self.bias_sum, self.xh, self.wcat.t(), out=self.gates)
+            check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
+                  "mirl_lstm_cell_fwd")
+        greedy = self.expo is None
+        if self.f_head:
+            taus = None
+            if self.iqn and not self.in_kernel_taus:
+                taus = pol._draw_taus(E * N).contiguous()        # a test's tau_source replaces the draw
+                self._taus_keep = taus
+            hid = self.fc_w.shape[0] if self.need_q else self.h1
+            no = self.na + (self.nq if self.need_q else 0)
+            wout = self.out_w if self.need_q else self.adv_w
+            parts, pitch = C.c_int32(), C.c_int32()
+            check(lib.mirl_act_head_parts(hid, no, C.byref(parts), C.byref(pitch)))
+            check(lib.mirl_act_head_hidden(
+                E, N, H, int(self.freq.shape[0]) if self.iqn else 0, hid, no, _p(self.h), _p(self.freq) if self.iqn else None, _p(taus),
+                self.rng_seed, _p(self.rng_step), _p(pol.quantile_layer.weight) if self.iqn else None,
+                _p(pol.quantile_layer.bias) if self.iqn else None, _p(self.fc_w), _p(self.fc_b), _p(wout), _p(self.part), None,
+                _stream()), "mirl_act_head_hidden")
+            check(lib.mirl_act_head_select(
+                E, N, self.A, parts.value, pitch.value, _p(self.part), _p(self.out_b), 1 if self.need_q else 0,
+                None if greedy else _p(self.eps), None if greedy else _p(self.expo), self.eps_min, self.rng_seed,
+                _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()), "mirl_act_head_select")
+            return
         feat = self.h
         if self.iqn:
             if self.in_kernel_taus:
@@ -262,7 +333,6 @@ class FastActingStep:
             hidden = torch._addmm_activation(self.fc_b[:self.h1], feat, self.fc_w[:self.h1].t(), use_gelu=False)
             outs = torch.addmm(self.out_b[:self.na], hidden, self.adv_w.t())   # (rows, A): the advantage stream
             pitch, val = self.na, None
-        greedy = self.expo is None
         check(lib.mirl_actor_head_rng(
             E, N, self.A, _p(outs), pitch, val, pitch, None if greedy else _p(self.eps), None if greedy else _p(self.expo),
             self.eps_min, self.rng_seed, None if greedy else _p(self.rng_step), _p(self.actions), _p(self.qvalues), None, _stream()),
