@@ -192,6 +192,8 @@ class SyntheticFeeder:
                 fields["initials"] = (u[1] < 0.002).float()
             if step.get("extra") is not None:
                 fields["extra"] = torch.randn(tuple(step["extra"].shape), device=device, generator=g)
+            if step.get("policy") is not None:          # the actor's q-values, stored with every transition (keep_policy_outputs)
+                fields["policy"] = torch.randn(tuple(step["policy"].shape), device=device, generator=g)
             self.pool.append(fields)
         self.t = 0
 

@@ -742,7 +742,7 @@ int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t* pool, int
                         uint8_t* dones, void* stream);
 /* ---- the policy network of one acting vector step at acting batch sizes (csrc/actnet.hip) -------------------------
  * Replaces, for CNN -> LSTM -> [quantile layer] -> FC -> dueling head policies, the library calls the actor's forward
- * (acting/actor.py:108-122 -> policies/torch/dqn.py:132-148, iqn.py:67-106) was made of: five launches per vector step
+ * (acting/actor.py:108-122 -> policies/torch/dqn.py:132-148, iqn.py:67-106) was made of: six launches per vector step
  * instead of fifteen, f32 MFMA throughout.
  *
  * mirl_act_conv_fwd: conv layer 2 (Ci 32, 4x4, stride 2) or 3 (Ci 64, 3x3, stride 1) of the Atari stack with 64 output
@@ -754,29 +754,42 @@ int mirl_act_conv_fwd(int32_t layer, int64_t frames, int32_t Hi, int32_t Wi, con
                       const float* bias, float* y, int64_t y_frame_pitch, void* stream);
 /* One LSTMCell step for E <= 64 rows (models/torch/modules/lstm.py:83-116 at timesteps = 1, gate order i, f, g, o):
  * gates = xh (E rows of K = F + H floats, xh_pitch apart: [features | h_in]) x w^T (4H, K: [W_ih | W_hh]) + bias
- * (4H: b_ih + b_hh); c_out = f * c_in + i * g; h_out = o * tanh(c_out).  One launch, the gates never reach HBM.      */
+ * (4H: b_ih + b_hh); c_out = f * c_in + i * g; h_out = o * tanh(c_out).  One launch, the gates never reach HBM:
+ * (H / 8) column blocks x KB slices of K, the last slice of a block to arrive adds the shares and runs the cell.
+ * `workspace` (mirl_act_lstm_workspace_bytes, 16-byte aligned) must be ZERO before the first call; every launch
+ * leaves its counters at zero again, so the call can sit in a captured graph.                                       */
 int mirl_act_lstm_supported(int32_t E, int32_t H, int32_t K);
+int mirl_act_lstm_workspace_bytes(int32_t E, int32_t H, int32_t K, int64_t* bytes);
 int mirl_act_lstm_fwd(int32_t E, int32_t H, int32_t K, const float* xh, int64_t xh_pitch, const float* w, const float* bias,
-                      const float* c_in, float* h_out, float* c_out, void* stream);
-/* The head's hidden layers over R = E * N rows (N quantile samples per env, policies/torch/iqn.py:67-106; N = 1 and
- * freq NULL without a quantile layer): tau = taus[m] or a Philox draw keyed (seed, *step, m) exactly as
- * mirl_cos_embed_rng; x = relu(cos(freq * tau) . wq^T + bq) * h[m / N] (wq (H, D)); hid = relu(x . wfc^T + bfc)
- * (wfc (HID, H): the last FC layer's rows, then the dueling value-hidden layer's, dqn.py:50-66); part[p][m][o] = the
- * share of out[m][o] = hid[m] . wout[o] (wout (NO, HID)) that hidden columns 128p .. 128p+127 contribute — p <
- * `parts`, rows `pitch` floats apart (mirl_act_head_parts).  tau_out (R) optional.  The (R, HID) activations stay in
- * LDS / registers.                                                                                                */
+                      const float* c_in, float* h_out, float* c_out, void* workspace, void* stream);
+/* The quantile layer's product over R = E * N rows (policies/torch/iqn.py:67-106): tau = taus[m] or a Philox draw keyed
+ * (seed, *step, m) exactly as mirl_cos_embed_rng; x[m] = relu(cos(freq * tau) . wq^T + bq) * h[m / N] (wq (H, D),
+ * D in {16, 32, 48, 64}; x (R, H)); tau_out (R) optional.                                                           */
+int mirl_act_embed(int32_t E, int32_t N, int32_t H, int32_t D, const float* h, const float* freq, const float* taus,
+                   uint64_t seed, const uint64_t* step, const float* wq, const float* bq, float* x, float* tau_out, void* stream);
+/* The head's hidden layers over R rows of x (R, H): hid = relu(x . wfc^T + bfc) (wfc (HID, H): the last FC layer's rows,
+ * then the dueling value-hidden layer's, dqn.py:50-66); part[p][m][o] = the share of out[m][o] = hid[m] . wout[o] (wout
+ * (NO, HID)) that hidden columns 64p .. 64p+63 contribute — p < `parts`, rows `pitch` floats apart
+ * (mirl_act_head_parts).  The (R, HID) activations stay in registers / LDS.                                         */
 int mirl_act_head_supported(int32_t E, int32_t N, int32_t H, int32_t D, int32_t HID, int32_t NO);
 int mirl_act_head_parts(int32_t HID, int32_t NO, int32_t* parts, int32_t* pitch);
-int mirl_act_head_hidden(int32_t E, int32_t N, int32_t H, int32_t D, int32_t HID, int32_t NO, const float* h,
-                         const float* freq, const float* taus, uint64_t seed, const uint64_t* step, const float* wq,
-                         const float* bq, const float* wfc, const float* bfc, const float* wout, float* part,
-                         float* tau_out, void* stream);
+int mirl_act_head_hidden(int32_t R, int32_t H, int32_t HID, int32_t NO, const float* x, const float* wfc, const float* bfc,
+                         const float* wout, float* part, void* stream);
 /* mirl_actor_head_rng over those shares: out[m][o] = bout[o] + sum_p part[p][m][o]; columns 0 .. A-1 = advantages,
  * column A = the dueling value when has_val; then V + A - mean_a A, mean over the N rows, first maximum,
  * epsilon-greedy with the same Philox draws (policies/torch/dqn.py:74-87, exploration/epsilon_greedy.py:74-100).   */
 int mirl_act_head_select(int32_t E, int32_t N, int32_t A, int32_t parts, int32_t pitch, const float* part, const float* bout,
                          int32_t has_val, const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
                          const uint64_t* rng_step, int32_t* actions, float* qvalues, void* stream);
+/* mirl_synth_env_step and mirl_actor_pre as ONE launch: the workgroup that draws env e's reward / done runs env e's
+ * pre-step on them (arguments: those of the two calls; rewards / dones still receive the env's raw outputs).      */
+int mirl_synth_env_step_pre(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock, int32_t slot,
+                            uint64_t seed, float p_neg, float p_nonpos, float p_done, uint8_t* obs, float* rewards,
+                            uint8_t* dones, int32_t H, int32_t A, const int32_t* actions, const float* h, const float* c,
+                            float* xh_tail, int64_t xh_pitch, float* c_in, float* state_pack, float* initials,
+                            float* rewards_out, uint8_t* dones_out, int32_t clip_rewards, float* ep_reward, int32_t* ep_len,
+                            float* out_reward, int32_t* out_len, int32_t* action_counts, uint64_t* rng_step, uint64_t step,
+                            void* stream);
 int mirl_episode_track(int32_t E, int32_t A, const float* rewards, const uint8_t* dones,
                        const int32_t* actions, float* ep_reward, int32_t* ep_len,
                        float* out_reward, int32_t* out_len, int32_t* action_counts, void* stream);

@@ -202,10 +202,12 @@ _SIGNATURES = {
     "mirl_act_conv_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_act_conv_fwd": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "mirl_act_lstm_supported": [_i32, _i32, _i32],
-    "mirl_act_lstm_fwd": [_i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_act_lstm_workspace_bytes": [_i32, _i32, _i32, _P(_i64)],
+    "mirl_act_lstm_fwd": [_i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_act_embed": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_act_head_supported": [_i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_act_head_parts": [_i32, _i32, _P(_i32), _P(_i32)],
-    "mirl_act_head_hidden": [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mirl_act_head_hidden": [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_act_head_select": [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp],
     "mirl_bias_relu_rows": [_i64, _i32, _vp, _vp, _vp],
     "mirl_colsum_blocks": [_i64, _i32, _P(_i32)],
@@ -220,6 +222,8 @@ _SIGNATURES = {
     "mirl_actor_head_rng": [_i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _f64, _u64, _vp, _vp, _vp, _vp, _vp],
     "mirl_stack_shift": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "mirl_synth_env_step": [_i32, _i64, _vp, _i32, _vp, _i32, _u64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp],
+    "mirl_synth_env_step_pre": [_i32, _i64, _vp, _i32, _vp, _i32, _u64, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp,
+                                _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp],
     "mirl_actor_pre": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
                        _vp, _vp, _u64, _vp],
     "mirl_episode_track": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

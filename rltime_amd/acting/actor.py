@@ -305,7 +305,11 @@ class Actor(ActingInterface):
             self._tracker.flush()
             return IngestedSamples(iters * self._num_envs, self._tracker)
         for _ in range(iters):
-            if fs.env_into:
+            clip = self.clip_rewards and sink is not None
+            pre_done = False
+            if fs.env_into and fs.env_pre and fs.tracker is not None:
+                obs, rewards, dones, stats, pre_done = fs.env_step_pre(clip=clip), None, None, None, True
+            elif fs.env_into:
                 obs, rewards, dones = fs.env_step()
                 stats = None
             else:
@@ -313,7 +317,7 @@ class Actor(ActingInterface):
             if stats is not None:
                 raise RuntimeError("the fused acting step keeps the episode statistics on the device; this env returns "
                                    "host episode stats (set actor.fast_step = False for it)")
-            fields = fs.step(obs, rewards, dones, sink=sink, keep_policy=keep_policy, clip=self.clip_rewards and sink is not None)
+            fields = fs.step(obs, rewards, dones, sink=sink, keep_policy=keep_policy, clip=clip, pre_done=pre_done)
             if sink is None:
                 if out is None:
                     out = DeviceSamples(fs.example, self._num_envs, self._base_env_id)

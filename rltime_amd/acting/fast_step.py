@@ -14,11 +14,10 @@ weight concatenations, rand / randint, fills).  Here one step is
     mirl_replay_ingest        1 copy + 1 launch  frames + state + scalars + plan + tree, straight
                                                from the static buffers (no clones)
     mirl_conv1_u8_fwd         2 launches       input layer from the env's uint8 frames
-    network                   5 launches       csrc/actnet.hip: conv 2, conv 3 (bias + ReLU in the epilogue, layer 3
+    network                   6 launches       csrc/actnet.hip: conv 2, conv 3 (bias + ReLU in the epilogue, layer 3
                                                writes the LSTM product's input rows), [features | h] x [W_ih | W_hh]^T
-                                               with the cell in its epilogue, quantile embedding -> feature product ->
-                                               hidden layers -> output shares in one launch, head with in-kernel
-                                               Philox draws.  (Shapes those kernels do not cover keep the round-3 graph
+                                               with the cell in the same launch, quantile embedding x features, hidden
+                                               layers -> output shares, head with in-kernel Philox draws.  (Shapes those kernels do not cover keep the round-3 graph
                                                of library calls, ~15 launches: MIRL_ACT_FUSED=0 forces it.)
 
 Everything that only depends on the weights (b_ih + b_hh, [W_ih | W_hh], the joint
@@ -160,10 +159,14 @@ class FastActingStep:
         self.adv_w = torch.zeros((self.na, h1), **f32)           # advantage stream alone (need_q=False)
         self.freq = (pol.embedding_range * np.pi).contiguous() if self.iqn else None
         # the network's own kernels (csrc/actnet.hip), piece by piece where the shape is covered
-        fused = os.environ.get("MIRL_ACT_FUSED", "1") != "0"
+        # MIRL_ACT_FUSED: 0 = library calls only, 1 (default) = own kernels where they measured faster (the acting batch of
+        # one rank of a multi-GPU job: <= 64 envs, <= 2048 quantile rows; profiles/r05_actnet_probe.jsonl), 2 = at any size
+        mode = os.environ.get("MIRL_ACT_FUSED", "1")
+        fused = mode != "0"
+        small = mode == "2" or E <= 64
         convs = list(self.cnn.layers)
         self.f_conv = False
-        if fused and len(convs) == 3:
+        if fused and small and len(convs) == 3:
             c2, c3 = convs[1], convs[2]
             h1o, w1o = self.y1.shape[2], self.y1.shape[3]
             k2, s2 = c2.kernel_size[0], c2.stride[0]
@@ -180,12 +183,17 @@ class FastActingStep:
                 self.conv_dims = (h1o, w1o, h2o, w2o, h3o, w3o)
         self.f_lstm = fused and bool(lib.mirl_act_lstm_supported(E, H, F + H))
         D = int(self.freq.shape[0]) if self.iqn else 0
-        self.f_head = fused and bool(lib.mirl_act_head_supported(E, self.N, H, D, h1 + hv, self.na + self.nq)) \
-            and self.fc.in_features == H
+        self.f_head = fused and (mode == "2" or E * self.N <= 2048) and self.fc.in_features == H \
+            and bool(lib.mirl_act_head_supported(E, self.N, H, D, h1 + hv, self.na + self.nq))
         if self.f_head:
             parts, pitch = C.c_int32(), C.c_int32()
             check(lib.mirl_act_head_parts(h1 + hv, self.na + self.nq, C.byref(parts), C.byref(pitch)))
             self.part = torch.zeros(parts.value * E * self.N * pitch.value, **f32)
+            self.xq = torch.empty((E * self.N, H), **f32) if self.iqn else None      # quantile product rows
+        if self.f_lstm:
+            need = C.c_int64()
+            check(lib.mirl_act_lstm_workspace_bytes(E, H, F + H, C.byref(need)))
+            self.lstm_ws = torch.zeros((need.value + 3) // 4, dtype=torch.int32, device=dev)   # zero once: the kernel restores it
         self.in_kernel_taus = self.iqn and getattr(pol, "tau_source", None) is None
         expl = actor._exploration
         self.expo = expl._device_exponents(actor._env_ids, dev) if expl is not None else None
@@ -193,7 +201,6 @@ class FastActingStep:
         self.last_obs = obs0
         # a frame-stack env produces its observations by the shift contract itself: de-duplicated
         # storage can take the newest plane without re-verifying it (MIRL_DEDUP_VERIFY=1: whole stacks)
-        import os
         self.trusted_stack = bool(getattr(actor._vec_env, "frame_stack", False)) and os.environ.get("MIRL_DEDUP_VERIFY", "0") != "1"
         self.tracker = None
         self.graph = None
@@ -201,6 +208,7 @@ class FastActingStep:
         # that the rollout graph and the per-step path see the same env stream
         env = actor._vec_env
         self.env_into = bool(getattr(env, "supports_step_into", lambda: False)())
+        self.env_pre = self.env_into and hasattr(env, "step_into_args") and os.environ.get("MIRL_ACT_ENV_PRE", "1") != "0"
         if self.env_into:
             self.obs_buf = torch.empty_like(obs0)
             self.env_rewards = torch.zeros(E, **f32)
@@ -247,6 +255,14 @@ class FastActingStep:
         self.eps.fill_(eps)
 
     # -- pieces ------------------------------------------------------------------------------
+    def _pre_args(self, tr, row, clip):
+        return (self.H, self.A, _p(self.actions), _p(self.h), _p(self.c),
+                C.c_void_p(self.xh.data_ptr() + 4 * self.F), self.F + self.H, _p(self.c_in), _p(self.state_pack), _p(self.initials),
+                _p(self.rewards), _p(self.dones), 1 if clip else 0,
+                _p(tr.ep_reward) if tr is not None else None, _p(tr.ep_len) if tr is not None else None,
+                _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
+                _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), 0xFFFFFFFFFFFFFFFF, _stream())
+
     def _pre(self, rewards, dones_u8, track=True, clip=False, row=None):
         """row: the episode tracker's ring row (None: reserve the next one).  The step counter the in-kernel draws are
         keyed with advances ON THE DEVICE (MIRL_STEP_ADVANCE); step_no mirrors it on the host."""
@@ -254,13 +270,21 @@ class FastActingStep:
         if tr is not None and row is None:
             row = tr.begin_step()
         self.step_no += 1
-        check(lib.mirl_actor_pre(
-            self.E, self.H, self.A, _p(rewards), _p(dones_u8), _p(self.actions), _p(self.h), _p(self.c),
-            C.c_void_p(self.xh.data_ptr() + 4 * self.F), self.F + self.H, _p(self.c_in), _p(self.state_pack), _p(self.initials),
-            _p(self.rewards), _p(self.dones), 1 if clip else 0,
-            _p(tr.ep_reward) if tr is not None else None, _p(tr.ep_len) if tr is not None else None,
-            _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
-            _p(tr.action_counts) if tr is not None else None, _p(self.rng_step), 0xFFFFFFFFFFFFFFFF, _stream()), "mirl_actor_pre")
+        a = self._pre_args(tr, row, clip)
+        check(lib.mirl_actor_pre(self.E, a[0], a[1], _p(rewards), _p(dones_u8), *a[2:]), "mirl_actor_pre")
+
+    def env_step_pre(self, clip=False, row=None):
+        """env.step and the pre-step as ONE launch (csrc/acting.hip k_synth_env_step<true>): the workgroup that draws an
+        env's reward / done applies them to that env's recurrent carry, stored state and episode statistics."""
+        env = self.actor._vec_env
+        tr = self.tracker
+        if tr is not None and row is None:
+            row = tr.begin_step()
+        self.step_no += 1
+        check(lib.mirl_synth_env_step_pre(*env.step_into_args(self.obs_buf, self.env_rewards, self.env_dones), *self._pre_args(tr, row, clip)),
+              "mirl_synth_env_step_pre")
+        env.advance_host()
+        return self.obs_buf
 
     def _conv1(self, obs, packed=False):
         """packed=True: self.wpk still holds the current weights (packed by the call's re-selection)."""
@@ -288,7 +312,7 @@ class FastActingStep:
             torch.as_strided(self.xh, (E, ch, hh, ww), (F + H, hh * ww, ww, 1)).copy_(x)   # NHWC -> the reference's (C, H, W) flatten
         if self.f_lstm:
             check(lib.mirl_act_lstm_fwd(E, H, F + H, _p(self.xh), F + H, _p(self.wcat), _p(self.bias_sum), _p(self.c_in), _p(self.h),
-                                        _p(self.c), _stream()), "mirl_act_lstm_fwd")
+                                        _p(self.c), _p(self.lstm_ws), _stream()), "mirl_act_lstm_fwd")
         else:
             torch.addmm(self.bias_sum, self.xh, self.wcat.t(), out=self.gates)
             check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
@@ -304,15 +328,18 @@ class FastActingStep:
             wout = self.out_w if self.need_q else self.adv_w
             parts, pitch = C.c_int32(), C.c_int32()
             check(lib.mirl_act_head_parts(hid, no, C.byref(parts), C.byref(pitch)))
-            check(lib.mirl_act_head_hidden(
-                E, N, H, int(self.freq.shape[0]) if self.iqn else 0, hid, no, _p(self.h), _p(self.freq) if self.iqn else None, _p(taus),
-                self.rng_seed, _p(self.rng_step), _p(pol.quantile_layer.weight) if self.iqn else None,
-                _p(pol.quantile_layer.bias) if self.iqn else None, _p(self.fc_w), _p(self.fc_b), _p(wout), _p(self.part), None,
-                _stream()), "mirl_act_head_hidden")
+            x = self.h
+            if self.iqn:
+                x = self.xq
+                check(lib.mirl_act_embed(E, N, H, int(self.freq.shape[0]), _p(self.h), _p(self.freq), _p(taus), self.rng_seed, _p(self.rng_step),
+                                         _p(pol.quantile_layer.weight), _p(pol.quantile_layer.bias), _p(x), None, _stream()), "mirl_act_embed")
+            eps_p, expo_p = (None, None) if greedy else (_p(self.eps), _p(self.expo))
+            check(lib.mirl_act_head_hidden(E * N, H, hid, no, _p(x), _p(self.fc_w), _p(self.fc_b), _p(wout), _p(self.part), _stream()),
+                  "mirl_act_head_hidden")
             check(lib.mirl_act_head_select(
                 E, N, self.A, parts.value, pitch.value, _p(self.part), _p(self.out_b), 1 if self.need_q else 0,
-                None if greedy else _p(self.eps), None if greedy else _p(self.expo), self.eps_min, self.rng_seed,
-                _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()), "mirl_act_head_select")
+                eps_p, expo_p, self.eps_min, self.rng_seed, _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()),
+                "mirl_act_head_select")
             return
         feat = self.h
         if self.iqn:
@@ -371,12 +398,14 @@ class FastActingStep:
         self._conv1(self.last_obs)
         self.graph.replay()
 
-    def step(self, obs, rewards, dones, sink=None, keep_policy=False, clip=False):
+    def step(self, obs, rewards, dones, sink=None, keep_policy=False, clip=False, pre_done=False):
         """One vector step AFTER env.step(self.actions) returned (obs, rewards, dones).  With a
         `sink` (device replay) the transition is ingested straight from the static buffers;
-        without one the caller gets clones of them (DeviceSamples fields)."""
-        dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
-        self._pre(rewards if rewards.dtype == torch.float32 else rewards.float(), dones_u8, clip=clip)
+        without one the caller gets clones of them (DeviceSamples fields).  pre_done: the pre-step already ran
+        with the env step (env_step_pre)."""
+        if not pre_done:
+            dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
+            self._pre(rewards if rewards.dtype == torch.float32 else rewards.float(), dones_u8, clip=clip)
         fields = None
         if sink is not None:
             sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
@@ -415,8 +444,11 @@ class FastActingStep:
 
     def _rollout_body(self, iters, sink, keep_policy, clip):
         for k in range(iters):
-            obs, rewards, dones = self.env_step()
-            self._pre(rewards, dones, clip=clip, row=k)
+            if self.env_pre:
+                obs = self.env_step_pre(clip=clip, row=k)
+            else:
+                obs, rewards, dones = self.env_step()
+                self._pre(rewards, dones, clip=clip, row=k)
             sink.ingest_planned(k, obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
                                 policy=self.qvalues if keep_policy else None)
             self._conv1(obs, packed=True)

@@ -73,6 +73,15 @@ class SyntheticAtariVecEnv:
               "mirl_synth_env_step")
         self._slot ^= 1
 
+    def step_into_args(self, obs_out, rewards_out, dones_out):
+        """The leading arguments of mirl_synth_env_step / mirl_synth_env_step_pre for the NEXT step (a caller that fuses
+        the env step with its own work launches the kernel itself and then calls advance_host())."""
+        return (self.num_envs, self._row_bytes, _p(self._pool), self._pool.shape[0], _p(self._clock), self._slot, self.seed,
+                self._p_neg, self._p_nonpos, self.done_prob, _p(obs_out), _p(rewards_out), _p(dones_out))
+
+    def advance_host(self):
+        self._slot ^= 1
+
     def clock_parity(self):
         """Which word of the clock pair the NEXT step reads: part of the identity of a captured rollout."""
         return self._slot

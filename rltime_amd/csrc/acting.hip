@@ -100,40 +100,47 @@ k_actor_head(int E, int N, int A, const float* __restrict__ adv, const float* __
 //     the episode statistics; dones as uint8;
 //   * episode reward / length accumulators and the action histogram (k_episode_track);
 //   * the step counter the acting head's Philox draws are keyed with.
-__global__ void __launch_bounds__(256)
-k_actor_pre(int E, int H, int A, const float* __restrict__ rewards_raw, const uint8_t* __restrict__ dones,
-            const int32_t* __restrict__ actions, const float* __restrict__ h, const float* __restrict__ c,
-            float* __restrict__ xh_tail, int64_t xh_pitch, float* __restrict__ c_in, float* __restrict__ state_pack,
-            float* __restrict__ initials, float* __restrict__ rewards_out, uint8_t* __restrict__ dones_out, int clip,
-            float* __restrict__ ep_reward, int32_t* __restrict__ ep_len, float* __restrict__ out_reward,
-            int32_t* __restrict__ out_len, int32_t* __restrict__ action_counts,
-            uint64_t* __restrict__ rng_step, uint64_t step) {
-  const int e = blockIdx.x;
-  const float keep = dones[e] ? 0.0f : 1.0f;
+struct ActorPreArgs {
+  int H, A;
+  const int32_t* actions; const float* h; const float* c;
+  float* xh_tail; int64_t xh_pitch; float* c_in; float* state_pack; float* initials; float* rewards_out; uint8_t* dones_out;
+  int clip;
+  float* ep_reward; int32_t* ep_len; float* out_reward; int32_t* out_len; int32_t* action_counts;
+  uint64_t* rng_step; uint64_t step;
+};
+
+// env e's share of the pre-step, by the 256 threads of one workgroup: (rr, dn) = the env's raw reward / done
+__device__ __forceinline__ void actor_pre_env(const ActorPreArgs& p, int e, float rr, int dn) {
+  const int H = p.H;
+  const float keep = dn ? 0.0f : 1.0f;
   for (int j = threadIdx.x; j < H; j += 256) {
-    const float hm = h[(int64_t)e * H + j] * keep, cm = c[(int64_t)e * H + j] * keep;
-    xh_tail[(int64_t)e * xh_pitch + j] = hm;
-    c_in[(int64_t)e * H + j] = cm;
-    state_pack[(int64_t)e * 2 * H + j] = hm;
-    state_pack[(int64_t)e * 2 * H + H + j] = cm;
+    const float hm = p.h[(int64_t)e * H + j] * keep, cm = p.c[(int64_t)e * H + j] * keep;
+    p.xh_tail[(int64_t)e * p.xh_pitch + j] = hm;
+    p.c_in[(int64_t)e * H + j] = cm;
+    p.state_pack[(int64_t)e * 2 * H + j] = hm;
+    p.state_pack[(int64_t)e * 2 * H + H + j] = cm;
   }
   if (threadIdx.x == 0) {
-    const float rr = rewards_raw[e];
-    const int dn = dones[e] ? 1 : 0;
-    initials[e] = dn ? 1.0f : 0.0f;
-    dones_out[e] = (uint8_t)dn;
-    rewards_out[e] = clip ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : rr;
-    if (ep_reward) {
-      float r = ep_reward[e] + rr;
-      int n = ep_len[e] + 1;
-      if (dn) { out_reward[e] = r; out_len[e] = n; r = 0.f; n = 0; }
-      else { out_reward[e] = 0.f; out_len[e] = 0; }
-      ep_reward[e] = r; ep_len[e] = n;
-      if (action_counts && actions) { const int a = actions[e]; if (a >= 0 && a < A) atomicAdd(action_counts + a, 1); }
+    p.initials[e] = dn ? 1.0f : 0.0f;
+    p.dones_out[e] = (uint8_t)dn;
+    p.rewards_out[e] = p.clip ? (rr > 0.f ? 1.f : (rr < 0.f ? -1.f : 0.f)) : rr;
+    if (p.ep_reward) {
+      float r = p.ep_reward[e] + rr;
+      int n = p.ep_len[e] + 1;
+      if (dn) { p.out_reward[e] = r; p.out_len[e] = n; r = 0.f; n = 0; }
+      else { p.out_reward[e] = 0.f; p.out_len[e] = 0; }
+      p.ep_reward[e] = r; p.ep_len[e] = n;
+      if (p.action_counts && p.actions) { const int a = p.actions[e]; if (a >= 0 && a < p.A) atomicAdd(p.action_counts + a, 1); }
     }
     // step == MIRL_STEP_ADVANCE: the counter advances on the device (a captured rollout replays with the same argument)
-    if (e == 0 && rng_step) *rng_step = step == ~0ull ? *rng_step + 1ull : step;
+    if (e == 0 && p.rng_step) *p.rng_step = p.step == ~0ull ? *p.rng_step + 1ull : p.step;
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_actor_pre(ActorPreArgs p, const float* __restrict__ rewards_raw, const uint8_t* __restrict__ dones) {
+  const int e = blockIdx.x;
+  actor_pre_env(p, e, rewards_raw[e], dones[e] ? 1 : 0);
 }
 
 // The frame-stack wrapper's shift on the device (env_wrappers/common.py:141-178 under an
@@ -159,22 +166,30 @@ k_stack_shift(int P, int plane_q, const uint4* __restrict__ in, uint4* __restric
 // = frame batch t % pool_n of a pre-generated pool copied into the env's static output block, reward in {-1, 0, 1} with
 // cumulative probabilities (p_neg, p_nonpos) and done with probability p_done from ONE Philox4x32-10 block per
 // (seed, t, env).  Capturable: every argument is the same for every replay.
+// PRE: the actor's pre-step (k_actor_pre) for env e rides in the workgroup that draws the env's reward / done — every one of
+// its threads makes the same Philox draw (no exchange), so env.step and the pre-step are ONE launch.
+template <bool PRE>
 __global__ void __launch_bounds__(256)
 k_synth_env_step(int row_q, const uint4* __restrict__ pool, int pool_n, int64_t pool_stride_q, const uint64_t* __restrict__ clock_in,
                  uint64_t* __restrict__ clock_out, uint64_t seed, float p_neg, float p_nonpos, float p_done,
-                 uint4* __restrict__ obs, float* __restrict__ rewards, uint8_t* __restrict__ dones) {
+                 uint4* __restrict__ obs, float* __restrict__ rewards, uint8_t* __restrict__ dones, ActorPreArgs pre) {
   const int e = blockIdx.y;
   const uint64_t t = *clock_in + 1ull;                 // every workgroup reads the word nobody writes in this launch
   const uint4* src = pool + (int64_t)(t % (uint64_t)pool_n) * pool_stride_q + (int64_t)e * row_q;
   uint4* dst = obs + (int64_t)e * row_q;
   for (int c = blockIdx.x * 256 + threadIdx.x; c < row_q; c += gridDim.x * 256) dst[c] = src[c];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && (PRE || threadIdx.x == 0)) {
     uint32_t r[4];
     philox_4x32(seed ^ 0xE17ull, t, (uint32_t)e, r);
     const float u0 = (float)(r[0] >> 8) * (1.0f / 16777216.0f), u1 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
-    rewards[e] = u0 < p_neg ? -1.0f : (u0 < p_nonpos ? 0.0f : 1.0f);
-    dones[e] = u1 < p_done ? 1 : 0;
-    if (e == 0) *clock_out = t;                        // the OTHER word of the pair: the next launch reads it
+    const float rr = u0 < p_neg ? -1.0f : (u0 < p_nonpos ? 0.0f : 1.0f);
+    const int dn = u1 < p_done ? 1 : 0;
+    if (threadIdx.x == 0) {
+      rewards[e] = rr;
+      dones[e] = (uint8_t)dn;
+      if (e == 0) *clock_out = t;                      // the OTHER word of the pair: the next launch reads it
+    }
+    if (PRE) actor_pre_env(pre, e, rr, dn);
   }
 }
 
@@ -191,9 +206,47 @@ extern "C" int mirl_synth_env_step(int32_t E, int64_t frame_bytes, const uint8_t
   mirl::ProfScope ps("k_synth_env_step", 2.0 * (double)E * (double)frame_bytes, (hipStream_t)stream);
   // the step counter is a PAIR of words: this launch reads clock[slot] and writes clock[slot ^ 1] — no workgroup can see
   // the new value, no atomics (a shared arrival counter cost 18 of the kernel's 25 us at 256 envs)
-  hipLaunchKernelGGL(mirl::k_synth_env_step, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, row_q, (const uint4*)pool, (int)pool_n,
+  hipLaunchKernelGGL(mirl::k_synth_env_step<false>, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, row_q, (const uint4*)pool, (int)pool_n,
                      (int64_t)E * row_q, (const uint64_t*)(clock + slot), clock + (slot ^ 1), seed, p_neg, p_nonpos, p_done,
-                     (uint4*)obs, rewards, dones);
+                     (uint4*)obs, rewards, dones, mirl::ActorPreArgs{});
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+static int fill_pre(mirl::ActorPreArgs& p, int32_t E, int32_t H, int32_t A, const int32_t* actions, const float* h, const float* c,
+                    float* xh_tail, int64_t xh_pitch, float* c_in, float* state_pack, float* initials, float* rewards_out,
+                    uint8_t* dones_out, int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
+                    int32_t* action_counts, uint64_t* rng_step, uint64_t step) {
+  if (E <= 0 || H <= 0 || !h || !c || !xh_tail || !c_in || !state_pack || !initials || !rewards_out ||
+      !dones_out || (ep_reward && (!ep_len || !out_reward || !out_len)))
+    return mirl::fail(MIRL_ERR_ARG, "bad actor_pre arguments");
+  p.H = H; p.A = A; p.actions = actions; p.h = h; p.c = c; p.xh_tail = xh_tail; p.xh_pitch = xh_pitch; p.c_in = c_in;
+  p.state_pack = state_pack; p.initials = initials; p.rewards_out = rewards_out; p.dones_out = dones_out; p.clip = clip_rewards;
+  p.ep_reward = ep_reward; p.ep_len = ep_len; p.out_reward = out_reward; p.out_len = out_len; p.action_counts = action_counts;
+  p.rng_step = rng_step; p.step = step;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_synth_env_step_pre(int32_t E, int64_t frame_bytes, const uint8_t* pool, int32_t pool_n, uint64_t* clock, int32_t slot,
+                                       uint64_t seed, float p_neg, float p_nonpos, float p_done, uint8_t* obs, float* rewards,
+                                       uint8_t* dones, int32_t H, int32_t A, const int32_t* actions, const float* h, const float* c,
+                                       float* xh_tail, int64_t xh_pitch, float* c_in, float* state_pack, float* initials,
+                                       float* rewards_out, uint8_t* dones_out, int32_t clip_rewards, float* ep_reward, int32_t* ep_len,
+                                       float* out_reward, int32_t* out_len, int32_t* action_counts, uint64_t* rng_step, uint64_t step,
+                                       void* stream) {
+  if (E <= 0 || frame_bytes <= 0 || (frame_bytes % 16) || pool_n <= 0 || !pool || !clock || !obs || !rewards || !dones ||
+      (slot != 0 && slot != 1) || ((uintptr_t)pool % 16) || ((uintptr_t)obs % 16) || ((uintptr_t)clock % 16))
+    return mirl::fail(MIRL_ERR_ARG, "bad synth_env_step arguments (16-byte aligned frame rows, slot 0 | 1)");
+  mirl::ActorPreArgs p;
+  int rc = fill_pre(p, E, H, A, actions, h, c, xh_tail, xh_pitch, c_in, state_pack, initials, rewards_out, dones_out, clip_rewards,
+                    ep_reward, ep_len, out_reward, out_len, action_counts, rng_step, step);
+  if (rc) return rc;
+  const int row_q = (int)(frame_bytes / 16);
+  int gx = (row_q + 255) / 256; if (gx > 8) gx = 8;
+  mirl::ProfScope ps("k_synth_env_step_pre", 2.0 * (double)E * (double)frame_bytes + (double)E * H * 4.0 * 6.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(mirl::k_synth_env_step<true>, dim3(gx, E), dim3(256), 0, (hipStream_t)stream, row_q, (const uint4*)pool, (int)pool_n,
+                     (int64_t)E * row_q, (const uint64_t*)(clock + slot), clock + (slot ^ 1), seed, p_neg, p_nonpos, p_done,
+                     (uint4*)obs, rewards, dones, p);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
@@ -216,13 +269,13 @@ extern "C" int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewa
                               float* c_in, float* state_pack, float* initials, float* rewards_out, uint8_t* dones_out,
                               int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
                               int32_t* action_counts, uint64_t* rng_step, uint64_t step, void* stream) {
-  if (E <= 0 || H <= 0 || !rewards_raw || !dones || !h || !c || !xh_tail || !c_in || !state_pack || !initials || !rewards_out ||
-      !dones_out || (ep_reward && (!ep_len || !out_reward || !out_len)))
-    return mirl::fail(MIRL_ERR_ARG, "bad actor_pre arguments");
+  if (!rewards_raw || !dones) return mirl::fail(MIRL_ERR_ARG, "bad actor_pre arguments");
+  mirl::ActorPreArgs p;
+  int rc = fill_pre(p, E, H, A, actions, h, c, xh_tail, xh_pitch, c_in, state_pack, initials, rewards_out, dones_out, clip_rewards,
+                    ep_reward, ep_len, out_reward, out_len, action_counts, rng_step, step);
+  if (rc) return rc;
   mirl::ProfScope ps("k_actor_pre", (double)E * H * 4.0 * 6.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(mirl::k_actor_pre, dim3(E), dim3(256), 0, (hipStream_t)stream, (int)E, (int)H, (int)A, rewards_raw, dones, actions,
-                     h, c, xh_tail, xh_pitch, c_in, state_pack, initials, rewards_out, dones_out, (int)clip_rewards, ep_reward,
-                     ep_len, out_reward, out_len, action_counts, rng_step, step);
+  hipLaunchKernelGGL(mirl::k_actor_pre, dim3(E), dim3(256), 0, (hipStream_t)stream, p, rewards_raw, dones);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

@@ -5,17 +5,17 @@
 // last FC (+ dueling value-hidden) -> outputs -> dueling combine / quantile mean / arg-max / epsilon-greedy.
 // Rounds 2-4 ran that as 15 launches per vector step on the libraries (MIOpen: zero-fill + implicit GEMM +
 // bias/ReLU per conv layer; hipBLASLt: four GEMMs whose M is 32 .. 8192 rows) — every one of them 4-16 us at
-// E = 32 whatever it computes, and 40 vector steps per learner step.  Here the same network is five launches:
+// E = 32 whatever it computes, and 40 vector steps per learner step.  Here the same network is six launches:
 //
 //   k_act_conv<L2>, k_act_conv<L3>  conv layers 2-3 as implicit GEMMs over NHWC rows, 16-row tiles (162 / 98
 //                                   workgroups at E = 32), bias + ReLU in the epilogue, no zero-fill; layer 3
 //                                   writes straight into the LSTM product's input rows [features | h]
-//   k_act_lstm                      [features | h] x [W_ih | W_hh]^T + (b_ih + b_hh) with the CELL in the epilogue:
-//                                   a workgroup owns 4 hidden units x 4 gates (one 16-column MFMA tile), its 8 waves
-//                                   split K; every weight byte is read exactly once per step (E <= 64)
-//   k_act_head_hidden               quantile fractions (Philox) -> cos features -> embedding product + ReLU ->
-//                                   x features (all in LDS) -> hidden layer(s) + ReLU -> the workgroup's share of
-//                                   the output layer; the (rows, 512) activations never reach HBM
+//   k_act_lstm                      [features | h] x [W_ih | W_hh]^T + (b_ih + b_hh) with the CELL in the same launch:
+//                                   256 workgroups = 64 column blocks (8 hidden units x 4 gates) x 4 slices of K, the
+//                                   last slice of a block to arrive adds the shares and runs the cell (E <= 64)
+//   k_act_embed                     quantile fractions (Philox) -> cos features -> embedding product + ReLU -> x features
+//   k_act_hidden                    hidden layer(s) + ReLU -> the workgroup's share of the output layer; the
+//                                   (rows, 1024) hidden activations never reach HBM
 //   k_act_head_select               sums the output shares, dueling combine, mean over quantile rows, arg-max,
 //                                   epsilon-greedy (the same Philox draws as k_actor_head)
 //
@@ -122,58 +122,72 @@ k_act_conv(ActConvArgs a) {
 // One LSTMCell step for E <= 64 envs (modules/lstm.py:83-116 at timesteps = 1; gate order i, f, g, o):
 //   gates[e][q*H + j] = bias[q*H + j] + sum_k xh[e][k] * w[q*H + j][k],  k over [features | h_in] (K = F + H)
 //   c = f * c_in + i * g,  h = o * tanh(c)
-// Workgroup b = hidden units 4b .. 4b+3: the 16 columns of its MFMA tile are (gate q = r >> 2, unit r & 3), so the
-// four gates of a unit meet in one workgroup.  Its 8 waves take the 16-wide K steps round-robin (wave w: steps w,
-// w + 8, ...: neighbouring waves read neighbouring 64-byte pieces of a weight row), partial tiles meet in LDS.
-// H / 4 workgroups x 8 waves = one wave per SIMD at H = 512; 12-15 loads of 1 KB in flight per wave.
+// At 32 rows this is a 30 MB weight stream against 0.5 GFLOP: what bounds it is how many CUs pull on the stream and how
+// often the 467 KB of input rows are re-read, not the matrix pipe.  Workgroup (jb, kb) = hidden units 8 jb .. 8 jb + 7
+// (two 16-column MFMA tiles whose columns are (gate q = r >> 2, unit r & 3): the four gates of a unit meet in one
+// workgroup) x the kb-th of KB slices of K; (H / 8) x KB = 256 workgroups at H = 512, one per CU.  Its 8 waves take the
+// slice's 16-wide K steps round-robin (neighbouring waves read neighbouring 64-byte pieces of a weight row); the input
+// rows of a slice are read once per workgroup and feed both tiles.  Partial tiles meet in LDS, the workgroup's share goes
+// to the workspace, and the LAST workgroup of a column block to arrive (one agent-scope counter per block) adds the KB
+// shares and the bias and runs the cell — every weight byte is read once per step, the gates never exist in HBM, and
+// there is no second launch.  The counter returns to zero, so the launch can be replayed from a captured graph.
 struct ActLstmArgs {
   const float* xh; int64_t xh_pitch;
   const float* w; const float* bias; const float* c_in;
   float* h_out; float* c_out;
-  int E, H, K;
+  float* shares; unsigned* arrived;      // workspace: [KB][H / 8][E][32] floats, [H / 8] counters (zero between launches)
+  int E, H, K, KB, SPB;                  // SPB: K steps per slice
 };
 
 template <int RT>
 __global__ void __launch_bounds__(512)
 k_act_lstm(ActLstmArgs a) {
-  __shared__ float red[8 * RT * 256];                       // [wave][row tile][16 rows][16 cols]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [8 waves][RT][2 tiles][16 rows][16 cols]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int j0 = blockIdx.x * 4;
-  const float* wp = a.w + ((int64_t)(r >> 2) * a.H + j0 + (r & 3)) * a.K + 4 * g;
+  const int jb = blockIdx.x, kb = blockIdx.y, j0 = 8 * jb;
+  const float* wp[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) wp[c] = a.w + ((int64_t)(r >> 2) * a.H + j0 + 4 * c + (r & 3)) * a.K + 4 * g;
   const float* xp[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     int row = 16 * t + r;
-    if (row >= a.E) row = a.E - 1;
+    if (row >= a.E) row = a.E - 1;                           // clamped rows are computed and never used
     xp[t] = a.xh + (int64_t)row * a.xh_pitch + 4 * g;
   }
-  an_f4 acc[RT];
+  an_f4 acc[RT][2];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) acc[t] = an_f4{0.f, 0.f, 0.f, 0.f};
-  // wave w takes K steps w, w + 8, w + 16, ...; a pass = U of them, double-buffered: pass p + 1's loads (U weight pieces +
-  // U * RT input pieces of 1 KB each) are in flight while pass p multiplies.  Steps past the end read step 0 and
-  // multiply by zero weights (uniform passes, no tail loop).
+  for (int t = 0; t < RT; ++t) { acc[t][0] = an_f4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = an_f4{0.f, 0.f, 0.f, 0.f}; }
   const int steps = a.K / 16;
-  constexpr int U = RT >= 4 ? 4 : 8;
-  const int passes = ((steps + 7) / 8 + U - 1) / U;
-  an_f4 b[2][U], av[2][U][RT];
+  const int s0 = kb * a.SPB;
+  const int s1 = s0 + a.SPB < steps ? s0 + a.SPB : steps;
+  // wave w takes steps s0 + w, s0 + w + 8, ...; a pass = U of them, double-buffered: pass p + 1's loads are in flight while
+  // pass p multiplies.  Straight-line passes (a conditional load would make the compiler wait for EVERY outstanding load
+  // at the join): a step past the slice's end reads step s0 and multiplies by zeroed weights.
+  constexpr int U = RT >= 4 ? 2 : 4;
+  const int passes = ((a.SPB + 7) / 8 + U - 1) / U;
+  an_f4 b[2][U][2], av[2][U][RT];
 #define AN_LSTM_LOAD(buf, pass)                                                                  \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
-    int ss = wave + 8 * (U * (pass) + u);                                                        \
-    if (ss >= steps) ss = 0;                                                                     \
-    b[buf][u] = *(const an_f4*)(wp + 16 * ss);                                                   \
+    int ss = s0 + wave + 8 * (U * (pass) + u);                                                   \
+    if (ss >= s1) ss = s0;                                                                       \
+    b[buf][u][0] = *(const an_f4*)(wp[0] + 16 * ss);                                             \
+    b[buf][u][1] = *(const an_f4*)(wp[1] + 16 * ss);                                             \
     _Pragma("unroll") for (int t = 0; t < RT; ++t) av[buf][u][t] = *(const an_f4*)(xp[t] + 16 * ss); \
   }
 #define AN_LSTM_MUL(buf, pass)                                                                   \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
-    const bool ok = wave + 8 * (U * (pass) + u) < steps;                                         \
-    an_f4 bb = b[buf][u];                                                                        \
-    bb.x = ok ? bb.x : 0.f; bb.y = ok ? bb.y : 0.f; bb.z = ok ? bb.z : 0.f; bb.w = ok ? bb.w : 0.f; \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) AN_MFMA4(acc[t], av[buf][u][t], bb);          \
+    const bool ok = s0 + wave + 8 * (U * (pass) + u) < s1;                                       \
+    an_f4 b0 = b[buf][u][0], b1 = b[buf][u][1];                                                  \
+    b0.x = ok ? b0.x : 0.f; b0.y = ok ? b0.y : 0.f; b0.z = ok ? b0.z : 0.f; b0.w = ok ? b0.w : 0.f; \
+    b1.x = ok ? b1.x : 0.f; b1.y = ok ? b1.y : 0.f; b1.z = ok ? b1.z : 0.f; b1.w = ok ? b1.w : 0.f; \
+    _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                             \
+      AN_MFMA4(acc[t][0], av[buf][u][t], b0);                                                    \
+      AN_MFMA4(acc[t][1], av[buf][u][t], b1);                                                    \
+    }                                                                                            \
   }
-  // straight-line loop body (no conditional loads: a branch would make the compiler wait for EVERY outstanding load at
-  // the join); a pass beyond the end loads step 0 and multiplies by zeros
   AN_LSTM_LOAD(0, 0)
   for (int p = 0; p < passes; p += 2) {
     AN_LSTM_LOAD(1, p + 1)
@@ -190,280 +204,302 @@ k_act_lstm(ActLstmArgs a) {
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) red[((wave * RT + t) * 16 + 4 * g + i) * 16 + r] = acc[t][i];
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(((wave * RT + t) * 2 + c) * 16 + 4 * g + i) * 16 + r] = acc[t][c][i];
   __syncthreads();
-  for (int idx = threadIdx.x; idx < a.E * 4; idx += 512) {
-    const int row = idx >> 2, u = idx & 3, t = row >> 4, rr = row & 15;
+  // this workgroup's share: rows < E x 32 columns (column 16 c + r of the block)
+  const int NJB = a.H / 8;
+  float* mine = a.shares + ((int64_t)kb * NJB + jb) * a.E * 32;
+  for (int idx = tid; idx < a.E * 32; idx += 512) {
+    const int row = idx >> 5, col = idx & 31, t = row >> 4, rr = row & 15, c = col >> 4, cr = col & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum = sum + red[(((w * RT + t) * 2 + c) * 16 + rr) * 16 + cr];
+    if (a.KB == 1) red[8 * RT * 512 + idx] = sum;          // single slice: the share stays in LDS
+    else __hip_atomic_store(mine + idx, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1) store
+  }
+  if (a.KB > 1) {
+    // No fence (an agent-scope release / acquire pair writes back and invalidates whole L2s on this 8-XCD part: measured
+    // 2x the kernel).  The shares travel as write-through stores and sc1 loads; `s_waitcnt vmcnt(0)` holds the arrival
+    // back until this wave's stores have reached the coherence point (the exchange form of csrc/lstm_seq.hip).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(a.arrived + jb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.KB - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(a.arrived + jb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch / replay
+  } else {
+    __syncthreads();
+  }
+  for (int idx = tid; idx < a.E * 8; idx += 512) {
+    const int row = idx >> 3, u = idx & 7;
     float pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      const int col = 16 * (u >> 2) + 4 * q + (u & 3);
       float sum = a.bias[q * a.H + j0 + u];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) sum = sum + red[((w * RT + t) * 16 + rr) * 16 + q * 4 + u];
+      if (a.KB == 1) sum = sum + red[8 * RT * 512 + row * 32 + col];
+      else for (int k = 0; k < a.KB; ++k)
+        sum = sum + __hip_atomic_load(a.shares + (((int64_t)k * NJB + jb) * a.E + row) * 32 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pre[q] = sum;
     }
     const float gi = an_sigmoid(pre[0]), gf = an_sigmoid(pre[1]), gg = tanhf(pre[2]), go = an_sigmoid(pre[3]);
     const int64_t at = (int64_t)row * a.H + j0 + u;
-    const float c = gf * a.c_in[at] + gi * gg;
-    a.c_out[at] = c;
-    a.h_out[at] = go * tanhf(c);
+    const float cc = gf * a.c_in[at] + gi * gg;
+    a.c_out[at] = cc;
+    a.h_out[at] = go * tanhf(cc);
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The head's hidden layers for R = E * N rows (N quantile samples per env; N = 1 without a quantile layer):
+// The quantile layer's product for R = E * N rows (policies/torch/iqn.py:67-106):
 //   tau[m]    = given, or 24-bit uniform of Philox4x32-10(seed ^ 0x7A5, *step, m)     (iqn.py:76, as k_cos_embed_rng)
 //   phi[m][i] = cos(freq[i] * tau[m]),  freq = pi * (1 .. D)                            (iqn.py:78-81)
 //   x[m][c]   = relu(phi[m] . wq[c] + bq[c]) * h[m / N][c]                              (iqn.py:82-102)
-//   hid[m][j] = relu(x[m] . wfc[j] + bfc[j]),  j < HID   (last FC layer, then the dueling value-hidden layer:
-//                                                         dqn.py:50-66 — both read the same x)
-//   part[cb][m][o] = sum over the workgroup's 128 hidden columns of hid[m][j] * wout[o][j],  o < NO <= NOP <= 32
-// (wout: the advantage rows over the FC columns and, when q-values are wanted, the value row over the value-hidden
-// columns — block-diagonal).  Workgroup (rb, cb) = rows 16*RT*rb .., hidden columns 128*cb ..; x for its rows is
-// rebuilt by each of the HID / 128 column workgroups (K = D is 8x shorter than K = H) and lives in LDS only.
-struct ActHeadArgs {
-  const float* h; const float* freq; const float* taus;
-  const float* wq; const float* bq; const float* wfc; const float* bfc; const float* wout;
-  float* part; float* tau_out;
+// Workgroup = 16 rows x 128 columns; K = D <= 64 is four MFMA steps per tile: a latency kernel.
+struct ActEmbedArgs {
+  const float* h; const float* freq; const float* taus; const float* wq; const float* bq;
+  float* x; float* tau_out;
   uint64_t seed; const uint64_t* step;
-  int E, N, H, D, HID, NO, NOP;                            // NOP: floats per output-share row (NO rounded up to 8)
+  int E, N, H, D;
 };
 
-template <int RT>
 __global__ void __launch_bounds__(256)
-k_act_head_hidden(ActHeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int XP = a.H + 4, PP = a.D + 4;                     // row pitches: 16-byte aligned, conflict-free operand reads
-  float* xs = lds;                                          // [16 RT][H + 4]
-  float* phi = xs + 16 * RT * XP;                           // [16 RT][D + 4]
-  float* outp = phi + 16 * RT * PP;                         // [4 waves][16 RT][NOP]
-  float* tau_s = outp + 4 * 16 * RT * a.NOP;                // [16 RT]
+k_act_embed(ActEmbedArgs a) {
+  __shared__ __attribute__((aligned(16))) float phi[16 * 68];
+  __shared__ float tau_s[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int64_t R = (int64_t)a.E * a.N;
-  const int64_t row0 = (int64_t)blockIdx.x * (16 * RT);
-  const bool quant = a.freq != nullptr;
-  if (quant) {
-    if (tid < 16 * RT) {
-      int64_t m = row0 + tid; if (m >= R) m = R - 1;
-      float t;
-      if (a.taus) t = a.taus[m];
-      else { uint32_t rn[4]; philox_4x32(a.seed ^ 0x7A5ull, *a.step, (uint32_t)m, rn); t = (float)(rn[0] >> 8) * (1.0f / 16777216.0f); }
-      tau_s[tid] = t;
-      if (a.tau_out && blockIdx.y == 0 && row0 + tid < R) a.tau_out[row0 + tid] = t;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 16 * RT * a.D; idx += 256) {
-      const int rr = idx / a.D, i = idx - rr * a.D;
-      phi[rr * PP + i] = cosf(a.freq[i] * tau_s[rr]);
-    }
-    __syncthreads();
-    // embedding product: 16 RT rows x H columns x K = D <= 64; wave w takes column tiles w, w + 4, ... (H / 64 of them).
-    // The phi rows stay in registers (zeros past D), the weights of tile j + 1 are in flight while tile j multiplies; a
-    // tile index past the end repeats the last tile (same values stored twice: branch-free passes).
-    const int nsD = a.D / 16, ntile = a.H / 64;
-    an_f4 pa[4][RT];
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq)
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-        pa[sq][t] = sq < nsD ? *(const an_f4*)(phi + (16 * t + r) * PP + 16 * sq + 4 * g) : an_f4{0.f, 0.f, 0.f, 0.f};
-    an_f4 qb[2][4];
-#define AN_EMB_LOAD(buf, j)                                                                      \
-  {                                                                                              \
-    const int ct = wave + 4 * ((j) < ntile ? (j) : ntile - 1);                                   \
-    _Pragma("unroll") for (int sq = 0; sq < 4; ++sq)                                             \
-      qb[buf][sq] = *(const an_f4*)(a.wq + (int64_t)(16 * ct + r) * a.D + 16 * (sq < nsD ? sq : 0) + 4 * g); \
-  }
-#define AN_EMB_MUL(buf, j)                                                                       \
-  {                                                                                              \
-    const int ct = wave + 4 * ((j) < ntile ? (j) : ntile - 1);                                   \
-    const int col = 16 * ct + r;                                                                 \
-    an_f4 acc[RT];                                                                               \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t) acc[t] = an_f4{0.f, 0.f, 0.f, 0.f};           \
-    _Pragma("unroll") for (int sq = 0; sq < 4; ++sq)                                             \
-      _Pragma("unroll") for (int t = 0; t < RT; ++t) AN_MFMA4(acc[t], pa[sq][t], qb[buf][sq]);   \
-    const float bs = a.bq[col];                                                                  \
-    _Pragma("unroll") for (int t = 0; t < RT; ++t)                                               \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-        const int rr = 16 * t + 4 * g + i;                                                       \
-        int64_t m = row0 + rr; if (m >= R) m = R - 1;                                            \
-        float v = acc[t][i] + bs;                                                                \
-        v = v > 0.f ? v : 0.f;                                                                   \
-        xs[rr * XP + col] = v * a.h[(m / a.N) * a.H + col];                                      \
-      }                                                                                          \
-  }
-    AN_EMB_LOAD(0, 0)
-    for (int j = 0; j < ntile; j += 2) {
-      AN_EMB_LOAD(1, j + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_EMB_MUL(0, j)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_EMB_LOAD(0, j + 2)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_EMB_MUL(1, j + 1)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef AN_EMB_LOAD
-#undef AN_EMB_MUL
-  } else {
-    for (int idx = tid; idx < 16 * RT * a.H; idx += 256) {
-      const int rr = idx / a.H, c = idx - rr * a.H;
-      int64_t m = row0 + rr; if (m >= R) m = R - 1;
-      xs[rr * XP + c] = a.h[(m / a.N) * a.H + c];
-    }
+  const int R = a.E * a.N, row0 = blockIdx.x * 16, PP = a.D + 4;
+  if (tid < 16) {
+    int m = row0 + tid; if (m >= R) m = R - 1;
+    float t;
+    if (a.taus) t = a.taus[m];
+    else { uint32_t rn[4]; philox_4x32(a.seed ^ 0x7A5ull, *a.step, (uint32_t)m, rn); t = (float)(rn[0] >> 8) * (1.0f / 16777216.0f); }
+    tau_s[tid] = t;
+    if (a.tau_out && blockIdx.y == 0 && row0 + tid < R) a.tau_out[row0 + tid] = t;
   }
   __syncthreads();
-  // hidden layer(s): this workgroup's columns 128 cb + 32 wave + {0, 16}
+  for (int idx = tid; idx < 16 * a.D; idx += 256) {
+    const int rr = idx / a.D, i = idx - rr * a.D;
+    phi[rr * PP + i] = cosf(a.freq[i] * tau_s[rr]);
+  }
+  __syncthreads();
+  const int nsD = a.D / 16;
   const int cbase = blockIdx.y * 128 + 32 * wave;
-  an_f4 acc[RT][2];
+  if (cbase >= a.H) return;
+  const bool on1 = cbase + 16 < a.H;
+  an_f4 acc[2] = {an_f4{0.f, 0.f, 0.f, 0.f}, an_f4{0.f, 0.f, 0.f, 0.f}};
+  an_f4 pa[4], q0[4], q1[4];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) { acc[t][0] = an_f4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = an_f4{0.f, 0.f, 0.f, 0.f}; }
-  const bool on0 = cbase < a.HID, on1 = cbase + 16 < a.HID;
-  if (on0) {
-    const float* w0 = a.wfc + (int64_t)(cbase + r) * a.H + 4 * g;
-    const float* w1 = a.wfc + (int64_t)((on1 ? cbase + 16 : cbase) + r) * a.H + 4 * g;
-    // K = H in passes of 4 steps (H % 64 == 0), weights double-buffered from L2 while the x rows come from LDS
-    const int passes = a.H / 64;
-    an_f4 b0[2][4], b1[2][4];
-#define AN_HID_LOAD(buf, pass)                                                                   \
-  {                                                                                              \
-    const int pp = (pass) < passes ? (pass) : 0;                                                 \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                              \
-      b0[buf][u] = *(const an_f4*)(w0 + 64 * pp + 16 * u);                                       \
-      b1[buf][u] = *(const an_f4*)(w1 + 64 * pp + 16 * u);                                       \
-    }                                                                                            \
+  for (int sq = 0; sq < 4; ++sq) {
+    const int sc = sq < nsD ? sq : 0;
+    pa[sq] = sq < nsD ? *(const an_f4*)(phi + r * PP + 16 * sq + 4 * g) : an_f4{0.f, 0.f, 0.f, 0.f};
+    q0[sq] = *(const an_f4*)(a.wq + (int64_t)(cbase + r) * a.D + 16 * sc + 4 * g);
+    q1[sq] = *(const an_f4*)(a.wq + (int64_t)((on1 ? cbase + 16 : cbase) + r) * a.D + 16 * sc + 4 * g);
   }
-    // (a pass beyond the end multiplies ZERO x rows: the LDS operand is masked, so no VALU op waits on the global loads)
-#define AN_HID_MUL(buf, pass)                                                                    \
-  {                                                                                              \
-    const bool ok = (pass) < passes;                                                             \
-    const int pp = ok ? (pass) : 0;                                                              \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                \
-      _Pragma("unroll") for (int t = 0; t < RT; ++t) {                                           \
-        an_f4 av = *(const an_f4*)(xs + (16 * t + r) * XP + 64 * pp + 16 * u + 4 * g);           \
-        av.x = ok ? av.x : 0.f; av.y = ok ? av.y : 0.f; av.z = ok ? av.z : 0.f; av.w = ok ? av.w : 0.f; \
-        AN_MFMA4(acc[t][0], av, b0[buf][u]);                                                     \
-        AN_MFMA4(acc[t][1], av, b1[buf][u]);                                                     \
-      }                                                                                          \
-  }
-    AN_HID_LOAD(0, 0)
-    for (int p = 0; p < passes; p += 2) {              // straight-line body, as in k_act_lstm
-      AN_HID_LOAD(1, p + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_HID_MUL(0, p)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_HID_LOAD(0, p + 2)
-      __builtin_amdgcn_sched_barrier(0);
-      AN_HID_MUL(1, p + 1)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#undef AN_HID_LOAD
-#undef AN_HID_MUL
-  }
-  // bias + ReLU, then this wave's share of the output layer: out[m][o] += sum_j hid[m][j] * wout[o][j]
-  const int c0 = cbase + r, c1 = cbase + 16 + r;
-  const float bf0 = on0 ? a.bfc[c0] : 0.f, bf1 = on1 ? a.bfc[c1] : 0.f;
+  // rows of this lane's accumulator elements -> env rows of h (one 32-bit division each, ahead of the products)
+  int mrow[4], erow[4];
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
+  for (int i = 0; i < 4; ++i) { int m = row0 + 4 * g + i; mrow[i] = m; if (m >= R) m = R - 1; erow[i] = m / a.N; }
+#pragma unroll
+  for (int sq = 0; sq < 4; ++sq) { AN_MFMA4(acc[0], pa[sq], q0[sq]); AN_MFMA4(acc[1], pa[sq], q1[sq]); }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c == 1 && !on1) break;
+    const int col = cbase + 16 * c + r;
+    const float bs = a.bq[col];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float v0 = acc[t][0][i] + bf0, v1 = acc[t][1][i] + bf1;
-      acc[t][0][i] = on0 ? (v0 > 0.f ? v0 : 0.f) : 0.f;
-      acc[t][1][i] = on1 ? (v1 > 0.f ? v1 : 0.f) : 0.f;
-    }
-  for (int o = 0; o < a.NO; ++o) {
-    const float wo0 = on0 ? a.wout[(int64_t)o * a.HID + c0] : 0.f, wo1 = on1 ? a.wout[(int64_t)o * a.HID + c1] : 0.f;
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float p = acc[t][0][i] * wo0 + acc[t][1][i] * wo1;
-        p = p + __shfl_xor(p, 1); p = p + __shfl_xor(p, 2); p = p + __shfl_xor(p, 4); p = p + __shfl_xor(p, 8);
-        if (r == 0) outp[(wave * 16 * RT + 16 * t + 4 * g + i) * a.NOP + o] = p;
+      if (mrow[i] < R) {
+        float v = acc[c][i] + bs;
+        v = v > 0.f ? v : 0.f;
+        a.x[(int64_t)mrow[i] * a.H + col] = v * a.h[(int64_t)erow[i] * a.H + col];
       }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 16 * RT * a.NOP; idx += 256) {
-    const int rr = idx / a.NOP, o = idx - rr * a.NOP;
-    const int64_t m = row0 + rr;
-    if (m < R && o < a.NO) {
-      const float s = ((outp[(0 * 16 * RT + rr) * a.NOP + o] + outp[(1 * 16 * RT + rr) * a.NOP + o]) +
-                       outp[(2 * 16 * RT + rr) * a.NOP + o]) + outp[(3 * 16 * RT + rr) * a.NOP + o];
-      a.part[((int64_t)blockIdx.y * R + m) * a.NOP + o] = s;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// The acting head over the output shares: out[m][o] = bout[o] + sum_p part[p][m][o]; columns 0 .. A-1 are the
-// advantages, column A (when has_val) the dueling value; rows are NOP floats apart.  Then exactly k_actor_head (acting.hip): V + A - mean_a A
-// (dqn.py:74-87), mean over the N quantile rows (iqn.py actor post-processing), first maximum, epsilon-greedy with
-// one Philox4x32-10 block per (step, env) (epsilon_greedy.py:74-100).  One wave per env.
-__global__ void __launch_bounds__(256)
-k_act_head_select(int E, int N, int A, int P, int NOP, const float* __restrict__ part, const float* __restrict__ bout, int has_val,
-                  const double* __restrict__ eps, const double* __restrict__ expo, double eps_min,
-                  uint64_t rng_seed, const uint64_t* __restrict__ rng_step,
-                  int32_t* __restrict__ actions, float* __restrict__ qvalues) {
-  const int lane = threadIdx.x & 63;
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (e >= E) return;
-  const int64_t R = (int64_t)E * N;
-  auto out = [&](int64_t m, int k) -> float {
-    float v = bout[k];
-    for (int p = 0; p < P; ++p) v = v + part[((int64_t)p * R + m) * NOP + k];
-    return v;
-  };
-  float best = 0.f; int arg = 0;
-  for (int a0 = 0; a0 < A; a0 += 8) {                 // 8 actions per sweep: bounded registers for any A
-    float acc[8];
+// The acting head over the output shares, for ONE env by ONE wave (lane n = quantile row n): out[m][o] = bout[o] +
+// sum_p part[p][m][o]; columns 0 .. A-1 are the advantages, column A (when has_val) the dueling value; rows are NOP = 8 CH
+// floats apart.  Then exactly k_actor_head (acting.hip): V + A - mean_a A (dqn.py:74-87), mean over the N quantile rows
+// (iqn.py actor post-processing), first maximum, epsilon-greedy with one Philox4x32-10 block per (step, env)
+// (epsilon_greedy.py:74-100).  All of a row's shares are fetched as 16-byte loads before anything is added.  (Running
+// this inside k_act_hidden, by the last column block of a row block to arrive, was built and measured: 104.6 vs 103.6 us
+// per vector step at 32 envs — the serial tail costs what the launch saved; profiles/r05_acting_probe.jsonl.)
+struct ActSelectArgs {
+  const float* part; const float* bout;
+  const double* eps; const double* expo; double eps_min;
+  uint64_t rng_seed; const uint64_t* rng_step;
+  int32_t* actions; float* qvalues;
+  int E, N, A, P, has_val;
+};
+
+template <int CH>
+__device__ __forceinline__ void act_select_env(const ActSelectArgs& a, int e, int lane) {
+  constexpr int NOP = 8 * CH;
+  const int R = a.E * a.N;
+  float acc[NOP];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int n = lane; n < N; n += 64) {
-      const int64_t m = (int64_t)e * N + n;
-      float off = 0.f;
-      if (has_val) {                                    // dueling: V + A - mean_a A
-        float mean = 0.f;
-        for (int k = 0; k < A; ++k) mean = mean + out(m, k);
-        off = out(m, A) - mean / (float)A;
+  for (int k = 0; k < NOP; ++k) acc[k] = 0.f;
+  for (int n = lane; n < a.N; n += 64) {
+    const int m = e * a.N + n;
+    float o[NOP];
+#pragma unroll
+    for (int k = 0; k < NOP; ++k) o[k] = k < a.A + (a.has_val ? 1 : 0) ? a.bout[k] : 0.f;
+    for (int p = 0; p < a.P; ++p) {
+      const an_f4* src = (const an_f4*)(a.part + ((int64_t)p * R + m) * NOP);
+#pragma unroll
+      for (int c = 0; c < 2 * CH; ++c) {
+        const an_f4 v = src[c];
+        o[4 * c] = o[4 * c] + v.x; o[4 * c + 1] = o[4 * c + 1] + v.y; o[4 * c + 2] = o[4 * c + 2] + v.z; o[4 * c + 3] = o[4 * c + 3] + v.w;
       }
+    }
+    float off = 0.f;
+    if (a.has_val) {                                    // dueling: V + A - mean_a A
+      float mean = 0.f, v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) if (a0 + k < A) acc[k] = acc[k] + (out(m, a0 + k) + off);
+      for (int k = 0; k < NOP; ++k) { if (k < a.A) mean = mean + o[k]; if (k == a.A) v = o[k]; }
+      off = v - mean / (float)a.A;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float s = acc[k];
-      for (int d = 32; d > 0; d >>= 1) s = s + __shfl_xor(s, d);
-      if (a0 + k < A) {
-        const float q = s / (float)N;
-        if (lane == 0) qvalues[(int64_t)e * A + a0 + k] = q;
-        if ((a0 + k == 0) || q > best) { best = q; arg = a0 + k; }     // first maximum, like argmax
-      }
+    for (int k = 0; k < NOP; ++k) if (k < a.A) acc[k] = acc[k] + (o[k] + off);
+  }
+  float best = 0.f; int arg = 0;
+#pragma unroll
+  for (int k = 0; k < NOP; ++k) {
+    float s = acc[k];
+    for (int d = 32; d > 0; d >>= 1) s = s + __shfl_xor(s, d);
+    if (k < a.A) {
+      const float q = s / (float)a.N;
+      if (lane == 0) a.qvalues[(int64_t)e * a.A + k] = q;
+      if (k == 0 || q > best) { best = q; arg = k; }     // first maximum, like argmax
     }
   }
   if (lane == 0) {
     int act = arg;
-    if (eps) {
-      const double pe = pow(*eps, expo ? expo[e] : 1.0);
-      const float per = (float)(pe > eps_min ? pe : eps_min);
+    if (a.eps) {
+      const double pe = pow(*a.eps, a.expo ? a.expo[e] : 1.0);
+      const float per = (float)(pe > a.eps_min ? pe : a.eps_min);
       uint32_t rn[4];
-      philox_4x32(rng_seed, *rng_step, (uint32_t)e, rn);
+      philox_4x32(a.rng_seed, *a.rng_step, (uint32_t)e, rn);
       const float uf = (float)(rn[0] >> 8) * (1.0f / 16777216.0f);
-      if (uf < per) act = (int)(((uint64_t)rn[1] * (uint64_t)A) >> 32);
+      if (uf < per) act = (int)(((uint64_t)rn[1] * (uint64_t)a.A) >> 32);
     }
-    actions[e] = act;
+    a.actions[e] = act;
   }
 }
 
-template <int RT>
-static int launch_head_hidden(const ActHeadArgs& a, size_t lds, dim3 grid, hipStream_t st) {
-  static bool raised = false;
-  if (!raised) {
-    MIRL_HIP(hipFuncSetAttribute((const void*)k_act_head_hidden<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    raised = true;
+template <int CH>
+__global__ void __launch_bounds__(256)
+k_act_head_select(ActSelectArgs a) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e < a.E) act_select_env<CH>(a, e, threadIdx.x & 63);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The head's hidden layers and its share of the output layer for R rows:
+//   hid[m][j]      = relu(x[m] . wfc[j] + bfc[j]),  j < HID   (last FC layer, then the dueling value-hidden layer:
+//                                                               dqn.py:50-66 — both read the same x)
+//   part[cb][m][o] = sum over hidden columns 64 cb .. 64 cb + 63 of hid[m][j] * wout[o][j],  o < NO <= NOP <= 32
+// (wout: the advantage rows over the FC columns and, when q-values are wanted, the value row over the value-hidden
+// columns — block-diagonal).  x rows are xrow_div rows apart in units of rows: row m reads x[(m / xdiv)] (xdiv = 1 for
+// the quantile product above; without a quantile layer x = h and xdiv = 1 too since N = 1).
+// Workgroup = 2 x 2 waves = (32 WR) rows x 64 columns, wave = (16 WR) x 32; both operands straight from L2 in 16-byte
+// pieces (the four waves share them through the CU's L1), K = H in passes of four 16-wide steps, fully unrolled and
+// double-buffered.  At R = 1024, HID = 1024 (32 envs x 32 quantiles, q-values wanted) WR = 2 gives 256 workgroups =
+// one wave per SIMD with 512 MFMAs each: the f32 matrix pipe's time for this product; at HID = 512 WR = 1 does.
+// The output layer is one more MFMA per wave: the ReLU'd tile goes through LDS into operand layout and meets wout's rows.
+struct ActHiddenArgs {
+  const float* x; const float* wfc; const float* bfc; const float* wout;
+  float* part;
+  int R, H, HID, NO, NOP;
+};
+
+template <int WR, int HP>
+__global__ void __launch_bounds__(256)
+k_act_hidden(ActHiddenArgs a) {
+  __shared__ __attribute__((aligned(16))) float hs[4 * 16 * WR * 36];       // per wave: (16 WR) x 32 hidden tile, pitch 36
+  __shared__ float outs[4 * 16 * WR * 32];                                   // per wave: (16 WR) x NOP output shares
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int row0 = blockIdx.x * (32 * WR) + 16 * WR * wr;
+  const int cbase = blockIdx.y * 64 + 32 * wc;
+  const float* xp[WR];
+#pragma unroll
+  for (int t = 0; t < WR; ++t) { int m = row0 + 16 * t + r; if (m >= a.R) m = a.R - 1; xp[t] = a.x + (int64_t)m * a.H + 4 * g; }
+  const bool on0 = cbase < a.HID, on1 = cbase + 16 < a.HID;
+  const float* wp[2];
+  wp[0] = a.wfc + (int64_t)((on0 ? cbase : 0) + r) * a.H + 4 * g;
+  wp[1] = a.wfc + (int64_t)((on1 ? cbase + 16 : 0) + r) * a.H + 4 * g;
+  an_f4 acc[WR][2];
+#pragma unroll
+  for (int t = 0; t < WR; ++t) { acc[t][0] = an_f4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = an_f4{0.f, 0.f, 0.f, 0.f}; }
+  an_f4 A[2][4][WR], B[2][4][2];
+#define AN_HID_LOAD(buf, pass)                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                \
+    B[buf][u][0] = *(const an_f4*)(wp[0] + 64 * (pass) + 16 * u);                                \
+    B[buf][u][1] = *(const an_f4*)(wp[1] + 64 * (pass) + 16 * u);                                \
+    _Pragma("unroll") for (int t = 0; t < WR; ++t) A[buf][u][t] = *(const an_f4*)(xp[t] + 64 * (pass) + 16 * u); \
   }
-  hipLaunchKernelGGL(k_act_head_hidden<RT>, grid, dim3(256), lds, st, a);
-  return MIRL_OK;
+  AN_HID_LOAD(0, 0)
+#pragma unroll
+  for (int p = 0; p < HP; ++p) {
+    if (p + 1 < HP) { AN_HID_LOAD((p + 1) & 1, p + 1) }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < WR; ++t) {
+        AN_MFMA4(acc[t][0], A[p & 1][u][t], B[p & 1][u][0]);
+        AN_MFMA4(acc[t][1], A[p & 1][u][t], B[p & 1][u][1]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef AN_HID_LOAD
+  // bias + ReLU (columns past HID: zero), tile into LDS in operand layout
+  float* hw = hs + wave * (16 * WR * 36);
+  const float bf0 = on0 ? a.bfc[cbase + r] : 0.f, bf1 = on1 ? a.bfc[cbase + 16 + r] : 0.f;
+#pragma unroll
+  for (int t = 0; t < WR; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v0 = acc[t][0][i] + bf0, v1 = acc[t][1][i] + bf1;
+      hw[(16 * t + 4 * g + i) * 36 + r] = on0 ? (v0 > 0.f ? v0 : 0.f) : 0.f;
+      hw[(16 * t + 4 * g + i) * 36 + 16 + r] = on1 ? (v1 > 0.f ? v1 : 0.f) : 0.f;
+    }
+  // this wave's share of the output layer: out[m][o] += sum over its 32 hidden columns of hid[m][j] * wout[o][j]
+  // (the same wave wrote hw: LDS operations of one wave execute in order)
+  float* ow = outs + wave * (16 * WR * 32);
+  for (int ot = 0; ot < (a.NOP + 15) / 16; ++ot) {
+    const int o = 16 * ot + r;
+    an_f4 w0 = an_f4{0.f, 0.f, 0.f, 0.f}, w1 = an_f4{0.f, 0.f, 0.f, 0.f};
+    if (o < a.NO) {
+      if (on0) w0 = *(const an_f4*)(a.wout + (int64_t)o * a.HID + cbase + 4 * g);
+      if (on1) w1 = *(const an_f4*)(a.wout + (int64_t)o * a.HID + cbase + 16 + 4 * g);
+    }
+#pragma unroll
+    for (int t = 0; t < WR; ++t) {
+      an_f4 oa = an_f4{0.f, 0.f, 0.f, 0.f};
+      const an_f4 h0 = *(const an_f4*)(hw + (16 * t + r) * 36 + 4 * g), h1 = *(const an_f4*)(hw + (16 * t + r) * 36 + 16 + 4 * g);
+      AN_MFMA4(oa, h0, w0);
+      AN_MFMA4(oa, h1, w1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (o < a.NOP) ow[(16 * t + 4 * g + i) * 32 + o] = oa[i];
+    }
+  }
+  __syncthreads();
+  // the two column halves of a row half add up; one share per (column block, row, output)
+  for (int idx = tid; idx < 32 * WR * a.NOP; idx += 256) {
+    const int rr = idx / a.NOP, o = idx - rr * a.NOP;
+    const int half = rr / (16 * WR), lr = rr - half * (16 * WR);
+    const int m = blockIdx.x * (32 * WR) + rr;
+    if (m < a.R && o < a.NO)
+      a.part[((int64_t)blockIdx.y * a.R + m) * a.NOP + o] = outs[((2 * half) * 16 * WR + lr) * 32 + o] + outs[((2 * half + 1) * 16 * WR + lr) * 32 + o];
+  }
 }
 
 }  // namespace mirl
@@ -508,74 +544,149 @@ extern "C" int mirl_act_conv_fwd(int32_t layer, int64_t frames, int32_t Hi, int3
 }
 
 extern "C" int mirl_act_lstm_supported(int32_t E, int32_t H, int32_t K) {
-  return E > 0 && E <= 64 && H > 0 && (H % 4) == 0 && K > 0 && (K % 16) == 0;
+  return E > 0 && E <= 64 && H > 0 && (H % 8) == 0 && K > 0 && (K % 16) == 0;
+}
+
+// K slices per column block: (H / 8) x KB workgroups ~ one per CU
+static int act_lstm_kb(int H, int K) {
+  int kb = 256 / (H / 8);
+  if (kb > 16) kb = 16;
+  if (kb > K / 16 / 8) kb = K / 16 / 8;
+  return kb < 1 ? 1 : kb;
+}
+
+extern "C" int mirl_act_lstm_workspace_bytes(int32_t E, int32_t H, int32_t K, int64_t* bytes) {
+  if (!bytes || !mirl_act_lstm_supported(E, H, K)) return fail(MIRL_ERR_ARG, "bad act_lstm_workspace_bytes arguments");
+  const int kb = act_lstm_kb(H, K);
+  *bytes = (int64_t)sizeof(float) * kb * (H / 8) * E * 32 + (int64_t)sizeof(unsigned) * (H / 8) + 256;
+  return MIRL_OK;
 }
 
 extern "C" int mirl_act_lstm_fwd(int32_t E, int32_t H, int32_t K, const float* xh, int64_t xh_pitch, const float* w, const float* bias,
-                                 const float* c_in, float* h_out, float* c_out, void* stream) {
-  if (!xh || !w || !bias || !c_in || !h_out || !c_out) return fail(MIRL_ERR_ARG, "bad act_lstm_fwd arguments");
-  if (!mirl_act_lstm_supported(E, H, K)) return fail(MIRL_ERR_ARG, "act_lstm_fwd: E <= 64, H % 4 == 0 and K % 16 == 0 are required");
-  if (xh_pitch < K || (xh_pitch % 4) || !an_al16(xh) || !an_al16(w)) return fail(MIRL_ERR_ARG, "act_lstm_fwd: 16-byte aligned rows are required");
+                                 const float* c_in, float* h_out, float* c_out, void* workspace, void* stream) {
+  if (!xh || !w || !bias || !c_in || !h_out || !c_out || !workspace) return fail(MIRL_ERR_ARG, "bad act_lstm_fwd arguments");
+  if (!mirl_act_lstm_supported(E, H, K)) return fail(MIRL_ERR_ARG, "act_lstm_fwd: E <= 64, H % 8 == 0 and K % 16 == 0 are required");
+  if (xh_pitch < K || (xh_pitch % 4) || !an_al16(xh) || !an_al16(w) || !an_al16(workspace)) return fail(MIRL_ERR_ARG, "act_lstm_fwd: 16-byte aligned rows are required");
   ActLstmArgs a;
   a.xh = xh; a.xh_pitch = xh_pitch; a.w = w; a.bias = bias; a.c_in = c_in; a.h_out = h_out; a.c_out = c_out;
   a.E = E; a.H = H; a.K = K;
+  a.KB = act_lstm_kb(H, K);
+  a.SPB = (K / 16 + a.KB - 1) / a.KB;
+  a.arrived = (unsigned*)workspace;                          // zero on first use (the caller allocates zeroed memory)
+  a.shares = (float*)((char*)workspace + ((sizeof(unsigned) * (H / 8) + 255) / 256) * 256);
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("k_act_lstm", 4.0 * (4.0 * H * K + (double)E * K + 3.0 * E * H), st, 2.0 * E * 4.0 * H * K);
-  const dim3 grid(H / 4);
-  if (E <= 16) hipLaunchKernelGGL(k_act_lstm<1>, grid, dim3(512), 0, st, a);
-  else if (E <= 32) hipLaunchKernelGGL(k_act_lstm<2>, grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(k_act_lstm<4>, grid, dim3(512), 0, st, a);
+  const dim3 grid(H / 8, a.KB);
+  const int rt = E <= 16 ? 1 : (E <= 32 ? 2 : 4);
+  const size_t lds = sizeof(float) * ((size_t)8 * rt * 512 + (a.KB == 1 ? (size_t)E * 32 : 0));
+  if (rt == 1) hipLaunchKernelGGL(k_act_lstm<1>, grid, dim3(512), lds, st, a);
+  else if (rt == 2) hipLaunchKernelGGL(k_act_lstm<2>, grid, dim3(512), lds, st, a);
+  else {
+    static bool raised = false;
+    if (!raised) { MIRL_HIP(hipFuncSetAttribute((const void*)k_act_lstm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); raised = true; }
+    hipLaunchKernelGGL(k_act_lstm<4>, grid, dim3(512), lds, st, a);
+  }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
 
 extern "C" int mirl_act_head_supported(int32_t E, int32_t N, int32_t H, int32_t D, int32_t HID, int32_t NO) {
-  if (E <= 0 || N <= 0 || H <= 0 || HID <= 0 || NO <= 0 || NO > 32) return 0;
-  if ((H % 64) || (HID % 16) || (D && (D % 16)) || D > 64 || H > 1024) return 0;
-  return 1;
+  if (E <= 0 || N <= 0 || H <= 0 || HID <= 0 || NO <= 0 || NO > 32 || (int64_t)E * N > (1 << 24)) return 0;
+  if ((HID % 16) || (D && (D % 16)) || D > 64) return 0;
+  return H == 64 || H == 128 || H == 256 || H == 512 || H == 1024;
 }
 
 extern "C" int mirl_act_head_parts(int32_t HID, int32_t NO, int32_t* parts, int32_t* pitch) {
   if (!parts || !pitch || HID <= 0 || NO <= 0 || NO > 32) return fail(MIRL_ERR_ARG, "bad act_head_parts arguments");
-  *parts = (HID + 127) / 128;
+  *parts = (HID + 63) / 64;
   *pitch = (NO + 7) / 8 * 8;
   return MIRL_OK;
 }
 
-extern "C" int mirl_act_head_hidden(int32_t E, int32_t N, int32_t H, int32_t D, int32_t HID, int32_t NO, const float* h,
-                                    const float* freq, const float* taus, uint64_t seed, const uint64_t* step, const float* wq,
-                                    const float* bq, const float* wfc, const float* bfc, const float* wout, float* part,
-                                    float* tau_out, void* stream) {
-  if (!h || !wfc || !bfc || !wout || !part) return fail(MIRL_ERR_ARG, "bad act_head_hidden arguments");
-  if (!mirl_act_head_supported(E, N, H, freq ? D : 0, HID, NO)) return fail(MIRL_ERR_ARG, "act_head_hidden: unsupported shape (H % 64, D in {16, 32, 48, 64}, HID % 16; NO <= 32)");
-  if (freq && (!wq || !bq || D <= 0 || (!taus && !step))) return fail(MIRL_ERR_ARG, "act_head_hidden: a quantile layer needs wq / bq and taus or a step word");
-  if (!an_al16(h) || !an_al16(wfc) || (freq && !an_al16(wq)) || !an_al16(part)) return fail(MIRL_ERR_ARG, "act_head_hidden: 16-byte aligned operands are required");
-  ActHeadArgs a;
-  a.h = h; a.freq = freq; a.taus = taus; a.wq = wq; a.bq = bq; a.wfc = wfc; a.bfc = bfc; a.wout = wout; a.part = part;
-  a.tau_out = tau_out; a.seed = seed; a.step = step;
-  a.E = E; a.N = N; a.H = H; a.D = freq ? D : 16; a.HID = HID; a.NO = NO; a.NOP = (NO + 7) / 8 * 8;
-  const int64_t R = (int64_t)E * N;
-  const int rt = R > 2048 ? 2 : 1;
-  const size_t lds = sizeof(float) * ((size_t)16 * rt * (H + 4) + (size_t)16 * rt * (a.D + 4) + (size_t)4 * 16 * rt * a.NOP + 16 * rt);
-  const dim3 grid((unsigned)((R + 16 * rt - 1) / (16 * rt)), (unsigned)((HID + 127) / 128));
+extern "C" int mirl_act_embed(int32_t E, int32_t N, int32_t H, int32_t D, const float* h, const float* freq, const float* taus,
+                              uint64_t seed, const uint64_t* step, const float* wq, const float* bq, float* x, float* tau_out, void* stream) {
+  if (E <= 0 || N <= 0 || H <= 0 || (H % 16) || D <= 0 || (D % 16) || D > 64 || !h || !freq || !wq || !bq || !x || (!taus && !step) ||
+      (int64_t)E * N > (1 << 24) || !an_al16(wq))
+    return fail(MIRL_ERR_ARG, "bad act_embed arguments (H % 16, D in {16, 32, 48, 64}, taus or a step word)");
+  ActEmbedArgs a;
+  a.h = h; a.freq = freq; a.taus = taus; a.wq = wq; a.bq = bq; a.x = x; a.tau_out = tau_out; a.seed = seed; a.step = step;
+  a.E = E; a.N = N; a.H = H; a.D = D;
+  const int R = E * N;
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps("k_act_head_hidden", 4.0 * ((double)E * H + (double)HID * H + (freq ? (double)H * D : 0.0) + (double)a.NOP * R * grid.y), st,
-               2.0 * (double)R * ((double)HID * H + (freq ? (double)grid.y * H * D : 0.0)));
-  int rc = rt == 1 ? launch_head_hidden<1>(a, lds, grid, st) : launch_head_hidden<2>(a, lds, grid, st);
-  if (rc) return rc;
+  ProfScope ps("k_act_embed", 4.0 * ((double)R * H + (double)E * H + (double)H * D), st, 2.0 * (double)R * H * D);
+  hipLaunchKernelGGL(k_act_embed, dim3((R + 15) / 16, (H + 127) / 128), dim3(256), 0, st, a);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
 
-extern "C" int mirl_act_head_select(int32_t E, int32_t N, int32_t A, int32_t parts, int32_t pitch, const float* part, const float* bout, int32_t has_val,
-                                    const double* eps, const double* expo, double eps_min, uint64_t rng_seed, const uint64_t* rng_step,
-                                    int32_t* actions, float* qvalues, void* stream) {
-  if (E <= 0 || N <= 0 || A <= 0 || A + (has_val ? 1 : 0) > pitch || parts <= 0 || !part || !bout || !actions || !qvalues || (eps && !rng_step))
+template <int WR>
+static void launch_hidden(const ActHiddenArgs& a, dim3 grid, hipStream_t st) {
+  switch (a.H / 64) {
+    case 1: hipLaunchKernelGGL((k_act_hidden<WR, 1>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_act_hidden<WR, 2>), grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_act_hidden<WR, 4>), grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((k_act_hidden<WR, 8>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_act_hidden<WR, 16>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+static int fill_select(ActSelectArgs& q, int32_t E, int32_t N, int32_t A, int32_t parts, int32_t pitch, const float* part, const float* bout,
+                       int32_t has_val, const double* eps, const double* expo, double eps_min, uint64_t rng_seed, const uint64_t* rng_step,
+                       int32_t* actions, float* qvalues) {
+  if (E <= 0 || N <= 0 || A <= 0 || A + (has_val ? 1 : 0) > pitch || pitch > 32 || (pitch % 8) || parts <= 0 || !part || !bout || !actions ||
+      !qvalues || (eps && !rng_step) || !an_al16(part) || (int64_t)parts * E * N * pitch * 4 >= (1LL << 31))
     return fail(MIRL_ERR_ARG, "bad act_head_select arguments");
+  q.part = part; q.bout = bout; q.eps = eps; q.expo = expo; q.eps_min = eps_min; q.rng_seed = rng_seed; q.rng_step = rng_step;
+  q.actions = actions; q.qvalues = qvalues; q.E = E; q.N = N; q.A = A; q.P = parts; q.has_val = has_val ? 1 : 0;
+  return MIRL_OK;
+}
+
+static int hidden_wr(int64_t R, int cbs) {
+  // 32-row workgroups while they are what fills the chip, 64-row ones (half the weight traffic per product) beyond
+  return ((R + 31) / 32 * cbs > 384) ? 2 : 1;
+}
+
+static int launch_hidden_any(ActHiddenArgs& a, hipStream_t st) {
+  const int cbs = (a.HID + 63) / 64;
+  const int wr = hidden_wr(a.R, cbs);
+  const dim3 grid((unsigned)((a.R + 32 * wr - 1) / (32 * wr)), (unsigned)cbs);
+  ProfScope ps("k_act_hidden", 4.0 * ((double)a.R * a.H + (double)a.HID * a.H + (double)a.NOP * a.R * cbs), st, 2.0 * (double)a.R * a.HID * a.H);
+  if (wr == 1) launch_hidden<1>(a, grid, st); else launch_hidden<2>(a, grid, st);
+  MIRL_LAUNCH_CHECK();
+  return MIRL_OK;
+}
+
+static int fill_hidden(ActHiddenArgs& a, int32_t R, int32_t H, int32_t HID, int32_t NO, const float* x, const float* wfc, const float* bfc,
+                       const float* wout, float* part) {
+  if (!x || !wfc || !bfc || !wout || !part || R <= 0) return fail(MIRL_ERR_ARG, "bad act_head_hidden arguments");
+  if (!mirl_act_head_supported(R, 1, H, 0, HID, NO)) return fail(MIRL_ERR_ARG, "act_head_hidden: unsupported shape (H in {64 .. 1024} a power of two, HID % 16; NO <= 32)");
+  if (!an_al16(x) || !an_al16(wfc) || !an_al16(wout) || !an_al16(part) || (HID % 4)) return fail(MIRL_ERR_ARG, "act_head_hidden: 16-byte aligned operands are required");
+  a.x = x; a.wfc = wfc; a.bfc = bfc; a.wout = wout; a.part = part;
+  a.R = R; a.H = H; a.HID = HID; a.NO = NO; a.NOP = (NO + 7) / 8 * 8;
+  return MIRL_OK;
+}
+
+extern "C" int mirl_act_head_hidden(int32_t R, int32_t H, int32_t HID, int32_t NO, const float* x, const float* wfc, const float* bfc,
+                                    const float* wout, float* part, void* stream) {
+  ActHiddenArgs a;
+  int rc = fill_hidden(a, R, H, HID, NO, x, wfc, bfc, wout, part); if (rc) return rc;
+  return launch_hidden_any(a, (hipStream_t)stream);
+}
+
+extern "C" int mirl_act_head_select(int32_t E, int32_t N, int32_t A, int32_t parts, int32_t pitch, const float* part, const float* bout,
+                                    int32_t has_val, const double* eps, const double* expo, double eps_min, uint64_t rng_seed,
+                                    const uint64_t* rng_step, int32_t* actions, float* qvalues, void* stream) {
+  ActSelectArgs q;
+  int rc = fill_select(q, E, N, A, parts, pitch, part, bout, has_val, eps, expo, eps_min, rng_seed, rng_step, actions, qvalues); if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("k_act_head_select", 0.0, st);
-  hipLaunchKernelGGL(k_act_head_select, dim3((E + 3) / 4), dim3(256), 0, st, (int)E, (int)N, (int)A, (int)parts, (int)pitch, part, bout, (int)has_val,
-                     eps, expo, eps_min, rng_seed, rng_step, actions, qvalues);
+  const dim3 grid((E + 3) / 4);
+  switch (pitch / 8) {
+    case 1: hipLaunchKernelGGL(k_act_head_select<1>, grid, dim3(256), 0, st, q); break;
+    case 2: hipLaunchKernelGGL(k_act_head_select<2>, grid, dim3(256), 0, st, q); break;
+    case 3: hipLaunchKernelGGL(k_act_head_select<3>, grid, dim3(256), 0, st, q); break;
+    default: hipLaunchKernelGGL(k_act_head_select<4>, grid, dim3(256), 0, st, q); break;
+  }
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }

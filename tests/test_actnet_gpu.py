@@ -55,7 +55,7 @@ def test_conv_shape_gate():
         assert lib.mirl_act_conv_supported(*bad) == 0, bad
 
 
-@pytest.mark.parametrize("E,H,Fin", [(16, 64, 3136), (32, 512, 3136), (7, 64, 48), (33, 64, 3136), (64, 512, 3136), (48, 128, 16)])
+@pytest.mark.parametrize("E,H,Fin", [(16, 64, 3136), (32, 512, 3136), (7, 64, 48), (33, 64, 3136), (64, 512, 3136), (48, 128, 16), (32, 8, 8)])
 def test_lstm_step(E, H, Fin):
     from rltime_amd._lib import lib, check
     torch.manual_seed(E + H)
@@ -67,7 +67,12 @@ def test_lstm_step(E, H, Fin):
     h = torch.empty(E, H, device="cuda")
     c = torch.empty(E, H, device="cuda")
     assert lib.mirl_act_lstm_supported(E, H, K) == 1
-    check(lib.mirl_act_lstm_fwd(E, H, K, _p(xh), K + 4, _p(w), _p(bias), _p(c_in), _p(h), _p(c), _st()), "mirl_act_lstm_fwd")
+    need = C.c_int64()
+    check(lib.mirl_act_lstm_workspace_bytes(E, H, K, C.byref(need)))
+    ws = torch.zeros((need.value + 3) // 4, dtype=torch.int32, device="cuda")
+    for _ in range(3):                                      # the launch restores its arrival counters: repeatable as is
+        h.fill_(float("nan"))
+        check(lib.mirl_act_lstm_fwd(E, H, K, _p(xh), K + 4, _p(w), _p(bias), _p(c_in), _p(h), _p(c), _p(ws), _st()), "mirl_act_lstm_fwd")
 
     def cell(dt):
         g = F.linear(xh[:, :K].to(dt), w.to(dt), bias.to(dt))
@@ -98,7 +103,7 @@ def _head_ref(dt, h, taus, freq, wq, bq, wfc, bfc, wout, bout, N, A, has_val):
 @pytest.mark.parametrize("E,N,H,D,HID,A,has_val", [
     (32, 32, 512, 64, 1024, 6, True), (32, 32, 512, 64, 512, 6, False), (16, 8, 64, 16, 128, 6, True), (16, 8, 64, 16, 64, 6, False),
     (32, 1, 64, 0, 128, 6, True), (256, 1, 512, 0, 1024, 18, True), (3, 5, 64, 32, 80, 4, False), (256, 32, 512, 64, 512, 6, False),
-    (5, 7, 128, 48, 272, 18, True)])
+    (5, 7, 128, 48, 272, 18, True), (64, 32, 512, 64, 1024, 6, True), (16, 4, 1024, 16, 64, 30, True)])
 def test_head(E, N, H, D, HID, A, has_val):
     """hidden layers + output shares + selection against the float64 head; quantile fractions handed in."""
     from rltime_amd._lib import lib, check
@@ -117,11 +122,14 @@ def test_head(E, N, H, D, HID, A, has_val):
     bout = torch.randn(NO, device=dev) * 0.1
     parts, pitch = C.c_int32(), C.c_int32()
     check(lib.mirl_act_head_parts(HID, NO, C.byref(parts), C.byref(pitch)))
-    assert parts.value == (HID + 127) // 128 and pitch.value >= NO and pitch.value % 8 == 0
+    assert parts.value == (HID + 63) // 64 and pitch.value >= NO and pitch.value % 8 == 0
     part = torch.full((parts.value * E * N * pitch.value,), float("nan"), device=dev)
     step = torch.tensor([5], dtype=torch.int64, device=dev)
-    check(lib.mirl_act_head_hidden(E, N, H, D, HID, NO, _p(h), _p(freq), _p(taus), 99, _p(step), _p(wq), _p(bq), _p(wfc), _p(bfc),
-                                   _p(wout), _p(part), None, _st()), "mirl_act_head_hidden")
+    x = h
+    if D:
+        x = torch.full((E * N, H), float("nan"), device=dev)
+        check(lib.mirl_act_embed(E, N, H, D, _p(h), _p(freq), _p(taus), 99, _p(step), _p(wq), _p(bq), _p(x), None, _st()), "mirl_act_embed")
+    check(lib.mirl_act_head_hidden(E * N, H, HID, NO, _p(x), _p(wfc), _p(bfc), _p(wout), _p(part), _st()), "mirl_act_head_hidden")
     actions = torch.full((E,), -1, dtype=torch.int32, device=dev)
     q = torch.empty(E, A, device=dev)
     check(lib.mirl_act_head_select(E, N, A, parts.value, pitch.value, _p(part), _p(bout), 1 if has_val else 0, None, None, 0.0, 99,
@@ -152,17 +160,17 @@ def test_head_draws_its_fractions_like_cos_embed_rng():
     check(lib.mirl_act_head_parts(HID, A, C.byref(parts), C.byref(pitch)))
     part = torch.zeros(parts.value * E * N * pitch.value, device=dev)
     tau_out = torch.empty(E * N, device=dev)
-    check(lib.mirl_act_head_hidden(E, N, H, D, HID, A, _p(h), _p(freq), None, 1234, _p(step), _p(wq), _p(bq), _p(wfc), _p(bfc), _p(wout),
-                                   _p(part), _p(tau_out), _st()))
+    x = torch.empty(E * N, H, device=dev)
+    check(lib.mirl_act_embed(E, N, H, D, _p(h), _p(freq), None, 1234, _p(step), _p(wq), _p(bq), _p(x), _p(tau_out), _st()))
     phi = torch.empty((E * N, D), device=dev)
     tau_ref = torch.empty(E * N, device=dev)
     check(lib.mirl_cos_embed_rng(E * N, D, 1234, _p(step), _p(freq), _p(phi), _p(tau_ref), _st()))
     assert torch.equal(tau_out, tau_ref)
-    # the same head from the handed-in fractions: identical shares
-    part2 = torch.zeros_like(part)
-    check(lib.mirl_act_head_hidden(E, N, H, D, HID, A, _p(h), _p(freq), _p(tau_ref), 1234, _p(step), _p(wq), _p(bq), _p(wfc), _p(bfc),
-                                   _p(wout), _p(part2), None, _st()))
-    assert torch.equal(part, part2)
+    # the same product from the handed-in fractions: identical rows
+    x2 = torch.empty_like(x)
+    check(lib.mirl_act_embed(E, N, H, D, _p(h), _p(freq), _p(tau_ref), 1234, _p(step), _p(wq), _p(bq), _p(x2), None, _st()))
+    assert torch.equal(x, x2)
+    check(lib.mirl_act_head_hidden(E * N, H, HID, A, _p(x), _p(wfc), _p(bfc), _p(wout), _p(part), _st()))
     # epsilon-greedy: same draws as the library-path head on the same (seed, step)
     eps = torch.tensor(0.5, dtype=torch.float64, device=dev)
     acts = torch.empty(E, dtype=torch.int32, device=dev)
@@ -183,6 +191,43 @@ def test_shape_gates_are_host_logic():
     from rltime_amd._lib import lib
     assert lib.mirl_act_head_supported(32, 32, 512, 64, 1024, 7) == 1
     for bad in [(32, 32, 500, 64, 1024, 7), (32, 32, 512, 80, 1024, 7), (32, 32, 512, 64, 1000, 7), (32, 32, 512, 64, 1024, 33),
-                (0, 32, 512, 64, 1024, 7)]:
+                (0, 32, 512, 64, 1024, 7), (32, 32, 192, 64, 1024, 7)]:
         assert lib.mirl_act_head_supported(*bad) == 0, bad
-    assert lib.mirl_act_lstm_supported(64, 512, 3648) == 1 and lib.mirl_act_lstm_supported(64, 510, 3648) == 0
+    assert lib.mirl_act_lstm_supported(64, 512, 3648) == 1 and lib.mirl_act_lstm_supported(64, 508, 3648) == 0
+
+
+def test_env_step_and_pre_step_in_one_launch():
+    """mirl_synth_env_step_pre == mirl_synth_env_step followed by mirl_actor_pre on its outputs (csrc/acting.hip)."""
+    from rltime_amd._lib import lib, check
+    from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
+    E, H, A, Fq = 48, 64, 6, 128
+    dev = "cuda"
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(4)
+        env = SyntheticAtariVecEnv(E, frame_shape=(4, 84, 84), n_actions=A, seed=9, done_prob=0.2)
+        obs = torch.zeros((E, 4, 84, 84), dtype=torch.uint8, device=dev)
+        rew, don = torch.zeros(E, device=dev), torch.zeros(E, dtype=torch.uint8, device=dev)
+        h, c = torch.randn(E, H, device=dev), torch.randn(E, H, device=dev)
+        actions = torch.randint(0, A, (E,), dtype=torch.int32, device=dev)
+        xh = torch.zeros(E, Fq + H, device=dev)
+        c_in, pack, init = torch.zeros(E, H, device=dev), torch.zeros(E, 2 * H, device=dev), torch.zeros(E, device=dev)
+        r_out, d_out = torch.zeros(E, device=dev), torch.zeros(E, dtype=torch.uint8, device=dev)
+        ep_r, ep_l = torch.zeros(E, device=dev), torch.zeros(E, dtype=torch.int32, device=dev)
+        o_r, o_l = torch.zeros(E, device=dev), torch.zeros(E, dtype=torch.int32, device=dev)
+        counts = torch.zeros(A, dtype=torch.int32, device=dev)
+        rng = torch.zeros(1, dtype=torch.int64, device=dev)
+        pre = (H, A, _p(actions), _p(h), _p(c), C.c_void_p(xh.data_ptr() + 4 * Fq), Fq + H, _p(c_in), _p(pack), _p(init), _p(r_out), _p(d_out),
+               1, _p(ep_r), _p(ep_l), _p(o_r), _p(o_l), _p(counts), _p(rng), 0xFFFFFFFFFFFFFFFF, _st())
+        for _ in range(5):
+            if fused:
+                check(lib.mirl_synth_env_step_pre(*env.step_into_args(obs, rew, don), *pre), "mirl_synth_env_step_pre")
+                env.advance_host()
+            else:
+                env.step_into(obs, rew, don)
+                check(lib.mirl_actor_pre(E, pre[0], pre[1], _p(rew), _p(don), *pre[2:]), "mirl_actor_pre")
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (obs, rew, don, xh, c_in, pack, init, r_out, d_out, ep_r, ep_l, o_r, o_l, counts, rng)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[0][-1].item()) == 5 and int(outs[0][2].sum()) > 0
