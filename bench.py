@@ -460,7 +460,9 @@ def copy_peak(device, stream_ptr_fn):
     a = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 256)
     b = torch.empty_like(a)
     best = None
-    for nt in (0, 1):
+    names = {0: "cached, grid-stride", 1: "non-temporal, one 4-vector chunk per lane", 4: "4 vectors per lane, cached loads + non-temporal stores",
+             6: "2 vectors per lane, non-temporal loads + stores"}
+    for nt in (0, 1, 4, 6):
         f = lambda: check(lib.mirl_copy_bytes_ex(C.c_void_p(b.data_ptr()), C.c_void_p(a.data_ptr()), n, nt, stream_ptr_fn()))  # noqa: E731
         for _ in range(3):
             f()
@@ -472,7 +474,7 @@ def copy_peak(device, stream_ptr_fn):
         torch.cuda.synchronize()
         rate = 2.0 * n / (e0.elapsed_time(e1) / 10) / 1e6
         if best is None or rate > best[0]:
-            best = (rate, "non-temporal, one chunk per lane" if nt else "cached, grid-stride")
+            best = (rate, names[nt])
     del a, b
     return best
 
@@ -538,6 +540,28 @@ def kernel_table(table, profile_steps):
     return kernels, ideal_ms
 
 
+def kernel_family(name):
+    """Device kernels that are not this library's, by what they are (the named list of the step's unpriced time)."""
+    n = name
+    if n.startswith("mirl::") or "mirl::" in n.split("(")[0]:
+        return None
+    if "copyBuffer" in n or "Memcpy" in n or "memcpy" in n.lower():
+        return "runtime copies (hipMemcpyAsync D2D / H2D: plan uploads, staging)"
+    if "fillBuffer" in n or "Memset" in n or "memset" in n.lower():
+        return "runtime fills (hipMemsetAsync)"
+    if n.startswith("Cijk_") or "gemm" in n.lower() and "igemm" not in n.lower():
+        return "hipBLASLt / rocBLAS GEMMs (acting batch, per-step LSTM backward products, small layers)"
+    if "igemm" in n or "SubTensorOp" in n or "miopen" in n.lower() or "naive_conv" in n:
+        return "MIOpen convolutions (+ their fills)"
+    if "multi_tensor" in n or "FusedAdam" in n or "adam" in n.lower():
+        return "optimizer (multi-tensor Adam, foreach scale / norm)"
+    if "reduce_kernel" in n or "Norm" in n:
+        return "PyTorch reductions (grad-norm, sums)"
+    if "elementwise" in n or "vectorized" in n or "CatArray" in n or "distribution" in n or "index" in n.lower():
+        return "PyTorch elementwise / copy / cat / rand kernels"
+    return "other"
+
+
 def library_roofline(one_step):
     """One extra step under the torch profiler: the LIBRARY contractions of the step — hipBLASLt / rocBLAS GEMMs and MIOpen
     convolutions called through aten — with their flop (aten's own count for mm / addmm / conv2d; 2 x MACs per requested
@@ -567,8 +591,21 @@ def library_roofline(one_step):
             dev_ms += t
             if "mm" in ev.key or "convolution" in ev.key or "conv2d" in ev.key:
                 lib_ms += t
+        # every DEVICE kernel of the step that is not librltime_hip's, by family: the part of the step no roofline prices
+        families = {}
+        for ev in prof.key_averages():
+            if "CPU" in str(getattr(ev, "device_type", "CPU")):
+                continue
+            fam = kernel_family(ev.key)
+            if fam is None:
+                continue
+            t = getattr(ev, "device_time_total", getattr(ev, "cuda_time_total", 0)) / 1e3
+            row = families.setdefault(fam, {"ms": 0.0, "launches": 0})
+            row["ms"] += t
+            row["launches"] += int(ev.count)
         return {"library_flop_per_step": flop, "library_contraction_ms": lib_ms, "aten_device_ms": dev_ms,
-                "library_roofline_ms": flop / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3}
+                "library_roofline_ms": flop / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                "other_kernels_by_family": {k: {"ms": round(v["ms"], 3), "launches": v["launches"]} for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}}
     except Exception as e:            # evidence, not the measurement: never sink the line
         print("library roofline pass failed: %r" % (e,), file=sys.stderr)
         return None
@@ -843,8 +880,8 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "measured_copy_peak_GBps": measured_peak[0] if measured_peak else None,
                 "frac_of_measured_copy_peak": (achieved / measured_peak[0]) if (achieved and measured_peak) else None,
-                "measured_copy_peak_how": "read + written bytes of a plain 16 B/lane device copy (mirl_copy_bytes_ex, the better of "
-                                          "two variants: %s) over the gather's 3.5 GB on this box, after the timed region; the "
+                "measured_copy_peak_how": "read + written bytes of a plain 16 B/lane device copy (mirl_copy_bytes_ex, the best of "
+                                          "four variants: %s) over the gather's 3.5 GB on this box, after the timed region; the "
                                           "gather itself is such a copy with indexed rows; `peak` is the HBM3E spec figure"
                                           % (measured_peak[1] if measured_peak else "-"),
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": avg_ms, "launches": launches,
@@ -874,6 +911,9 @@ def main():
                 "library_contractions_measured_ms": round(lr["library_contraction_ms"], 3) if lr else None,
                 "library_flop_per_step": lr["library_flop_per_step"] if lr else None,
                 "all_aten_kernels_measured_ms": round(lr["aten_device_ms"], 3) if lr else None,
+                # the step's time that carries no roofline at all, by kernel family (one step under torch.profiler; the acting
+                # rollout's kernels run from a captured graph and appear under their own names)
+                "unpriced_by_family": lr.get("other_kernels_by_family") if lr else None,
                 "how": "sum over the step's kernels of max(algorithmic bytes / 8 TB/s, flop / pipe peak): librltime_hip kernels from "
                        "roofline_all (latency-bound ones count 0), hipBLASLt / MIOpen contractions from one extra step under "
                        "torch.profiler(with_flops) priced at the dense f32 MFMA peak (157.3 TFLOP/s); elementwise / copy kernels of "

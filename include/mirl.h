@@ -356,14 +356,6 @@ int mirl_loss_iqn(int64_t M, int32_t N, int32_t Nt, int32_t A, const float* z,
  * i.e. the masked inputs of the following step.  h_out / c_out may be NULL.     */
 int mirl_lstm_cell_fwd(int32_t B, int32_t H, float* gates, const float* c_in, const float* keep_next,
                        float* h_out, float* c_out, float* h_next, float* c_next, void* stream);
-/* One whole LSTM step in one launch: gates [B][4H] holds the input projection (+ biases)
- * on entry; the recurrent contribution h_in [B][H] x w_hh [4H][H]^T is accumulated on
- * f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32) and the cell applied in the epilogue —
- * same outputs as mirl_lstm_cell_fwd after `gates += h_in @ w_hh^T`.  B, H multiples
- * of 32.                                                                            */
-int mirl_lstm_step_fwd(int32_t B, int32_t H, const float* h_in, const float* w_hh, float* gates,
-                       const float* c_in, const float* keep_next, float* h_out, float* c_out,
-                       float* h_next, float* c_next, void* stream);
 /* A whole forward sweep of the recurrent layer (all T steps of all B sequences) in ONE
  * persistent launch (csrc/lstm_seq.hip; replaces the T-step loop of
  * rltime/models/torch/modules/lstm.py:83-116): W_hh stays resident in LDS, the cell runs
@@ -584,13 +576,6 @@ int mirl_gemm3_nn_qp_partial_rows(int64_t M, int64_t* rows);
 int mirl_gemm3_nn_qp(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                      const float* emb, int64_t ldemb, const float* x, int64_t ldx, float* d_pre, int64_t ldd,
                      float* dx, int64_t lddx, float* db_partial, void* stream);
-int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes);
-int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes, void* stream);
-int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
-                  const float* bias, int32_t relu, void* stream);
-int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
-                      const float* bias, int32_t relu, const float* mul, int64_t ldmul, int32_t group_shift, float* pre,
-                      int64_t ldpre, void* stream);
 
 /* ---- forward of the middle conv layers on the bf16 matrix pipe, f32 result (csrc/conv3.hip).  Replaces
  * `F.relu(conv(x))` of rltime/models/torch/modules/cnn.py:47-49 for NHWC activations (the Atari models' layers 2
@@ -605,20 +590,6 @@ int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t l
 int mirl_conv3_fwd_supported(int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S, int32_t H, int32_t W);
 int mirl_conv3_fwd(int64_t N, int32_t H, int32_t W, int32_t C, int32_t F, int32_t KH, int32_t KW, int32_t S,
                    const float* x, const float* w, const float* bias, int32_t relu, float* y, void* stream);
-
-/* ---- the backward of a small NHWC convolution as wide GEMMs (csrc/conv_col.hip + mirl_gemm3).
- * Replaces MIOpen's weight / data gradient kernels behind autograd for the reference's conv layers 2 and 3
- * (rltime/models/torch/modules/cnn.py:43-50).  With row = (n, oy, ox) one output position:
- *   mirl_im2col_nhwc:  col[row][(ky, kx, c)] = x[n][oy*S + ky][ox*S + kx][c]          float [N*OH*OW][KH*KW*C]
- *       -> weight gradient  dW^T[(ky,kx,c)][f] = mirl_gemm3(TN, col, g)   (g = d loss / d conv output, [rows][F])
- *   mirl_col2im_nhwc:  dx[n][y][x][c] = sum over the windows covering (y, x) of dcol[row][(ky, kx, c)], in fixed
- *       (ky, kx) order (deterministic), times (relu_mask[n][y][x][c] > 0) when relu_mask is given (the ReLU of the
- *       layer below)      <- dcol = mirl_gemm3(NN, g, W as [F][KH*KW*C])
- * C % 4 == 0, 16-byte aligned buffers, fewer than 2^31 positions; no padding, no dilation.  One HBM pass each.   */
-int mirl_im2col_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t S, const float* x,
-                     float* col, void* stream);
-int mirl_col2im_nhwc(int64_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t S, const float* col,
-                     const float* relu_mask, float* dx, void* stream);
 
 /* ---- weight gradient of the middle conv layers on the bf16 matrix pipe, f32 results (csrc/conv_wrw.hip).
  * Replaces MIOpen's igemm_wrw kernels behind autograd for conv layers 2 and 3

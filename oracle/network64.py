@@ -18,9 +18,10 @@ Plain-torch float64 restatement, from a float32 state_dict, of
 
 It is the independent anchor of tests/test_network_ab_gpu.py: the HIP path (products on the bf16 matrix
 pipe, persistent LSTM sweeps) and the library path are both measured against THIS evaluation of the same
-weights on the same gathered batch.  "parity": float64 has no fixture from the reference (the reference
-computes in float32); the float32 pin is tests/test_e2e_gpu.py, this file bounds the rounding error of
-either float32 path from the other side.
+weights on the same gathered batch.  PINNED: tests/golden/generate.py run_network64_pin runs the reference's own
+SequentialModel + IQNPolicy (float32, CPU) and Net64 on the same seeded weights, frames, stored state, initials and
+quantile fractions and asserts outputs within 1e-5 and gradients within 1e-4 (measured 1.4e-6); the reference's
+outputs travel as tests/golden/network64_pin.npz and tests/test_oracle_golden.py repeats the check without it.
 """
 import math
 
@@ -95,9 +96,16 @@ class Net64:
         phi = torch.cos(taus.to(self.dev).double().unsqueeze(1) * rng.unsqueeze(0) * math.pi)   # iqn.py:78-81
         emb = F.relu(phi @ p["quantile_layer.weight"].t() + p["quantile_layer.bias"])
         inner = (x.unsqueeze(1) * emb.reshape(x.shape[0], N, -1)).reshape(x.shape[0] * N, -1)    # iqn.py:84,102
-        h = F.relu(inner @ p["model.layers.2.layers.0.0.weight"].t() + p["model.layers.2.layers.0.0.bias"])
+        pre_h = inner @ p["model.layers.2.layers.0.0.weight"].t() + p["model.layers.2.layers.0.0.bias"]
+        h = F.relu(pre_h)
         adv = h @ p["out_layer.weight"].t() + p["out_layer.bias"]
-        hv = F.relu(inner @ p["value_hidden_layer.weight"].t() + p["value_hidden_layer.bias"])   # dqn.py:50-66
+        pre_v = inner @ p["value_hidden_layer.weight"].t() + p["value_hidden_layer.bias"]
+        hv = F.relu(pre_v)                                                                       # dqn.py:50-66
+        # ReLU units whose pre-activation is within float32 rounding of zero: a float32 evaluation may take the other
+        # branch there, which switches that unit's whole gradient row (tests/test_network_ab_gpu.py conditions its
+        # per-parameter gradient bar on this count)
+        with torch.no_grad():
+            self.relu_near_zero = sum(int((t.abs() <= 4e-7 * t.abs().max()).sum()) for t in (pre_h, pre_v))
         val = hv @ p["value_layer.weight"].t() + p["value_layer.bias"]
         z = val + adv - adv.mean(1, keepdim=True)                                                # dqn.py:74-87
         return z.reshape(x.shape[0], N, -1)
@@ -150,4 +158,5 @@ def learner_eval(online, target, batch, taus, gamma, P, kappa=1.0, double_q=True
                                   flat(batch["weights"]), kappa, T, "mean", None)
     names = list(online.params())
     grads = torch.autograd.grad(loss, [online.p[k] for k in names])
-    return {"targets": y, "loss": loss.detach(), "report": report, "grads": dict(zip(names, grads))}
+    return {"targets": y, "loss": loss.detach(), "report": report, "grads": dict(zip(names, grads)),
+            "relu_near_zero": online.relu_near_zero}       # of the training pass (the last head evaluated on `online`)

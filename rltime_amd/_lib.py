@@ -152,7 +152,6 @@ _SIGNATURES = {
     "mirl_loss_dqn": [_i64, _i32, _vp, _vp, _vp, _vp, _f64, _i32, _f64, _vp, _vp, _vp, _vp],
     "mirl_loss_iqn": [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp],
     "mirl_lstm_cell_fwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "mirl_lstm_step_fwd": [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mirl_lstm_seq_supported": [_i32, _i32, _i32],
     "mirl_lstm_seq_workspace_bytes": [_i32, _i32, _P(_i64)],
     "mirl_lstm_seq_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
@@ -185,8 +184,6 @@ _SIGNATURES = {
     "mirl_conv_wrw_b3_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_conv_wrw_b3_scratch_bytes": [_i32, _i32, _i32, _i32, _P(_i64)],
     "mirl_conv_wrw_b3": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp],
-    "mirl_im2col_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
-    "mirl_col2im_nhwc": [_i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_gemm3_supported": [_i32, _i64, _i64, _i64],
     "mirl_gemm3_workspace_bytes": [_i32, _i64, _i64, _i64, _P(_i64)],
     "mirl_gemm3": [_i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp],
@@ -195,10 +192,6 @@ _SIGNATURES = {
     "mirl_gemm3_nn_qp": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "mirl_gemm3_head_workspace_bytes": [_i64, _i64, _P(_i64)],
     "mirl_gemm3_nt_head": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp],
-    "mirl_gemm3_presplit_bytes": [_i64, _i64, _P(_i64)],
-    "mirl_gemm3_presplit": [_i64, _i64, _vp, _i64, _i64, _vp, _vp],
-    "mirl_gemm3_ps": [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp],
-    "mirl_gemm3_ps_mul": [_i64, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp],
     "mirl_act_conv_supported": [_i32, _i32, _i32, _i32, _i32, _i32, _i32],
     "mirl_act_conv_fwd": [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "mirl_act_lstm_supported": [_i32, _i32, _i32],

@@ -35,8 +35,9 @@
 // for the quantile layer (mirl_gemm3_nt_mul), the IQN feature product applied on those vectors.  Outputs whose
 // rows are not 16-byte aligned take a scalar-store instantiation.
 // Measured (MI355X, profiles/r03_gemm3_*): 200-226 TFLOP/s of f32 product against 142-145 for the library's f32
-// kernels; the matrix pipe is 67 % busy at a power-limited 1.67 GHz.  Opt-in experiments that measured no gain:
-// MIRL_GEMM3_PERSIST=1 (persistent workgroups), MIRL_GEMM3_ORDER=1|2 (all waves stage first / compute first).
+// kernels; the matrix pipe is 67 % busy at a power-limited 1.67 GHz.  Built, measured without gain and removed again
+// (evidence under profiles/r04_gemm3_*): weights pre-split once per optimizer step, persistent workgroups for long K,
+// all waves staging first / computing first.
 #include "common.hpp"
 #include "split3.hpp"
 #include <stdlib.h>
@@ -51,7 +52,6 @@ struct G3Args {
   int mt, nt;            // output tiles along M / N
   int splits;            // K chunks (1 = none); with splits > 1, C is [splits][M][N] partials (ldc = N)
   int steps_per_split;   // K-steps of 16 per chunk
-  int order;             // 0: the two waves of a SIMD take opposite stage/compute orders; 1: all stage first; 2: all compute first
   // epilogue extension (NT): C = f(A B^T + bias) * mul[row >> mul_shift][col]; `pre` (optional) receives f(...) itself
   const float* mul; int64_t ldmul; int mul_shift;
   float* pre; int64_t ldpre;
@@ -59,7 +59,6 @@ struct G3Args {
   // epilogue extension EP == 2 (NT): the O <= 8 output units that FOLLOW this layer, out[row][o] = sum_n f(...)[row][n] * w2[o][n],
   // as partial sums per 64-column block: part[(col / 64)][row][8]; C may then be null (the activation itself is not stored)
   const float* w2; float* part;
-  const char* Bps;       // B operand already split (mirl_gemm3_presplit): rows of K/16 blocks of [hi 16 | mid 16 | lo 16] bf16
   // epilogue extension EP == 3 (NN, a data gradient g W that feeds the IQN feature product's backward, iqn.py:84,102): with
   // d = A B (never stored), e = `pre` (the ReLU'd embedding, READ here), x = mul[row >> 5]:
   //   C[row][col] = e > 0 ? d * x : 0;   gsum[row >> 5][col] = sum over the group's 32 rows of d * e;
@@ -67,7 +66,6 @@ struct G3Args {
   float* gsum; int64_t ldgsum;
 };
 
-constexpr int G3_PSBLK = 96;     // bytes of one pre-split 16-k block: three parts x 16 bf16
 
 // One operand's loader state: two rows per thread (r and r + 128 of the 256-row tile), four consecutive k each.
 template <bool KC>
@@ -125,49 +123,6 @@ struct G3Loader {
   }
 };
 
-// The B operand from PRE-SPLIT planes (weights, split once per optimizer step instead of by every one of the M / 256 row
-// tiles that multiply with them): a thread moves 48 contiguous bytes = three 16-byte chunks of row t >> 1 per K-step,
-// chunk c = 3 (t & 1) + i -> part c >> 1, k half c & 1; no VALU work, three 16-byte LDS writes.
-typedef unsigned g3_u32x4 __attribute__((ext_vector_type(4)));     // a native vector: arrays of HIP's uint4 struct stay in scratch
-struct G3LoaderPS {
-  const char* p;
-  int lds_off[3];
-  __device__ __forceinline__ void init(const char* planes, int64_t row0, int64_t rows, int64_t k0, int64_t K, int t) {
-    const int r = t >> 1, half = t & 1;
-    int64_t row = row0 + r; if (row > rows - 1) row = rows - 1;
-    p = planes + (row * (K / 16) + k0 / 16) * G3_PSBLK + half * 48;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const int c = 3 * half + i; lds_off[i] = (c >> 1) * G3_PLANE + r * G3_PITCH + (c & 1) * 16; }
-  }
-  __device__ __forceinline__ void load(g3_u32x4 (&v)[3]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const g3_u32x4*>(p + 16 * i);
-    p += G3_PSBLK;
-  }
-  __device__ __forceinline__ void store(char* planes, const g3_u32x4 (&v)[3]) const {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<g3_u32x4*>(planes + lds_off[i]) = v[i];
-  }
-};
-
-// rows x K floats (element (r, k) at W[r * row_stride + k * k_stride]) -> pre-split planes; one thread per four k
-__global__ void __launch_bounds__(256)
-k_g3_presplit(const float* __restrict__ W, int64_t rows, int64_t K, int64_t row_stride, int64_t k_stride, char* __restrict__ planes) {
-  const int64_t kq = K / 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * kq; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / kq, q = i - r * kq;
-    float x[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = W[r * row_stride + (q * 4 + e) * k_stride];
-    uint2 h, m, l;
-    g3_split4(x, h, m, l);
-    char* d = planes + (r * (K / 16) + q / 4) * G3_PSBLK + (q & 3) * 8;
-    *reinterpret_cast<uint2*>(d) = h;
-    *reinterpret_cast<uint2*>(d + 32) = m;
-    *reinterpret_cast<uint2*>(d + 64) = l;
-  }
-}
-
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
 // of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.  (Issuing all 18 fragment reads before the
 // first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.)
@@ -201,13 +156,10 @@ __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[T
 }
 
 
-template <bool BPS, bool BKC> struct G3BSel { typedef G3Loader<BKC> L; typedef float V[2][4]; };
-template <bool BKC> struct G3BSel<true, BKC> { typedef G3LoaderPS L; typedef g3_u32x4 V[3]; };
-
 // NARROW: outputs at most 64 columns wide (the quantile layer's weight gradient, 512 x 64 over K = 1.3 M rows): the
 // eight waves stack along M — 32 rows x 64 columns each, 12 MFMAs per K-step instead of 48 of which 36 multiplied
 // columns that do not exist — so the product is bound by reading its K x M operand, not by the matrix pipe.
-template <bool AKC, bool BKC, int EP, bool VEC, bool BPS = false, bool NARROW = false>
+template <bool AKC, bool BKC, int EP, bool VEC, bool NARROW = false>
 __global__ void __launch_bounds__(512)
 k_gemm3(G3Args g) {
   constexpr int TI = NARROW ? 1 : 4;
@@ -229,7 +181,7 @@ k_gemm3(G3Args g) {
   const int row_w = NARROW ? wu * 32 : wm * 128;                      // this wave's first row inside the tile
   const int a_off = (row_w + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
   const int b_off = (wn * 64 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
-  const bool stage_first = g.order == 0 ? ((wu >> 2) & 1) : g.order == 1;      // waves w and w + 4 share a SIMD and take opposite orders
+  const bool stage_first = (wu >> 2) & 1;      // waves w and w + 4 share a SIMD and take opposite orders
 
   // first tile of this workgroup
   int e = l, it = 0, jt = 0;
@@ -245,11 +197,10 @@ k_gemm3(G3Args g) {
     if (e >= E) return;
   }
 
-  G3Loader<AKC> la; typename G3BSel<BPS, BKC>::L lb;
-  float va[2][4]; typename G3BSel<BPS, BKC>::V vb;
+  G3Loader<AKC> la; G3Loader<BKC> lb;
+  float va[2][4], vb[2][4];
   la.init(g.A, g.lda, (int64_t)it * 256, g.M, ks0 * 16, t);
-  if constexpr (BPS) lb.init(g.Bps, (int64_t)jt * 256, g.N, ks0 * 16, g.K, t);
-  else lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
+  lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, ks0 * 16, t);
   if (nk > 0) { la.load(va); lb.load(vb); }
 
   g3_f32x16 acc[TI][2];
@@ -291,8 +242,7 @@ k_gemm3(G3Args g) {
       more = e < E;
       if (more) {
         la.init(g.A, g.lda, (int64_t)it * 256, g.M, 0, t);
-        if constexpr (BPS) lb.init(g.Bps, (int64_t)jt * 256, g.N, 0, g.K, t);
-        else lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, 0, t);
+        lb.init(g.B, g.ldb, (int64_t)jt * 256, g.N, 0, t);
         la.load(va); lb.load(vb);
       }
     }
@@ -591,16 +541,10 @@ extern "C" int mirl_gemm3_workspace_bytes(int32_t layout, int64_t M, int64_t N, 
 static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
                      int64_t workspace_bytes, const float* mul, int64_t ldmul, int32_t mul_shift, float* pre, int64_t ldpre,
-                     void* stream, const void* b_planes = nullptr, const float* w2 = nullptr, float* part = nullptr,
+                     void* stream, const float* w2 = nullptr, float* part = nullptr,
                      float* gsum = nullptr, int64_t ldgsum = 0) {
   using namespace mirl;
   if (!mirl_gemm3_supported(layout, M, N, K)) return fail(MIRL_ERR_ARG, "gemm3: unsupported layout / shape");
-  if (b_planes) {
-    // pre-split B: planes are [N rows][K / 16 blocks] whatever the weight's own layout was, so NT and NN are ONE kernel
-    if (layout == 2) return fail(MIRL_ERR_ARG, "gemm3: pre-split B exists for NT / NN (a weight operand), not for TN");
-    if ((uintptr_t)b_planes % 16) return fail(MIRL_ERR_ARG, "gemm3: pre-split planes must be 16-byte aligned");
-    B = reinterpret_cast<const float*>(b_planes); ldb = K; layout = 0;
-  }
   if (!A || !B || (!C && !w2)) return fail(MIRL_ERR_ARG, "gemm3: null operand");
   const bool akc = layout != 2, bkc = layout == 0;
   if (akc && ((lda % 4) || ((uintptr_t)A % 16) || lda < K)) return fail(MIRL_ERR_ARG, "gemm3: A must be 16-byte aligned with lda % 4 == 0");
@@ -614,19 +558,15 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
-  g.Bps = reinterpret_cast<const char*>(b_planes);
   g.w2 = w2; g.part = part; g.gsum = gsum; g.ldgsum = ldgsum;
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
   g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!w2 || !((uintptr_t)w2 % 16)) && (!bias || !((uintptr_t)bias % 16)) &&
              (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));
   g.mt = (int)((M + 255) / 256); g.nt = (int)((N + 255) / 256);
   g.splits = 1; g.steps_per_split = (int)(K / 16);
-  static const int order_env = getenv("MIRL_GEMM3_ORDER") ? atoi(getenv("MIRL_GEMM3_ORDER")) : 0;
-  g.order = order_env;
   static const int narrow_env = getenv("MIRL_GEMM3_NARROW") ? atoi(getenv("MIRL_GEMM3_NARROW")) : 1;
-  static const int persist_env = getenv("MIRL_GEMM3_PERSIST") ? atoi(getenv("MIRL_GEMM3_PERSIST")) : 0;   // measured: no gain (7.36 vs 7.32 ms), opt-in
   unsigned grid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);                 // one tile per workgroup
-  if (persist_env || K <= 128) {          // short K: the tile is mostly epilogue — let the next tile's loads fly during the stores
+  if (K <= 128) {          // short K: the tile is mostly epilogue — let the next tile's loads fly during the stores
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -650,13 +590,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
                            {(const void*)k_gemm3<true, true, 1, false>, (const void*)k_gemm3<true, true, 1, true>}};
   const int which = (mul && !gsum) ? 3 : layout;
   const void* fn = fns[which][vec];
-  if (b_planes) {
-    static bool ps_attr[2][2] = {{false, false}, {false, false}};
-    const void* ps[2][2] = {{(const void*)k_gemm3<true, true, 0, false, true>, (const void*)k_gemm3<true, true, 0, true, true>},
-                            {(const void*)k_gemm3<true, true, 1, false, true>, (const void*)k_gemm3<true, true, 1, true, true>}};
-    fn = ps[mul ? 1 : 0][vec];
-    if (!ps_attr[mul ? 1 : 0][vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); ps_attr[mul ? 1 : 0][vec] = true; }
-  } else if (gsum) {
+  if (gsum) {
     if (!vec || layout != 1 || !mul || mul_shift != 5 || !pre || !part || (ldgsum % 4) || ((uintptr_t)gsum % 16) || ((uintptr_t)part % 16) || (M % 32))
       return fail(MIRL_ERR_ARG, "gemm3: the fused feature-product backward needs the NN form, groups of 32 rows and 16-byte aligned rows");
     static bool qp_attr = false;
@@ -670,7 +604,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   } else if (layout == 2 && N <= 64 && narrow_env) {
     // weight gradient of a narrow layer: eight waves stacked along M, 12 MFMAs per K-step (k_gemm3 NARROW)
     static bool nr_attr[2] = {false, false};
-    const void* nr[2] = {(const void*)k_gemm3<false, false, 0, false, false, true>, (const void*)k_gemm3<false, false, 0, true, false, true>};
+    const void* nr[2] = {(const void*)k_gemm3<false, false, 0, false, true>, (const void*)k_gemm3<false, false, 0, true, true>};
     fn = nr[vec];
     if (!nr_attr[vec]) { MIRL_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS)); nr_attr[vec] = true; }
   } else
@@ -681,7 +615,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * (layout == 2 ? (double)g.splits : 1.0));
     if (mul) bytes += 4.0 * ((pre ? (double)M * N : 0.0) + (double)(M >> mul_shift) * N * (gsum ? 2.0 : 1.0));
     if (w2) bytes += 4.0 * (8.0 * (double)N + 8.0 * (double)M * (double)((N + 63) / 64)) - (C ? 0.0 : 4.0 * (double)M * N);
-    ProfScope ps(gsum ? "k_gemm3_nn_qp" : mul ? "k_gemm3_nt_mul" : b_planes ? "k_gemm3_ps" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
+    ProfScope ps(gsum ? "k_gemm3_nn_qp" : mul ? "k_gemm3_nt_mul" : w2 ? "k_gemm3_nt_head" : layout == 0 ? "k_gemm3_nt" : layout == 1 ? "k_gemm3_nn" : "k_gemm3_tn", bytes, st, flop);
     void* kargs[] = {(void*)&g};
     MIRL_HIP(hipLaunchKernel(fn, dim3(grid), dim3(512), kargs, G3_LDS, st));
   }
@@ -724,41 +658,7 @@ extern "C" int mirl_gemm3_nn_qp(int64_t M, int64_t N, int64_t K, const float* A,
   if (!emb || !x || !d_pre || !dx || !db_partial || ldemb < N || ldx < N || lddx < N || (ldemb % 4) || ((uintptr_t)emb % 16))
     return fail(MIRL_ERR_ARG, "gemm3_nn_qp: bad embedding / feature / output arguments");
   return g3_launch(1, M, N, K, A, lda, B, ldb, d_pre, ldd, nullptr, 0, nullptr, 0, x, ldx, 5, const_cast<float*>(emb), ldemb, stream,
-                   nullptr, nullptr, db_partial, dx, lddx);
-}
-
-// ---- weights split once (per optimizer step) instead of by every row tile ------------------------------------
-extern "C" int mirl_gemm3_presplit_bytes(int64_t rows, int64_t K, int64_t* bytes) {
-  if (!bytes || rows < 1 || K < 16 || (K % 16)) return mirl::fail(MIRL_ERR_ARG, "gemm3_presplit_bytes: rows >= 1, K a multiple of 16");
-  *bytes = rows * (K / 16) * (int64_t)mirl::G3_PSBLK;
-  return MIRL_OK;
-}
-
-extern "C" int mirl_gemm3_presplit(int64_t rows, int64_t K, const float* W, int64_t row_stride, int64_t k_stride, void* planes,
-                                   void* stream) {
-  using namespace mirl;
-  if (rows < 1 || K < 16 || (K % 16) || !W || !planes || ((uintptr_t)planes % 16) || row_stride < 1 || k_stride < 1)
-    return fail(MIRL_ERR_ARG, "bad gemm3_presplit arguments");
-  const int64_t n = rows * (K / 4);
-  unsigned grid = (unsigned)((n + 255) / 256); if (grid > 8192) grid = 8192;
-  ProfScope ps("k_g3_presplit", 10.0 * (double)rows * (double)K, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_g3_presplit, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, rows, K, row_stride, k_stride, (char*)planes);
-  MIRL_LAUNCH_CHECK();
-  return MIRL_OK;
-}
-
-extern "C" int mirl_gemm3_ps(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
-                             const float* bias, int32_t relu, void* stream) {
-  return g3_launch(0, M, N, K, A, lda, nullptr, K, C, ldc, bias, relu, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream, b_planes);
-}
-
-extern "C" int mirl_gemm3_ps_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const void* b_planes, float* C, int64_t ldc,
-                                 const float* bias, int32_t relu, const float* mul, int64_t ldmul, int32_t group_shift, float* pre,
-                                 int64_t ldpre, void* stream) {
-  using namespace mirl;
-  if (!mul || group_shift < 0 || group_shift > 30 || ldmul < N || (pre && ldpre < N))
-    return fail(MIRL_ERR_ARG, "gemm3_ps_mul: bad multiplier / pre-activation arguments");
-  return g3_launch(0, M, N, K, A, lda, nullptr, K, C, ldc, bias, relu, nullptr, 0, mul, ldmul, group_shift, pre, ldpre, stream, b_planes);
+                   nullptr, db_partial, dx, lddx);
 }
 
 // ---- a wide layer and the narrow one that follows it, in one pass over the activation ----------------------------
@@ -783,7 +683,7 @@ extern "C" int mirl_gemm3_nt_head(int64_t M, int64_t N, int64_t K, const float* 
       ((uintptr_t)workspace % 16) || (N % 4))
     return fail(MIRL_ERR_ARG, "bad gemm3_nt_head arguments (1 <= O <= 8, N % 4 == 0, 16-byte aligned workspace of head_workspace_bytes)");
   if (!C) ldc = N;
-  int rc = g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream, nullptr, w2,
+  int rc = g3_launch(0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream, w2,
                      (float*)workspace);
   if (rc) return rc;
   const int ncb = (int)((N + 255) / 256 * 4);

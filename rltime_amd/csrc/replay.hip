@@ -621,32 +621,6 @@ k_gather_rows_v1(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ 
   if (h2) __builtin_nontemporal_store(w2, t4 + c + 1024);
 }
 
-// MIRL_GATHER_VARIANT=2: the same row copy with at most TWO 16-byte vectors in flight per lane — a row is cut into
-// `parts` pieces of <= 1024 vectors, one 512-lane workgroup each.  tools/copy_probe.py (profiles/r04_copy_probe.jsonl):
-// a plain copy of this size moves 6.0 TB/s with 2 vectors per lane against 5.4 with 4 (and 4.1 with 8) on MI355X.
-__global__ void __launch_bounds__(512)
-k_gather_rows_v2(Dev d, const uint8_t* __restrict__ ring, uint8_t* __restrict__ out,
-                 const int32_t* __restrict__ env, const int64_t* __restrict__ start,
-                 int B, int overlapped, int32_t row_bytes, int64_t ring_stride, int parts, int piece) {
-  const int64_t rb = blockIdx.x / parts;
-  const int part = blockIdx.x - (int)(rb * parts);
-  const int r = (int)(rb / B), b = (int)(rb % B);
-  int32_t e = env[b];
-  if (e < 0 || e >= d.E) e = 0;
-  const int64_t src_off = row_src_off(d, overlapped, r, e, start[b]);
-  const u32x4* s4 = (const u32x4*)(ring + ((int64_t)e * d.C + src_off % d.C) * ring_stride);
-  u32x4* t4 = (u32x4*)(out + rb * (int64_t)row_bytes);
-  const int n = row_bytes >> 4;
-  const int lo = part * piece, hi = lo + piece < n ? lo + piece : n;
-  const int c0 = lo + threadIdx.x, c1 = c0 + 512;
-  u32x4 v0, v1;
-  const bool h0 = c0 < hi, h1 = c1 < hi;
-  if (h0) v0 = __builtin_nontemporal_load(s4 + c0);
-  if (h1) v1 = __builtin_nontemporal_load(s4 + c1);
-  if (h0) __builtin_nontemporal_store(v0, t4 + c0);
-  if (h1) __builtin_nontemporal_store(v1, t4 + c1);
-}
-
 // out[r][b] = the P-plane stack of ring transition src(r, b), rebuilt from the
 // newest planes of that transition and its P-1 predecessors (zero fill beyond the
 // recorded depth).  Same launch shape as the whole-frame gather: 512 lanes per
@@ -1563,12 +1537,7 @@ static int gather_leaf(mirl_replay* h, const void* ring, void* out, const int32_
   {
   ProfScope ps(ring == (const void*)h->d.frames ? "k_gather_rows(frames)" : (ring == (const void*)h->d.state ? "k_gather_rows(recurrent state)" : "k_gather_rows(extra)"),
                2.0 * (double)blocks * row_bytes, st);
-  if (vec && h->gather_variant == 2 && row_bytes >= 512 * 16) {
-    const int n = row_bytes >> 4, parts = (n + 1023) / 1024, piece = ((n + parts - 1) / parts + 3) / 4 * 4;
-    hipLaunchKernelGGL(k_gather_rows_v2, dim3((unsigned)(blocks * parts)), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
-                       env, start, B, h->overlapped, row_bytes, ring_stride, parts, piece);
-  }
-  else if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16) {    // small rows (recurrent state) keep the 256-lane shape
+  if (vec && h->gather_variant == 1 && row_bytes >= 512 * 16) {    // small rows (recurrent state) keep the 256-lane shape
     if (h->gather_nt == 2)                                          // cached loads, non-temporal stores
       hipLaunchKernelGGL(k_gather_rows_v1<0>, dim3((unsigned)blocks), dim3(512), 0, st, h->d, (const uint8_t*)ring, (uint8_t*)out,
                          env, start, B, h->overlapped, row_bytes, ring_stride, h->gather_order);

@@ -165,13 +165,6 @@ class _ConvBiasReLU(torch.autograd.Function):
             db = g.sum((0, 2, 3))
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dx = dw = None
-        if (need_x or need_w) and conv_col_supported(x, weight, ctx.stride, g):
-            # both gradients as wide split-bf16 GEMMs over the window matrix (csrc/conv_col.hip + gemm3)
-            if need_w:
-                dw = conv_wgrad_col(g, x, weight, ctx.stride)
-            if need_x:
-                dx = conv_dgrad_col(g, x, weight, ctx.stride)
-            need_x = need_w = False
         if need_w and conv_wrw_supported(x, weight, ctx.stride, g):
             dw = conv_wgrad_b3(g, x, weight, ctx.stride)      # split-bf16 implicit GEMM, reduction over positions (csrc/conv_wrw.hip)
             need_w = False
@@ -226,76 +219,6 @@ def conv_wgrad_b3(g, x, weight, stride):
     L.check(L.lib.mirl_conv_wrw_b3(n, h, w, c, f, kh, kw, int(stride[0]), _p(x), _p(g), _p(scratch), scratch.numel(), _p(dw),
                                    _stream()), "mirl_conv_wrw_b3")
     return dw.permute(0, 3, 1, 2)                     # logical (F, C, KH, KW) with channels_last strides
-# conv layers 2-3 backward as im2col / col2im around the split-bf16 GEMMs.  MEASURED SLOWER and therefore OFF by default
-# (MIRL_CONV_COL=1 turns it on): the explicit window matrix is 4.6 GB (layer 3) + 6.8 GB (layer 2) at the 40 960 frames of
-# a learner step, written once and read once per gradient — 102.7 vs 93.7 ms per step on the same box
-# (profiles/r04_conv_col_probe.jsonl); MIOpen's implicit GEMMs never materialise it.
-# Window-matrix multiply-adds below MIRL_CONV_COL_MIN_WORK stay on the library either way.
-_CONV_COL = os.environ.get("MIRL_CONV_COL", "0") != "0"
-_CONV_COL_MIN_WORK = int(os.environ.get("MIRL_CONV_COL_MIN_WORK", str(1 << 31)))
-
-
-def conv_col_supported(x, weight, stride, g, min_work=None):
-    """Do both gradients of this NHWC conv run as GEMMs over the explicit window matrix?"""
-    if not (_CONV_COL and gemm3.enabled() and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32
-            and x.dim() == 4 and stride[0] == stride[1]
-            and x.is_contiguous(memory_format=torch.channels_last) and g.is_contiguous(memory_format=torch.channels_last)
-            and weight.is_contiguous(memory_format=torch.channels_last)
-            and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0):
-        return False
-    n, c, h, w = x.shape
-    f, _, kh, kw = weight.shape
-    rows, k = g.shape[0] * g.shape[2] * g.shape[3], kh * kw * c
-    if c % 4 or f % 16 or k % 16 or rows % 16 or rows // 16 < 8 or rows >= (1 << 31) or n * h * w >= (1 << 31):
-        return False
-    return rows * k * f >= (_CONV_COL_MIN_WORK if min_work is None else min_work)
-
-
-def _conv_dims(x, weight, stride):
-    n, c, h, w = x.shape
-    f, _, kh, kw = weight.shape
-    s = int(stride[0])
-    return n, c, h, w, f, kh, kw, s, (h - kh) // s + 1, (w - kw) // s + 1
-
-
-def im2col_nhwc(x, kh, kw, s):
-    """Window matrix [(n, oy, ox)][(ky, kx, c)] of an NHWC activation (one launch, csrc/conv_col.hip)."""
-    L = _lib()
-    n, c, h, w = x.shape
-    oh, ow = (h - kh) // s + 1, (w - kw) // s + 1
-    col = torch.empty((n * oh * ow, kh * kw * c), dtype=torch.float32, device=x.device)
-    L.check(L.lib.mirl_im2col_nhwc(n, h, w, c, kh, kw, s, _p(x), _p(col), _stream()), "mirl_im2col_nhwc")
-    return col
-
-
-def col2im_nhwc(dcol, x_like, kh, kw, s, relu_mask=None):
-    """Sum the window matrix's gradient back onto the NHWC input grid (x_like: shape / memory format of the result)."""
-    L = _lib()
-    n, c, h, w = x_like.shape
-    dx = torch.empty_like(x_like, memory_format=torch.channels_last)
-    L.check(L.lib.mirl_col2im_nhwc(n, h, w, c, kh, kw, s, _p(dcol), _p(relu_mask), _p(dx), _stream()), "mirl_col2im_nhwc")
-    return dx
-
-
-def conv_wgrad_col(g, x, weight, stride):
-    """d loss / d weight of conv2d(x, weight, stride): col(x)^T g as ONE split-K product; returned in the weight's own
-    (channels_last) memory format."""
-    n, c, h, w, f, kh, kw, s, oh, ow = _conv_dims(x, weight, stride)
-    col = im2col_nhwc(x, kh, kw, s)
-    g2 = g.permute(0, 2, 3, 1).reshape(n * oh * ow, f)              # a view of the NHWC gradient
-    dwt = gemm3.gemm(gemm3.TN, col, g2)                             # (kh*kw*c, f)
-    return dwt.t().contiguous().view(f, kh, kw, c).permute(0, 3, 1, 2)
-
-
-def conv_dgrad_col(g, x, weight, stride, relu_mask=None):
-    """d loss / d input: g W as one product onto the window matrix, then col2im."""
-    n, c, h, w, f, kh, kw, s, oh, ow = _conv_dims(x, weight, stride)
-    g2 = g.permute(0, 2, 3, 1).reshape(n * oh * ow, f)
-    wmat = weight.permute(0, 2, 3, 1).reshape(f, kh * kw * c)       # the channels_last weight as stored
-    dcol = gemm3.gemm(gemm3.NN, g2, wmat)
-    return col2im_nhwc(dcol, x, kh, kw, s, relu_mask)
-
-
 def conv2_bwd_data_supported(x, weight, stride, g):
     if not (g.is_contiguous(memory_format=torch.channels_last) and g.data_ptr() % 16 == 0
             and tuple(stride) == (2, 2) and weight.shape[2] == weight.shape[3]):

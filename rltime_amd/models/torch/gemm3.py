@@ -64,53 +64,12 @@ def _workspace(device, nbytes):
     return buf
 
 
-# ---- weight operands split once per version (csrc/gemm3.hip mirl_gemm3_presplit) ---------------------------------
-# Every NT / NN product here has a WEIGHT as its B operand: 5 120 row tiles of one launch, and 3-5 launches per
-# optimizer step, each split the same 256 x 16 tile again.  The planes are cached per (storage, version counter,
-# layout): Adam's in-place update or a target-network copy bumps `_version`, the next product re-splits (one ~5 us launch).
-# MEASURED SLOWER and therefore OFF by default (MIRL_GEMM3_PRESPLIT=1 turns it on): bit-identical results, but
-# 8.31 vs 6.87 ms at NT 1 310 720 x 1024 x 512, 8.11 vs 7.04 at NN, 106.3 vs 97.8 ms per learner step
-# (profiles/r04_gemm3_probe_presplit.jsonl) — the split VALU work of the B half was not on the critical
-# path (it overlaps the other wave's MFMAs), while three 16-byte loads per thread and K-step from 96-byte blocks cost
-# more than two from the f32 rows.
-_PRESPLIT = os.environ.get("MIRL_GEMM3_PRESPLIT", "0") != "0"
-_planes = {}
-
-
-def presplit_enabled():
-    return _PRESPLIT
-
-
-def weight_planes(w, layout):
-    """Pre-split planes of the B operand `w` of an NT ((N, K) weight) or NN ((K, N) operand) product, cached."""
-    L = _lib()
-    key = (w.data_ptr(), layout, tuple(w.shape), tuple(w.stride()), torch.cuda.current_stream().cuda_stream)
-    hit = _planes.get(key)
-    # an entry holds a reference to ITS tensor: while it is cached no other tensor can live at that address, so a
-    # (pointer, version) match really is the same data (a temporary's recycled address could otherwise alias it)
-    if hit is not None and hit[0] == w._version and hit[2].untyped_storage().data_ptr() == w.untyped_storage().data_ptr():
-        return hit[1]
-    if layout == NT:
-        rows, K, rs, ks = w.shape[0], w.shape[1], w.stride(0), 1
-    else:
-        rows, K, rs, ks = w.shape[1], w.shape[0], 1, w.stride(0)
-    need = C.c_int64()
-    L.check(L.lib.mirl_gemm3_presplit_bytes(rows, K, C.byref(need)), "mirl_gemm3_presplit_bytes")
-    buf = hit[1] if hit is not None and hit[1].numel() == need.value else torch.empty(need.value, dtype=torch.uint8, device=w.device)
-    L.check(L.lib.mirl_gemm3_presplit(rows, K, _p(w), rs, ks, _p(buf), _stream()), "mirl_gemm3_presplit")
-    if len(_planes) > 64:
-        _planes.clear()
-    _planes[key] = (w._version, buf, w)
-    return buf
-
-
 _joint = {}
 
 
 def joint_rows(tensors):
     """torch.cat(tensors, 0) of long-lived weights / biases as ONE persistent tensor, rebuilt only when a source's version
-    counter moved (the dueling head's [last FC | value-hidden] weights: fused.py).  Persistent, so that its pre-split planes
-    can be cached like a parameter's."""
+    counter moved (the dueling head's [last FC | value-hidden] weights: fused.py)."""
     key = tuple(t.data_ptr() for t in tensors)
     vers = tuple(t._version for t in tensors)
     hit = _joint.get(key)
@@ -119,7 +78,7 @@ def joint_rows(tensors):
     with torch.no_grad():
         if hit is not None and hit[1].shape[0] == sum(t.shape[0] for t in tensors):
             out = hit[1]
-            torch.cat([t.detach() for t in tensors], 0, out=out)     # in place: bumps out._version -> its planes re-split
+            torch.cat([t.detach() for t in tensors], 0, out=out)
         else:
             out = torch.cat([t.detach() for t in tensors], 0)
     if len(_joint) > 32:
@@ -130,17 +89,9 @@ def joint_rows(tensors):
 
 def gemm(layout, a, b, bias=None, relu=False, out=None, weight_b=False):
     """NT: a (M,K) @ b (N,K)^T [+ bias, ReLU];  NN: a (M,K) @ b (K,N);  TN: a (K,M)^T @ b (K,N).
-    weight_b: b is a weight (long-lived, changes only through in-place updates): use its cached pre-split planes."""
+    weight_b: b is a weight (kept for the call sites; a pre-split cache of weight operands was measured slower and removed:
+    profiles/r04_gemm3_probe_presplit.jsonl)."""
     L = _lib()
-    if weight_b and _PRESPLIT and layout in (NT, NN):
-        M, K = a.shape
-        N = b.shape[0] if layout == NT else b.shape[1]
-        planes = weight_planes(b.detach(), layout)
-        if out is None:
-            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        L.check(L.lib.mirl_gemm3_ps(M, N, K, _p(a), a.stride(0), _p(planes), _p(out), out.stride(0),
-                                    _p(bias) if bias is not None else None, 1 if relu else 0, _stream()), "mirl_gemm3_ps")
-        return out
     if layout == NT:
         M, K, N = a.shape[0], a.shape[1], b.shape[0]
     elif layout == NN:
@@ -250,12 +201,6 @@ def quantile_product(x, phi, weight, bias, n, keep_embedding):
     R, K, N = phi.shape[0], phi.shape[1], weight.shape[0]
     out = torch.empty((R, N), dtype=torch.float32, device=phi.device)
     emb = torch.empty((R, N), dtype=torch.float32, device=phi.device) if keep_embedding else None
-    if _PRESPLIT:
-        planes = weight_planes(weight.detach(), NT)
-        L.check(L.lib.mirl_gemm3_ps_mul(R, N, K, _p(phi), phi.stride(0), _p(planes), _p(out), out.stride(0), _p(bias), 1, _p(x),
-                                        x.stride(0), n.bit_length() - 1, _p(emb) if emb is not None else None, N, _stream()),
-                "mirl_gemm3_ps_mul")
-        return out, emb
     L.check(L.lib.mirl_gemm3_nt_mul(R, N, K, _p(phi), phi.stride(0), _p(weight), weight.stride(0), _p(out), out.stride(0),
                                     _p(bias), 1, _p(x), x.stride(0), n.bit_length() - 1,
                                     _p(emb) if emb is not None else None, N, _stream()), "mirl_gemm3_nt_mul")

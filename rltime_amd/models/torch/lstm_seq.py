@@ -9,8 +9,7 @@ Same recurrence as the reference's LSTMCell time loop with per-step reset
 
 but the input projection of all T steps is ONE GEMM, a forward step is one rocBLAS
 GEMM accumulated IN PLACE onto its slice of that projection + one fused cell kernel
-(csrc/lstm.hip mirl_lstm_cell_fwd) — or, opt-in, ONE launch (mirl_lstm_step_fwd: the
-recurrent GEMM on f32 MFMA with the cell in its epilogue) —, a backward step one cell
+(csrc/lstm.hip mirl_lstm_cell_fwd), a backward step one cell
 kernel (mirl_lstm_cell_bwd) + one rocBLAS GEMM, and the weight
 gradients of W_ih and W_hh are one GEMM each over all timesteps after the
 backward sweep.
@@ -25,15 +24,9 @@ from . import gemm3
 
 import os
 
-# The one-launch step kernel (recurrent GEMM on f32 MFMA + cell epilogue) is correct
-# (tests/test_lstm_gpu.py) but no faster than the two launches at B = H = 512: 18.8 us
-# per step (16x16x4 tiles, 4 waves per SIMD; a 32x32x2 / one-wave-per-SIMD version:
-# 21.3 us) against 12.6 us (rocBLAS GEMM) + 5.7 us (cell kernel) + ~1.5 us launch gap.
-# Like the library GEMM it is bound by moving W_hh (re-read by every batch tile, every
-# step: ~100 MB L2->LDS per step) — the gain is in keeping W_hh resident across steps
-# (persistent kernel), not in fusing one step.  Off by default; MIRL_LSTM_FUSED_STEP=1.
-_FUSED_STEP = os.environ.get("MIRL_LSTM_FUSED_STEP", "0") == "1"
-
+# (A one-launch step kernel — recurrent GEMM on f32 MFMA with the cell in its epilogue — was built in round 2 and measured no
+# faster than GEMM + cell at B = H = 512 (18.8 vs 12.6 + 5.7 us): the gain is in keeping W_hh resident across steps, which the
+# persistent kernel below does.  Removed in round 5; at acting batch sizes csrc/actnet.hip k_act_lstm is that idea done right.)
 
 # The persistent sequence kernel (csrc/lstm_seq.hip: one launch per sweep, W_hh resident in
 # LDS, h exchanged between workgroups through write-through stores + arrival counters) is
@@ -105,15 +98,7 @@ def _forward_sweep(gates, w, h0, c0, keep, need_grad):
     torch.mul(h0, keep[0].unsqueeze(-1), out=hm[0])
     torch.mul(c0, keep[0].unsqueeze(-1), out=cm[0])
     wt = w.t()
-    fused_step = _FUSED_STEP and B % 32 == 0 and H % 64 == 0
     for t in range(T):
-        if fused_step:
-            # recurrent GEMM on f32 MFMA with the cell in its epilogue: one launch per step
-            check(lib.mirl_lstm_step_fwd(
-                B, H, _p(hm[t]), _p(w), _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,
-                _p(out[t]), _p(c_all[t]) if need_grad else None, _p(hm[t + 1]), _p(cm[t + 1]), st),
-                "mirl_lstm_step_fwd")
-            continue
         gates[t].addmm_(hm[t], wt)
         check(lib.mirl_lstm_cell_fwd(
             B, H, _p(gates[t]), _p(cm[t]), _p(keep[t + 1]) if t + 1 < T else None,

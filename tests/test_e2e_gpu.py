@@ -174,7 +174,7 @@ def _scripted_actor(spec):
     return ScriptedActor()
 
 
-def _iqn_series_with_replayed_taus(fixture, channels_last=False):
+def _iqn_series_with_replayed_taus(fixture, channels_last=False, train_args=None):
     """Train rltime_amd's IQN on the fixture's scripted stream from the reference's initial weights, replaying the
     reference's quantile fractions in call order -> (series, fixture arrays).  channels_last: the CNN keeps NHWC
     activations (the shipped model configs' layout, rltime_amd/configs/models/modules/nature_cnn.json; a memory layout,
@@ -225,6 +225,7 @@ def _iqn_series_with_replayed_taus(fixture, channels_last=False):
     tr.init_policies = init_from_reference
     args = copy.deepcopy(cfg["train"])
     args["burn_in_full_forward"] = True
+    args.update(train_args or {})
     tr.train(**args)
     assert cursor["call"] == len(sizes)                      # same number and order of tau draws
     assert len(series["qloss"]) == len(d["qloss"])
@@ -253,10 +254,11 @@ ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k
                   "k_conv1_u8_wrw_b3", "k_conv2_bwd_data_b3", "k_conv3_bwd_data_b3", "k_conv_wrw_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
 
 
-@pytest.mark.parametrize("forced,nhwc", [(True, True), ("gemm3", True), ("conv", True), ("lstm", True), (False, True), (False, False)],
+@pytest.mark.parametrize("forced,nhwc,full_sel", [(True, True, False), ("gemm3", True, False), ("conv", True, False), ("lstm", True, False),
+                                                  (False, True, False), (False, False, False), (True, True, True)],
                          ids=["every-hip-kernel-forced-on", "only-gemm3-forced", "only-conv-forced", "only-persistent-lstm-forced",
-                              "library-products-nhwc", "library-products-nchw"])
-def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, nhwc, monkeypatch):
+                              "library-products-nhwc", "library-products-nchw", "every-hip-kernel-forced-on-full-head-selection"])
+def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, nhwc, full_sel, monkeypatch):
     """The reference-pinned run that EXECUTES the round-3 arithmetic: the same algorithm as above on a model whose
     layer shapes the hand-written kernels take ((4,36,36) frames -> 32@8/4 -> 64@4/2 -> 64@3/1 -> LSTM 512 ->
     quantile 64 -> FC 128 | value-hidden 128; B = 16 sequences, T = 6, burn-in 4), trained by the unmodified
@@ -266,6 +268,8 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     epilogue), the dueling tail's fused backward and the persistent LSTM sweeps (forward AND backward) all run inside
     the pinned trajectory — asserted from the per-kernel launch table.  Not forced: the same model with those
     products on the library (MIOpen / hipBLASLt f32) — both must follow the reference equally well.
+    full_sel: the double-Q selection from the full dueling head (selection_advantage_only=False: V + A - mean_a A like the
+    reference, instead of the advantage stream alone) — the same bars, so a deviation cannot hide behind that optimisation.
     Bar: 2e-3 over the first 40 Adam steps (rltime/training/torch/iqn.py:54-129, multi_step_trainer.py:278-353)."""
     from rltime_amd import _lib
     from rltime_amd.models.torch import fused, gemm3, lstm_seq
@@ -279,7 +283,8 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     _lib.check(_lib.lib.mirl_profile_reset())
     _lib.check(_lib.lib.mirl_profile_set(2))
     try:
-        series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per_wide.npz", channels_last=nhwc)
+        series, d = _iqn_series_with_replayed_taus("e2e_iqn_lstm_per_wide.npz", channels_last=nhwc,
+                                                   train_args={"selection_advantage_only": False} if full_sel else None)
         torch.cuda.synchronize()
         table = {r["name"]: r["calls"] for r in _lib.profile_table()}
     finally:
@@ -288,7 +293,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     n = 40
     dev = np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"])
     gdev = np.abs(np.array(series["grad_norm"]) - d["grad_norm"]) / np.abs(d["grad_norm"])
-    label = {True: "all forced", False: "library nhwc" if nhwc else "library nchw"}.get(forced, "only %s forced" % forced)
+    label = {True: "all forced" + (", full-head selection" if full_sel else ""), False: "library nhwc" if nhwc else "library nchw"}.get(forced, "only %s forced" % forced)
     line = "wide IQN-LSTM e2e (%s): max rel dev over the first 10 / 20 / 40 / all %d steps: qloss %.2e / %.2e / %.2e / %.2e, " \
            "grad norm %.2e / %.2e / %.2e / %.2e" % (label, len(d["qloss"]), dev[:10].max(), dev[:20].max(), dev[:n].max(), dev.max(),
                                                   gdev[:10].max(), gdev[:20].max(), gdev[:n].max(), gdev.max())
@@ -299,17 +304,20 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
         with open(os.path.join(art, "wide_e2e_deviation.txt"), "a") as f:
             f.write(line + "\n")
     np.testing.assert_allclose(series["qloss"][:n], d["qloss"][:n], rtol=2e-3, atol=1e-5)
-    # gradient norms: 2e-3 like every other pinned trajectory, with room for ONE discrete event.  On MI355X some variants
-    # of this run show a single step (step 17 of 40: a gradient spike from 1.4 to 6.0) at 2.445e-3 — the SAME figure to
-    # four digits under different arithmetic (every HIP kernel forced; only the split-bf16 GEMMs; and, on another box and
-    # test order, the plain MIOpen / hipBLASLt path in NCHW), while the other variants sit at 1.1e-4
-    # (profiles/r04_wide_e2e_deviation_by_kernel_family.txt).  A deviation that is identical across arithmetics and absent
-    # or present as a whole is not rounding drift but one near-tie resolved the other way — the double-Q arg-max over six
-    # actions of a mean over eight quantiles (iqn.py:36-45), 96 rows x 40 steps of it — after which that row bootstraps
-    # from another action's quantiles.  So: at least 38 of the 40 steps within 2e-3, all of them within 6e-3; the loss
-    # series itself stays within 2e-3 everywhere (measured 1.7e-4).
+    # gradient norms: 2e-3 like every other pinned trajectory — except at the steps where the REFERENCE's own run holds a
+    # double-Q near-tie.  The fixture records, per learner step, the smallest gap between the best and second-best action of
+    # the selection scores (mean over eight quantiles, training/torch/iqn.py:36-45) over the 96 batch rows
+    # (tests/golden/generate.py boot_with_gap: sel_gap_min / sel_scale).  A float32 re-implementation whose scores differ
+    # from the reference's in the fifth digit resolves such a row the other way, and that row then bootstraps from another
+    # action's quantiles: a discrete change of one target, not rounding drift.  In the reference's run the first such step
+    # is step 17 (gap 8.0e-5 of the scores' magnitude; every earlier step >= 2.8e-4) — exactly the one step every
+    # arithmetic variant of round 4 showed at 2.445e-3 (profiles/r04_wide_e2e_deviation_by_kernel_family.txt).  Those
+    # steps, and only those, get the 6e-3 bar; everything else is held to 2e-3.
     rel = np.abs(np.array(series["grad_norm"][:n]) - d["grad_norm"][:n]) / np.abs(d["grad_norm"][:n])
-    assert (rel <= 2e-3).sum() >= n - 2 and rel.max() <= 6e-3, rel
+    near_tie = (d["sel_gap_min"][:n] / d["sel_scale"][:n]) <= 1e-4
+    assert 1 <= int(near_tie.sum()) <= 6, near_tie.nonzero()
+    assert rel[~near_tie].max() <= 2e-3, (rel, near_tie.nonzero())
+    assert rel[near_tie].max() <= 6e-3, (rel, near_tie.nonzero())
     if forced is True:
         missing = [k for k in ROUND3_KERNELS if not table.get(k)]
         assert not missing, ("kernels that never ran inside the pinned trajectory", missing, table)

@@ -223,65 +223,6 @@ def test_quantile_product_autograd_with_and_without_the_epilogue(monkeypatch):
             assert bad <= 8, (k, bad)
 
 
-@pytest.mark.parametrize("lay,M,N,K", [("nt", 1000, 300, 64), ("nt", 513, 1024, 512), ("nt", 4096, 2048, 3136), ("nt", 1, 1, 16),
-                                       ("nn", 777, 260, 48), ("nn", 5000, 512, 1024), ("nn", 2048, 3136, 2048)])
-def test_presplit_weight_operand_is_bit_identical(lay, M, N, K, monkeypatch):
-    """mirl_gemm3_presplit + mirl_gemm3_ps (the B operand — a weight — split ONCE into its three bf16 planes instead of by
-    every row tile) against mirl_gemm3 splitting while staging: the same parts, the same six products in the same order,
-    so the results are the same BITS — for the (N, K) weight of a forward (NT), the (K, N) operand of a data gradient
-    (NN, transposed while splitting), ragged tiles, a strided weight, bias + ReLU."""
-    from rltime_amd.models.torch import gemm3
-    gen = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
-    a, b = _operands(lay, M, N, K, gen, pad_b=4 if lay == "nt" else 0)
-    a[::7] *= 37.0
-    b[::5] *= 0.013
-    bias = torch.randn(N, device="cuda", generator=gen)
-    L = LAYOUTS[lay]
-    monkeypatch.setattr(gemm3, "_PRESPLIT", True)
-    for kw in ({}, {"bias": bias, "relu": True}):
-        plain = gemm3.gemm(L, a, b, **kw)
-        ps = gemm3.gemm(L, a, b, weight_b=True, **kw)
-        assert torch.equal(plain, ps), (lay, kw.keys())
-
-
-def test_presplit_planes_follow_in_place_weight_updates(monkeypatch):
-    """The planes are cached per (storage, version counter): an optimizer-style in-place update re-splits, an unchanged
-    weight does not (one k_g3_presplit launch per version), and two weights never alias each other's planes."""
-    from rltime_amd import _lib
-    from rltime_amd.models.torch import gemm3
-    gen = torch.Generator(device="cuda").manual_seed(5)
-    x = torch.randn(700, 128, device="cuda", generator=gen)
-    w = torch.nn.Parameter(torch.randn(320, 128, device="cuda", generator=gen))
-    w2 = torch.nn.Parameter(torch.randn(320, 128, device="cuda", generator=gen))
-    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
-    monkeypatch.setattr(gemm3, "_PRESPLIT", True)              # opt-in (measured slower than splitting while staging)
-    gemm3._planes.clear()
-    _lib.check(_lib.lib.mirl_profile_reset())
-    _lib.check(_lib.lib.mirl_profile_set(2))
-    try:
-        with torch.no_grad():
-            y0 = gemm3.linear_fwd(x, w)
-            y0b = gemm3.linear_fwd(x, w)                       # cached planes
-            z0 = gemm3.linear_fwd(x, w2)
-            y_ref, z_ref = gemm3.gemm(0, x, w.detach()), gemm3.gemm(0, x, w2.detach())     # splitting while staging
-            w.mul_(1.5)                                        # what Adam / copy_from do: in place, version bumped
-            y1 = gemm3.linear_fwd(x, w)
-            joint = gemm3.joint_rows((w, w2))
-            j0 = gemm3.linear_fwd(x, joint)
-            w2.add_(1.0)
-            j1 = gemm3.linear_fwd(x, gemm3.joint_rows((w, w2)))
-        torch.cuda.synchronize()
-        calls = {r["name"]: r["calls"] for r in _lib.profile_table()}
-    finally:
-        _lib.check(_lib.lib.mirl_profile_set(0))
-    assert gemm3.joint_rows((w, w2)) is joint                   # persistent: the same tensor, refreshed in place
-    assert torch.equal(y0, y0b) and torch.equal(y0, y_ref) and torch.equal(z0, z_ref)
-    assert torch.equal(y1, gemm3.gemm(0, x, w.detach())) and not torch.equal(y0, y1)
-    assert torch.equal(j0[:, :320], y1) and torch.equal(j1[:, :320], y1)
-    assert torch.equal(j1[:, 320:], gemm3.gemm(0, x, w2.detach()))
-    assert calls.get("k_g3_presplit") == 5, calls              # w, w2, w again, joint, joint again — not one per product
-
-
 @pytest.mark.parametrize("M,N,K,O", [(256, 256, 16, 1), (1000, 512, 64, 7), (777, 1024, 512, 7), (4099, 300, 128, 8), (33, 68, 32, 3)])
 def test_fused_following_layer_matches_two_products(M, N, K, O, monkeypatch):
     """mirl_gemm3_nt_head: hidden = relu(x W^T + b) and out = hidden W2^T + b2 (O <= 8 units) from ONE launch + a

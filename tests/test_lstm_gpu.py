@@ -11,17 +11,13 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("T,B,I,H", [(1, 3, 5, 4), (7, 5, 12, 8), (20, 33, 40, 64), (80, 16, 64, 512),
                                      (5, 32, 24, 64), (12, 64, 40, 128), (9, 256, 48, 512),
                                      (80, 512, 32, 512), (6, 48, 20, 256), (3, 80, 8, 128)])
-@pytest.mark.parametrize("mode", ["gemm+cell", "step_kernel", "persistent"])
+@pytest.mark.parametrize("mode", ["gemm+cell", "persistent"])
 def test_fused_lstm_matches_loop(T, B, I, H, mode, monkeypatch):
     """persistent = the one-launch-per-sweep kernel (csrc/lstm_seq.hip), incl. the config-D
     shape T=80, B=512, H=512 with mid-sequence resets (20 % of the initials set), a ragged
     row block (B=48, 80: 3 and 5 sixteen-row tiles) and H = 128 / 256."""
     from rltime_amd.models.torch import lstm_seq
     from rltime_amd.models.torch.modules import LSTM
-    step_kernel = mode == "step_kernel"
-    if step_kernel and (B % 32 or H % 64):
-        pytest.skip("the one-launch step kernel needs B % 32 == 0 and H % 64 == 0")
-    monkeypatch.setattr(lstm_seq, "_FUSED_STEP", step_kernel)
     monkeypatch.setattr(lstm_seq, "_PERSISTENT", mode == "persistent")
     if mode == "persistent" and not lstm_seq.persistent_supported(T, B, H):
         pytest.skip("shape outside the persistent kernel (B % 16, H in {128, 256, 512}, T >= 2)")
@@ -144,33 +140,6 @@ def test_prepared_input_feeds_the_same_values():
             a = model(raw, 1)["output"]
             b = model(pre, 1)["output"]
         assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("B,H", [(32, 64), (64, 192), (512, 512), (256, 512)])
-def test_fused_lstm_step_kernel_matches_gemm_plus_cell(B, H):
-    """mirl_lstm_step_fwd (recurrent GEMM on f32 MFMA + cell epilogue, one launch)
-    against the two-launch path it replaces (rocBLAS addmm_ + mirl_lstm_cell_fwd) on
-    random, asymmetric operands: activated gates, h, c and the masked carries."""
-    import ctypes as C
-    from rltime_amd._lib import lib, check
-    g = torch.Generator(device="cuda").manual_seed(B + H)
-    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)   # noqa: E731
-    h_in, w, proj, c_in = rnd(B, H) * 0.5, rnd(4 * H, H) * (1.0 / H ** 0.5), rnd(B, 4 * H), rnd(B, H)
-    keep = (torch.rand(B, device="cuda", generator=g) > 0.3).float()
-    p = lambda t: C.c_void_p(t.data_ptr())                          # noqa: E731
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    outs = []
-    for fused in (True, False):
-        gates = proj.clone()
-        h_out, c_out, h_next, c_next = (torch.empty(B, H, device="cuda") for _ in range(4))
-        if fused:
-            check(lib.mirl_lstm_step_fwd(B, H, p(h_in), p(w), p(gates), p(c_in), p(keep), p(h_out), p(c_out), p(h_next), p(c_next), st))
-        else:
-            gates.addmm_(h_in, w.t())
-            check(lib.mirl_lstm_cell_fwd(B, H, p(gates), p(c_in), p(keep), p(h_out), p(c_out), p(h_next), p(c_next), st))
-        outs.append((gates, h_out, c_out, h_next, c_next))
-    for name, a, b in zip(("gates", "h", "c", "h_next", "c_next"), outs[0], outs[1]):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
 
 
 def _sweep_inputs(T, B, H, seed):

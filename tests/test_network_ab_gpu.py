@@ -290,9 +290,16 @@ def test_config_d_learner_evaluation_hip_vs_library_vs_float64(monkeypatch):
     #     same unit flipped in both), once 2.6e-3 on the hip path and 5.2e-4 on the library path, once 1.5e-3 against 2.8e-3;
     #   * the two float32 paths differ by no more than each differs from float64 (max entry <= 2.5e-3, observed 8.5e-4);
     #   * the global gradient norm — what clipping and the logged series see — agrees to 1e-4.
+    # The 3e-3 escape is tied to the event it excuses: it applies only when the float64 evaluation itself holds hidden units
+    # of the last FC / value-hidden layers whose pre-activation lies within float32 rounding of zero (oracle/network64.py
+    # `relu_near_zero`: |pre| <= 4e-7 of the layer's largest, i.e. a few ulp); with none, every parameter must sit within
+    # 2 x the library path's own distance from float64.
+    escape = 3e-3 if ref["relu_near_zero"] > 0 else 0.0
+    facts["relu_units_within_float32_rounding_of_zero"] = int(ref["relu_near_zero"])
+    print(json.dumps({"relu_units_within_float32_rounding_of_zero": facts["relu_units_within_float32_rounding_of_zero"]}))
     for k, v in ah["grad_dev"].items():
-        assert v["max"] <= max(2.0 * al["grad_dev"][k]["max"], 3e-3), (k, v, al["grad_dev"][k])
-    assert ah["grad_dev_max"] <= max(1.5 * al["grad_dev_max"], 3e-3) and ah["grad_l2_max"] <= max(1.5 * al["grad_l2_max"], 4e-4), \
+        assert v["max"] <= max(2.0 * al["grad_dev"][k]["max"], escape), (k, v, al["grad_dev"][k], escape)
+    assert ah["grad_dev_max"] <= max(1.5 * al["grad_dev_max"], escape) and ah["grad_l2_max"] <= max(1.5 * al["grad_l2_max"], 4e-4), \
         (ah["grad_dev_max"], al["grad_dev_max"], ah["grad_l2_max"], al["grad_l2_max"])
     assert facts["grad_dev_max"] <= 2.5e-3, facts["grad_dev_max"]
     assert facts["grad_norm_rel_dev"] <= 1e-4 and ah["grad_norm_rel_dev"] <= max(2.0 * al["grad_norm_rel_dev"], 1e-5), (facts["grad_norm_rel_dev"], ah["grad_norm_rel_dev"], al["grad_norm_rel_dev"])

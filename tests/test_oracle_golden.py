@@ -103,3 +103,34 @@ def test_qmath_cases():
                 assert torch.equal(loss.detach(), t(tag + ".iqn.loss"))
                 assert torch.equal(z.grad, t(tag + ".iqn.grad"))
                 assert torch.equal(rep, t(tag + ".iqn.report"))
+
+
+def test_network64_is_pinned_to_the_reference_network():
+    """oracle/network64.py (the float64 anchor of tests/test_network_ab_gpu.py) against the reference's own
+    SequentialModel + IQNPolicy run in float32 on the CPU (rltime/models/torch/modules/{cnn,lstm,fc}.py,
+    policies/torch/{iqn,dqn}.py; fixture written by tests/golden/generate.py run_network64_pin from the imported
+    reference): outputs within 1e-5, gradients of a fixed linear functional within 1e-4 (relative to the largest
+    entry) — float32 rounding of the reference itself, nothing else."""
+    import io
+    import os
+    import numpy as np
+    import torch
+    from oracle.network64 import Net64
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "network64_pin.npz"))
+    sd = torch.load(io.BytesIO(fx["state_dict"].tobytes()), map_location="cpu", weights_only=True)
+    T, B = fx["x"].shape[:2]
+    N = fx["z"].shape[1]
+    net = Net64(sd, [2, 1], N, "cpu")
+    z64 = net.predict(torch.from_numpy(fx["x"]), torch.from_numpy(fx["hx"])[0], torch.from_numpy(fx["cx"])[0],
+                      torch.from_numpy(fx["initials"]), torch.from_numpy(fx["taus"]), T)
+    z = torch.from_numpy(fx["z"])
+    assert z64.shape == z.shape == (T * B, N, z.shape[2])
+    assert float((z64.detach().float() - z).abs().max() / z.abs().max()) <= 1e-5
+    names = list(net.params())
+    grads = torch.autograd.grad((z64 * torch.from_numpy(fx["weight"]).double()).sum(), [net.p[k] for k in names])
+    checked = 0
+    for k, g in zip(names, grads):
+        want = torch.from_numpy(fx["grad." + k])
+        assert float((g.float() - want).abs().max() / (want.abs().max() + 1e-12)) <= 1e-4, k
+        checked += 1
+    assert checked == sum(1 for k in fx.files if k.startswith("grad.")) >= 12

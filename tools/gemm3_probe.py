@@ -101,13 +101,6 @@ def main():
             reps = 5 if flop > 1e11 else 20
             t3 = timed(lambda: gemm3.gemm(layout, a, b, out=out), reps)
             tl = timed(lib, reps)
-            if layout != gemm3.TN:
-                gemm3._PRESPLIT = True
-                ps = gemm3.gemm(layout, a, b, weight_b=True)
-                rec["presplit_bit_identical"] = bool(torch.equal(ps, out))
-                tp = timed(lambda: gemm3.gemm(layout, a, b, out=out, weight_b=True), reps)
-                rec.update(ms_presplit_b=round(tp, 4), tflops_presplit_b=round(flop / tp / 1e9, 1))
-                gemm3._PRESPLIT = False
             rec.update(ms_gemm3=round(t3, 4), ms_lib_f32=round(tl, 4), tflops_gemm3=round(flop / t3 / 1e9, 1),
                        tflops_lib=round(flop / tl / 1e9, 1), frac_of_bf16x6_peak=round(flop / t3 / 1e9 / 416.7, 3))
         print(json.dumps(rec), flush=True)

@@ -23,12 +23,10 @@ def main():
         h0, c0 = torch.randn(B, H, device="cuda", generator=g), torch.randn(B, H, device="cuda", generator=g)
         keep = (torch.rand(T, B, device="cuda", generator=g) > 0.01).float()
         lstm_seq._BWD_PERSISTENT_MAX_B = 1 << 20
-        for name, pers, step in (("persistent", True, False), ("gemm+cell", False, False), ("step_kernel", False, True)):
+        for name, pers in (("persistent", True), ("gemm+cell", False)):
             for need_grad in (False, True):
-                lstm_seq._PERSISTENT, lstm_seq._FUSED_STEP = pers, step
+                lstm_seq._PERSISTENT = pers
                 if pers and not lstm_seq.persistent_supported(T, B, H):
-                    continue
-                if step and (B % 32 or H % 64):
                     continue
                 gates = gx.clone()
                 for _ in range(3):
