@@ -66,11 +66,11 @@ CONFIGS = {
         workload="BASELINE configs[3] atari_iqn_lstm: recurrent IQN, prioritized sequence replay",
         metric="sampled transitions/sec (= learner steps/sec x B x T), IQN-LSTM B=512 T=80 84x84x4"),
     "rainbow_iqn": dict(
-        file="synthetic_atari_rainbow_iqn.json", envs=32,
+        file="synthetic_atari_rainbow_iqn.json", envs=32, train_args={"graph_learner_step": True},
         workload="BASELINE configs[2] Rainbow-style IQN: dueling, 3-step, prioritized replay (2^20-leaf sum tree)",
         metric="sampled transitions/sec (= learner steps/sec x B), Rainbow-IQN B=512 T=1 84x84x4"),
     "dqn_uniform": dict(
-        file="synthetic_atari_dqn.json", envs=32,
+        file="synthetic_atari_dqn.json", envs=32, train_args={"graph_learner_step": True},
         workload="BASELINE configs[1] DQN + uniform replay, 1M buffer",
         metric="sampled transitions/sec (= learner steps/sec x B), DQN uniform replay B=256 T=1 84x84x4"),
 }
@@ -134,6 +134,7 @@ def build_config(args, rank, world, scaling, overlap=None):
                      ("burn_in_timesteps", args.burn_in), ("nstep_target", args.nstep_target)):
         if val is not None:
             targs[key] = val
+    targs.update(spec.get("train_args", {}))        # T = 1 configs: the learner step from a captured HIP graph
     for kv in args.train_arg:
         k, v = kv.split("=", 1)
         targs[k] = json.loads(v)
@@ -741,7 +742,9 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables, overlap=None):
 
     T, P, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs["mbatch_size"]
     n = targs.get("nstep_target") or targs["nstep_train"]
+    gstep = getattr(trainer, "_gstep", None)
     res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
+               graph_step=bool(gstep is not None and gstep.get("graph") is not None),
                table=table, prof_step_ms=prof_step_ms, lib_roof=lib_roof, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
                hist_stats=hist_stats, fill_s=fill_s, rccl=rccl, overlap=bool(targs.get("overlap_acting")) and not args.no_acting)
     trainer.actors = real_actors
@@ -856,6 +859,7 @@ def main():
                 "acting_policy_forward_in_step": not args.no_acting,
                 "acting_forward_hip_graph": (not args.no_acting) and (not args.no_acting_graph),
                 "acting_overlapped_on_second_stream": res["overlap"],
+                "learner_step_hip_graph": res["graph_step"],
                 "parallelism": "dp%d (replay sharded by env, grad all-reduce)" % world + (" — ranks SHARE GPUs over gloo (--share-gpu): launcher check, not a scaling number" if args.share_gpu else ""),
                 "replay_fill_seconds": round(res["fill_s"], 2),
                 # switches that differ from what a reference json config would select on its own

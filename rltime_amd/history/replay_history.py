@@ -406,12 +406,13 @@ class ReplayHistoryBuffer(History):
             return None
         rng = None if self._device_rng else self._draw_host_rng(B)
         dev = self.device
-        slot = torch.empty(B, dtype=torch.int32, device=dev)
-        env = torch.empty(B, dtype=torch.int32, device=dev)
-        start = torch.empty(B, dtype=torch.int64, device=dev)
-        loss_start = torch.empty(B, dtype=torch.int64, device=dev)
-        weight = torch.empty(B, dtype=torch.float32, device=dev)
-        stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        new = self._buffer
+        slot = new("slot", (B,), torch.int32)
+        env = new("env", (B,), torch.int32)
+        start = new("start", (B,), torch.int64)
+        loss_start = new("loss_start", (B,), torch.int64)
+        weight = new("weight", (B,), torch.float32)
+        stats = new("stats", (2,), torch.float64, zero=True)
         self._seed += 1
         rc = check(lib.mirl_replay_sample(
             self._h, B, -1.0 if train_progress is None else float(train_progress),
@@ -425,26 +426,38 @@ class ReplayHistoryBuffer(History):
                             "stats": stats, "loss_start": loss_start}
         return self._gather(B, env, start, weight, loss_start)
 
+    def _buffer(self, name, shape, dtype, zero=False):
+        """An output tensor of a sample / gather call.  static_batches (set by a trainer that replays its learner step
+        from a captured HIP graph, training/torch_trainer.py): the SAME storage on every call — a batch then lives until
+        the next get_train_data call, which is what the synchronous loop needs (multi_step_trainer.py:245-375)."""
+        if not getattr(self, "static_batches", False):
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        cache = self.__dict__.setdefault("_static_out", {})
+        key = (name, tuple(shape), dtype)
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+        elif zero:
+            t.zero_()
+        return t
+
     def _gather(self, B, env, start, weight, loss_start=None):
         lay, dev = self._layout, self.device
         L = self.nstep_train + self.prefix_steps
         R = self._rows
         per = self._MODE == _lib.MODE_PER
-        frames = torch.empty((R, B) + lay.frame_shape, dtype=torch.uint8, device=dev)
-        extra = torch.empty((R, B, lay.extra_f32), dtype=torch.float32, device=dev) \
-            if lay.extra_f32 else None
-        state = torch.empty((R, B, lay.state_f32), dtype=torch.float32, device=dev) \
-            if lay.state_f32 else None
-        initials = torch.empty((R, B), dtype=torch.float32, device=dev) \
-            if lay.has_initials else None
-        returns = torch.empty((L, B), dtype=torch.float32, device=dev)
-        nsteps = torch.empty((L, B), dtype=torch.float32, device=dev)
-        masks = torch.empty((L, B), dtype=torch.float32, device=dev)
-        actions = torch.empty((L, B), dtype=torch.int64, device=dev)
-        policy = torch.empty((L, B, self._policy_f32), dtype=torch.float32, device=dev) \
-            if self._policy_f32 else None
-        weights = torch.empty((L, B), dtype=torch.float32, device=dev) if per else None
-        loss_idx = torch.empty((L, B, 2), dtype=torch.int64, device=dev) if per else None
+        new = self._buffer
+        frames = new("frames", (R, B) + tuple(lay.frame_shape), torch.uint8)
+        extra = new("extra", (R, B, lay.extra_f32), torch.float32) if lay.extra_f32 else None
+        state = new("state", (R, B, lay.state_f32), torch.float32) if lay.state_f32 else None
+        initials = new("initials", (R, B), torch.float32) if lay.has_initials else None
+        returns = new("returns", (L, B), torch.float32)
+        nsteps = new("nsteps", (L, B), torch.float32)
+        masks = new("masks", (L, B), torch.float32)
+        actions = new("actions", (L, B), torch.int64)
+        policy = new("policy", (L, B, self._policy_f32), torch.float32) if self._policy_f32 else None
+        weights = new("weights", (L, B), torch.float32) if per else None
+        loss_idx = new("loss_idx", (L, B, 2), torch.int64) if per else None
         out = _lib.Batch(
             frames=_ptr(frames), extra=_ptr(extra), state=_ptr(state),
             initials=_ptr(initials), returns=_ptr(returns), nsteps=_ptr(nsteps),

@@ -64,6 +64,10 @@ def _workspace(device, nbytes):
     return buf
 
 
+# Set while a learner step is being captured into a HIP graph (training/torch_trainer.py): every version-keyed cache below
+# then rebuilds its buffer IN PLACE inside the capture, so the rebuild is part of the graph and re-runs with every replay
+# (a replay moves no version counter: a cache hit at capture time would freeze that operand for good).
+REFRESH_ALWAYS = False
 _joint = {}
 
 
@@ -73,7 +77,7 @@ def joint_rows(tensors):
     key = tuple(t.data_ptr() for t in tensors)
     vers = tuple(t._version for t in tensors)
     hit = _joint.get(key)
-    if hit is not None and hit[0] == vers:
+    if hit is not None and hit[0] == vers and not REFRESH_ALWAYS:
         return hit[1]
     with torch.no_grad():
         if hit is not None and hit[1].shape[0] == sum(t.shape[0] for t in tensors):
@@ -241,7 +245,8 @@ def joint_pad8(w2):
     """(O, N) -> persistent zero-padded (8, N) copy, refreshed when w2's version counter moves."""
     key = (w2.data_ptr(), tuple(w2.shape))
     hit = _pad8.get(key)
-    if hit is not None and hit[0] == w2._version and hit[2].untyped_storage().data_ptr() == w2.untyped_storage().data_ptr():
+    if hit is not None and hit[0] == w2._version and hit[2].untyped_storage().data_ptr() == w2.untyped_storage().data_ptr() \
+            and not REFRESH_ALWAYS:
         return hit[1]
     with torch.no_grad():
         pad = hit[1] if hit is not None else torch.zeros((8, w2.shape[1]), dtype=torch.float32, device=w2.device)
@@ -259,7 +264,7 @@ def joint_blockdiag(blocks):
     key = tuple(t.data_ptr() for t in blocks)
     vers = tuple(t._version for t in blocks)
     hit = _joint.get(("bd",) + key)
-    if hit is not None and hit[0] == vers:
+    if hit is not None and hit[0] == vers and not REFRESH_ALWAYS:
         return hit[1]
     with torch.no_grad():
         out = hit[1] if hit is not None else torch.zeros((sum(t.shape[0] for t in blocks), sum(t.shape[1] for t in blocks)),

@@ -176,9 +176,15 @@ class LSTM(BaseModule):
             # no-grad passes (target net, double-Q selection, burn-in, acting): the permuted copy is a pure function of
             # the weights — kept per (storage address, version counter), rebuilt after an optimizer step / weight copy
             key = (w.data_ptr(), w._version, c, h, wd)
-            if self._w_ih_nhwc is None or self._w_ih_nhwc[0] != key:
+            from . import gemm3
+            if self._w_ih_nhwc is None or self._w_ih_nhwc[0] != key or gemm3.REFRESH_ALWAYS:
                 with torch.no_grad():
-                    self._w_ih_nhwc = (key, w.detach().view(-1, c, h, wd).permute(0, 2, 3, 1).reshape(-1, h * wd * c).contiguous())
+                    src = w.detach().view(-1, c, h, wd).permute(0, 2, 3, 1)
+                    if self._w_ih_nhwc is not None and self._w_ih_nhwc[1].shape == (w.shape[0], h * wd * c):
+                        self._w_ih_nhwc[1].view(-1, h, wd, c).copy_(src)          # in place: captured graphs keep reading this buffer
+                        self._w_ih_nhwc = (key, self._w_ih_nhwc[1])
+                    else:
+                        self._w_ih_nhwc = (key, src.reshape(-1, h * wd * c).contiguous())
             return rows, self._w_ih_nhwc[1]
         return x.reshape(-1, self.inp_size), w
 

@@ -38,7 +38,10 @@ def conv_out_size(sz, kernel, stride, padding=0, dilation=1):
 
 def set_lr(optimizer, lr):
     for g in optimizer.param_groups:
-        g["lr"] = lr
+        if isinstance(g["lr"], torch.Tensor):
+            g["lr"].fill_(lr)          # a capturable optimizer keeps its learning rate on the device (graphed learner step)
+        else:
+            g["lr"] = lr
 
 
 def make_tensor(x, device, non_blocking=False):

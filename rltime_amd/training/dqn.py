@@ -53,6 +53,10 @@ class DQN(TorchTrainer):
             return
         idx = extra_train_data["loss_indices"]
         assert losses.shape == idx.shape[:1]
+        if getattr(self, "_defer_losses", None) is not None:
+            # a learner step being captured (torch_trainer._learner_step_graphed): the priority update follows each replay
+            self._defer_losses.append((idx, losses))
+            return
         self._pre_update_losses()
         self.history_buffer.update_losses(idx, losses)
 

@@ -141,6 +141,8 @@ class MultiStepTrainer(PolicyTrainer):
                              "carry truncated n-step targets (multi_step_trainer.py:294-297 asserts against it)")
         self._init_history_buffer(history_mode, async_history, self.nstep_target, nstep_train,
                                   prefix_steps=burn_in_timesteps)
+        if getattr(self, "graph_learner_step", False):
+            self.history_buffer.static_batches = True      # batches in the same buffers every step: a captured graph reads them
         self._actors_last_update_steps = 0
         self.rnn_steps_train = rnn_steps_train or nstep_train
         assert (not burn_in_timesteps) or self.policy.is_recurrent(), \
@@ -441,6 +443,10 @@ class MultiStepTrainer(PolicyTrainer):
         flatten, targets, minibatch epochs.  bench.py times exactly this (plus
         sampling and ingest)."""
         rnn_steps_train = rnn_steps_train or nstep_train
+        if getattr(self, "_graph_step_ok", None) is not None and self._graph_step_ok(train_data, burn_in_timesteps, epochs, minibatches):
+            self._start_timer("train")
+            self._learner_step_graphed(train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap)
+            return
         self._prepare_frames(train_data)
         if burn_in_timesteps:
             train_data = self._burn_in(train_data, burn_in_timesteps, do_target_states=rnn_bootstrap)

@@ -9,7 +9,8 @@ from rltime_amd.models.torch.utils import set_lr
 class TorchTrainer(MultiStepTrainer):
     def _train(self, clip_grad=None, clip_grad_dynamic_alpha=None, adam_epsilon=1e-8,
                vf_scale_epsilon=None, apply_initial_lr=False, burn_in_full_forward=False,
-               share_online_cnn=True, share_online_projection=True, selection_advantage_only=True, **kwargs):
+               share_online_cnn=True, share_online_projection=True, selection_advantage_only=True,
+               graph_learner_step=False, **kwargs):
         """torch_trainer.py:9-44.  apply_initial_lr=False mirrors the reference,
         whose train_init ignores `lr` (Adam starts at 1e-3, SURVEY A-14)."""
         self.clip_grad = float(clip_grad) if clip_grad is not None else None
@@ -27,11 +28,24 @@ class TorchTrainer(MultiStepTrainer):
         # double-Q action selection from the dueling head's advantage stream alone (policies/dqn.py predict_selection):
         # the same arg-max, half of the selection pass's widest GEMM
         self.selection_advantage_only = selection_advantage_only
+        # graph_learner_step (not in the reference): targets -> forward / backward -> clip -> Adam of one learner step as ONE
+        # captured HIP graph (see _learner_step_graphed).  For the launch-bound T = 1 configs, where the ~150 launches of a
+        # step cost more host time than GPU time; needs static batch buffers and a capturable optimizer, so it is decided
+        # here, before train_init.  MIRL_GRAPH_STEP=0 switches it off.
+        import os
+        # ("no-capture": the same set-up — static batches, capturable Adam — with every step issued eagerly: the A/B of the tests)
+        self.graph_learner_step = bool(graph_learner_step) and os.environ.get("MIRL_GRAPH_STEP", "1") != "0"
+        self._graph_capture = graph_learner_step != "no-capture"
+        self._gstep = None
         super()._train(**kwargs)
 
     def train_init(self, lr):
         """torch_trainer.py:80-83."""
         kw = {"lr": lr} if self._apply_initial_lr else {}
+        if getattr(self, "graph_learner_step", False) and self.policy.is_cuda():
+            # the step counters and the learning rate live on the device: the update can be captured and replayed
+            dev = next(self.policy.parameters()).device
+            kw = {"lr": torch.tensor(float(kw.get("lr", 1e-3)), dtype=torch.float32, device=dev), "capturable": True}
         self.optimizer = torch.optim.Adam(self.policy.parameters(), eps=self.adam_epsilon, **kw)
 
     def set_lr(self, lr):
@@ -112,7 +126,7 @@ class TorchTrainer(MultiStepTrainer):
             coef = torch.clamp(clip / (norm + 1e-6), max=1.0)     # torch.nn.utils.clip_grad_norm_
             torch._foreach_mul_(grads, coef)
             self.value_log.log("grad_norm_clipped", norm * coef, group="train")
-        if self.policy.is_cuda():
+        if self.policy.is_cuda() and not torch.cuda.is_current_stream_capturing():
             self._check_sweeps()
         self.optimizer.step()
 
@@ -143,3 +157,99 @@ class TorchTrainer(MultiStepTrainer):
         dp = getattr(self, "data_parallel", None)
         if dp is not None:
             dp.all_reduce_gradients(self.policy)
+
+    # -- one learner step as ONE captured HIP graph -------------------------------------------------------------------
+    # The T = 1 configs (DQN + uniform replay B = 256, Rainbow-IQN B = 512) run ~150 kernels of 5-25 us per learner step:
+    # 2.16 ms per step of which 1.0 ms is GPU work (profiles/r04_bench_dqn_uniform.json) — the host's launch rate is the
+    # bound.  Everything between the gathered batch and the new weights is data-independent control flow, so it is captured
+    # once and replayed: frame conversion -> target net + selection forwards -> target kernel -> online forward -> loss kernel
+    # -> backward -> gradient norm / clip -> Adam.  Outside the graph, per step: acting (its own rollout graph), sampling and
+    # gather (host bookkeeping; they write the SAME buffers every step: History.static_batches), update_losses (its epoch
+    # stamp is a launch argument), the learning-rate fill, the logged scalars (one stack), the host counters.
+    # What a replay cannot do is run Python, so: (i) every version-keyed operand cache rebuilds inside the capture
+    # (gemm3.REFRESH_ALWAYS) and therefore with every replay; (ii) the parameters' version counters are bumped by hand after
+    # a replay (the actor's "weights unchanged" stamp reads them); (iii) the persistent-LSTM status check runs after the
+    # replay instead of inside train_batch.  The first three steps of a batch shape run eagerly (lazy library state, Adam's
+    # state tensors), the fourth is captured and replayed.  Same arithmetic, same order: bit-identical to the same set-up
+    # issued eagerly (tests/test_graph_step_gpu.py).  Against the DEFAULT eager step the trajectory differs by float32
+    # rounding only: a capturable Adam evaluates its bias corrections on the device in float32, the default one on the host
+    # in double (first loss identical, 1e-7 relative per step after that).
+    def _graph_step_ok(self, train_data, burn_in_timesteps, epochs, minibatches):
+        if not getattr(self, "graph_learner_step", False) or not self.policy.is_cuda():
+            return False
+        dp = getattr(self, "data_parallel", None)
+        return (burn_in_timesteps == 0 and epochs * minibatches == 1 and (dp is None or not dp.active) and self._ov is None
+                and self.clip_grad_dynamic_alpha is None and getattr(self.history_buffer, "static_batches", False))
+
+    @staticmethod
+    def _leaves(tree, out=None):
+        out = [] if out is None else out
+        if isinstance(tree, dict):
+            for k in sorted(tree):
+                TorchTrainer._leaves(tree[k], out)
+        elif isinstance(tree, (list, tuple)):
+            for v in tree:
+                TorchTrainer._leaves(v, out)
+        elif isinstance(tree, torch.Tensor):
+            out.append(tree)
+        return out
+
+    def _graph_step_body(self, train_data, nstep_target, rnn_steps_train, rnn_bootstrap):
+        from .multi_step_trainer import _flat
+        from rltime_amd.general.utils import deep_apply
+        self._prepare_frames(train_data)
+        self._share_online_features(train_data, nstep_target)
+        flat = deep_apply(train_data, _flat)
+        flat["targets"] = self.calc_target_values(
+            flat["returns"], flat["target_states"], flat["target_masks"], nsteps=flat["nsteps"],
+            timesteps=1 if not rnn_bootstrap else rnn_steps_train)
+        self.train_batch(flat["states"], flat["targets"], flat["policy_outputs"], flat["extra_data"], rnn_steps_train)
+
+    def _learner_step_graphed(self, train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap):
+        from rltime_amd.general.utils import quiet_gc
+        from rltime_amd.models.torch import gemm3, lstm_seq
+        st = self._gstep
+        sig = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in self._leaves(train_data))
+        if st is None or st["sig"] != sig:
+            st = self._gstep = {"sig": sig, "eager": 0, "graph": None, "logs": [], "losses": None, "data": None}
+        batch_size = train_data["returns"].shape[0] * train_data["returns"].shape[1]
+        self.get_train_indexes(batch_size, batch_size, nstep_train)          # the reference's np.random.shuffle is consumed
+        if st["graph"] is None and (st["eager"] < 3 or not self._graph_capture):
+            st["eager"] += 1
+            self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap)
+        else:
+            if st["graph"] is None:
+                logs, real_log = st["logs"], self.value_log.log
+
+                def tap(key, value, *a, **k):
+                    if isinstance(value, torch.Tensor) and value.is_cuda:
+                        logs.append((key, value, a, k))
+                    else:
+                        real_log(key, value, *a, **k)
+                self.value_log.log = tap
+                self._defer_losses = []
+                gemm3.REFRESH_ALWAYS = True
+                graph = torch.cuda.CUDAGraph()
+                try:
+                    with quiet_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap)
+                finally:
+                    gemm3.REFRESH_ALWAYS = False
+                    self.value_log.log = real_log
+                    st["losses"], self._defer_losses = self._defer_losses, None
+                st["graph"] = graph
+            st["graph"].replay()
+            for p in self.policy.parameters():                        # a replay moved the data, not the version counters
+                torch.autograd.graph.increment_version(p)
+            if st["losses"]:
+                for idx, losses in st["losses"]:
+                    self._pre_update_losses()
+                    self.history_buffer.update_losses(idx, losses)
+            if st["logs"]:
+                vals = torch.stack([v.detach().reshape(()).float() for _, v, _, _ in st["logs"]])      # one launch for all scalars
+                for i, (key, _, a, k) in enumerate(st["logs"]):
+                    self.value_log.log(key, vals[i], *a, **k)
+            self._check_sweeps()
+        self.value_log.log("batch_size", batch_size, group="train")
+        self._update_steps_trained(batch_size)
+        self.ts_learner_steps += 1
