@@ -16,12 +16,20 @@ class IQN(DQN):
         reference's order (target net, then the selection net with independent
         taus) and one fused kernel for mean-argmax / gather / rescale."""
         with torch.no_grad():
-            z_t = self.target_policy.predict(target_states, timesteps=timesteps)[0]
             sel = self.policy if self.double_q else self.target_policy
             # the selection pass only feeds argmax_a mean_N Z: with a dueling head that is the advantage stream's
             # arg-max (DQNPolicy.predict_selection) — the value-hidden half of the head's widest GEMM is skipped
             fwd = (getattr(sel, "predict_selection", None) if getattr(self, "selection_advantage_only", True) else None) or sel.predict
-            z_s = fwd(target_states, timesteps=timesteps)[0]
+            if sel is not self.target_policy and self._passes_overlap(returns.shape[0]):
+                # two different networks on the same states: the target pass on the second stream (multi_step_trainer.py
+                # _side_by_side); the target net's fractions are drawn first, as in the reference
+                def no_grad(f):
+                    with torch.no_grad():
+                        return f(target_states, timesteps=timesteps)[0]
+                z_t, z_s = self._side_by_side(lambda: no_grad(self.target_policy.predict), lambda: no_grad(fwd))
+            else:
+                z_t = self.target_policy.predict(target_states, timesteps=timesteps)[0]
+                z_s = fwd(target_states, timesteps=timesteps)[0]
             mk = self.policy.make_tensor
             return qops.q_target_iqn(z_t, z_s, mk(returns), mk(nsteps), mk(target_masks),
                                      self.gamma, self.vf_scale_epsilon)

@@ -66,8 +66,14 @@ class MultiStepTrainer(PolicyTrainer):
         todo = [(self.policy, train_data["states"])]
         if do_target_states:
             todo.append((self.target_policy, train_data["target_states"]))
-        for policy, states in todo:
-            prefix = deep_apply(deep_apply(states, lambda x: x[:P]), _flat)
+        # `states` and `target_states` of a gathered batch are two row ranges of ONE block (history.py:245-265: rows [0, L)
+        # and [n, L + n) of the same stacked arrays — in the reference too), so with n == P the row the online pass
+        # replaces (its row P) IS the row the target pass, which runs second, starts from.  The reference-pinned small
+        # trajectories (P = n = 2) only match with that order kept, so it is: the passes run side by side only when n != P.
+        prefixes = [deep_apply(deep_apply(states, lambda x: x[:P]), _flat) for _, states in todo]
+        aliased = getattr(self, "nstep_target", None) == P
+
+        def one(policy, states, prefix):
             last_rnn = policy.model.last_recurrent_layer()
             if getattr(self, "burn_in_full_forward", False) or last_rnn is None:
                 # the reference's exact call (actor_predict: whole head + a tau draw)
@@ -85,9 +91,45 @@ class MultiStepTrainer(PolicyTrainer):
                 fresh = layer.get_state(states[key]["initials"][P])
                 for name, value in fresh.items():
                     states[key][name][P] = policy.make_tensor(value)
+        rows = train_data["returns"].shape[0] * train_data["returns"].shape[1]
+        if len(todo) == 2 and todo[0][0] is not todo[1][0] and self._passes_overlap(rows) and not aliased \
+                and not getattr(self, "burn_in_full_forward", False):
+            # the online and the target net's prefix passes share nothing but the (read-only) converted frames: side by side
+            self._side_by_side(lambda: one(*todo[1], prefixes[1]), lambda: one(*todo[0], prefixes[0]))
+        else:
+            for (policy, states), prefix in zip(todo, prefixes):
+                one(policy, states, prefix)
         out = deep_apply(train_data, lambda x: x[P:])
         self._end_timer()
         return out
+
+    # -- independent no-grad passes side by side --------------------------------------------------------------------------
+    # One rank of an 8-GPU job trains 64 sequences: 5 120 rows per pass, kernels that fill a quarter to a half of the chip,
+    # and LSTM sweeps whose time is the exchange latency of 40 / 80 dependent steps whatever the batch.  The target net's
+    # and the online net's no-grad passes of a learner step — the two burn-in prefixes (multi_step_trainer.py:90-131), then
+    # the target-value pass and the double-Q selection pass (training/torch/iqn.py:15-45) — share no result, so the second
+    # of each pair runs on a second HIP stream.  Same kernels on the same operands (workspaces are per stream, the
+    # persistent sweeps' exchange buffers per call): identical results; the quantile fractions are still drawn in the
+    # reference's order (the host issues torch.rand in program order).  "auto": only where a pass is small (<= 8 192 rows);
+    # at B = 512 every kernel fills the chip and two streams only interleave.
+    def _passes_overlap(self, rows):
+        mode = getattr(self, "overlap_passes", "auto")
+        if mode in (False, None, "off") or not self.policy.is_cuda() or self._ov is not None:
+            return False
+        return mode is True or mode == "on" or rows <= 8192
+
+    def _side_by_side(self, on_side, on_main):
+        """Run on_side() on the second stream while on_main() runs on the current one; returns their results."""
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_pass_stream", None)
+        if side is None:
+            side = self._pass_stream = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            a = on_side()
+        b = on_main()
+        main.wait_stream(side)
+        return a, b
 
     def _init_history_buffer(self, mode, async_history, nstep_target, nstep_train, prefix_steps):
         """multi_step_trainer.py:133-150.  async_history is refused: the
@@ -111,10 +153,12 @@ class MultiStepTrainer(PolicyTrainer):
     def _train(self, gamma, nstep_train, lr, history_mode, mbatch_size=None, nstep_target=None,
                lr_anneal=False, epochs=1, minibatches=1, warmup_steps=0,
                actor_update_frequency_steps=1000, burn_in_timesteps=0, rnn_steps_train=None,
-               rnn_bootstrap=False, async_history=False, overlap_acting=False, global_sampling=False):
+               rnn_bootstrap=False, async_history=False, overlap_acting=False, global_sampling=False,
+               overlap_passes="auto"):
         """multi_step_trainer.py:152-379.  overlap_acting (not in the reference): run the
         acting + ingest of iteration k+1 on a second HIP stream while iteration k trains
         (see _loop_iteration_overlapped)."""
+        self.overlap_passes = overlap_passes      # "auto" | True | False: independent no-grad passes on a second stream
         self.overlap_acting = overlap_acting     # True | "serial" (same schedule on ONE stream: race check)
         # multi-GPU + prioritized replay: sample exactly like one tree over all shards
         # (history needs device_rng=True); default: per-shard proportional + global IS weights

@@ -29,9 +29,9 @@ for w in "$@"; do
     probe32|probe256|probe32old|probe256old)
       E=${w#probe}; E=${E%old}; X=""; case $w in *old) X="MIRL_ACT_FUSED=0";; esac
       env $X timeout 300 python tools/acting_probe.py 400 --envs=$E > "$OUT/$w.json" 2> "$OUT/$w.err"; echo "$w rc=$?"; cat "$OUT/$w.json"; tail -2 "$OUT/$w.err";;
-    share8|share8old|share4|share2)
-      N=${w#share}; N=${N%old}; X=""; case $w in *old) X="MIRL_ACT_FUSED=0";; esac
-      env $X timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --mbatch $((512/N)) --envs $((256/N)) --replay-size $((1000000/N)) > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "$w rc=$?"; tail -c 400 "$OUT/bench_$w.err"
+    share8|share8old|share4|share2|share8serial|share4serial|share2serial)
+      N=${w#share}; N=${N%old}; N=${N%serial}; X=""; F=""; case $w in *old) X="MIRL_ACT_FUSED=0";; *serial) F="--train-arg overlap_passes=false";; esac
+      env $X timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline $F --mbatch $((512/N)) --envs $((256/N)) --replay-size $((1000000/N)) > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "$w rc=$?"; tail -c 400 "$OUT/bench_$w.err"
       python - "$OUT/bench_$w.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
