@@ -159,14 +159,15 @@ class FastActingStep:
         self.adv_w = torch.zeros((self.na, h1), **f32)           # advantage stream alone (need_q=False)
         self.freq = (pol.embedding_range * np.pi).contiguous() if self.iqn else None
         # the network's own kernels (csrc/actnet.hip), piece by piece where the shape is covered
-        # MIRL_ACT_FUSED: 0 = library calls only, 1 (default) = own kernels where they measured faster (the acting batch of
-        # one rank of a multi-GPU job: <= 64 envs, <= 2048 quantile rows; profiles/r05_actnet_probe.jsonl), 2 = at any size
+        # MIRL_ACT_FUSED: 0 = library calls only, 1 (default) = own kernels where they measured faster (conv layers and the
+        # quantile product at any batch; the LSTM step and the head's hidden layers at the acting batch of one rank of a
+        # multi-GPU job: <= 64 envs, <= 2048 quantile rows; profiles/r05_actnet_probe.jsonl), 2 = everything at any size
         mode = os.environ.get("MIRL_ACT_FUSED", "1")
         fused = mode != "0"
         small = mode == "2" or E <= 64
         convs = list(self.cnn.layers)
         self.f_conv = False
-        if fused and small and len(convs) == 3:
+        if fused and len(convs) == 3:          # any batch: 16-pixel tiles below ~100 frames, LDS-resident weights above
             c2, c3 = convs[1], convs[2]
             h1o, w1o = self.y1.shape[2], self.y1.shape[3]
             k2, s2 = c2.kernel_size[0], c2.stride[0]
@@ -185,11 +186,13 @@ class FastActingStep:
         D = int(self.freq.shape[0]) if self.iqn else 0
         self.f_head = fused and (mode == "2" or E * self.N <= 2048) and self.fc.in_features == H \
             and bool(lib.mirl_act_head_supported(E, self.N, H, D, h1 + hv, self.na + self.nq))
+        # the quantile product as one launch at any batch (cos features + embedding product + ReLU + feature multiply)
+        self.f_embed = fused and self.iqn and H % 16 == 0 and D % 16 == 0 and 0 < D <= 64 and E * self.N <= (1 << 24)
+        self.xq = torch.empty((E * self.N, H), **f32) if self.f_embed else None      # quantile product rows
         if self.f_head:
             parts, pitch = C.c_int32(), C.c_int32()
             check(lib.mirl_act_head_parts(h1 + hv, self.na + self.nq, C.byref(parts), C.byref(pitch)))
             self.part = torch.zeros(parts.value * E * self.N * pitch.value, **f32)
-            self.xq = torch.empty((E * self.N, H), **f32) if self.iqn else None      # quantile product rows
         if self.f_lstm:
             need = C.c_int64()
             check(lib.mirl_act_lstm_workspace_bytes(E, H, F + H, C.byref(need)))
@@ -318,31 +321,18 @@ class FastActingStep:
             check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
                   "mirl_lstm_cell_fwd")
         greedy = self.expo is None
-        if self.f_head:
+        eps_p, expo_p = (None, None) if greedy else (_p(self.eps), _p(self.expo))
+        feat = self.h
+        if self.f_embed:
+            # quantile fractions -> cos features -> embedding product + ReLU -> x features: one launch at any batch
             taus = None
-            if self.iqn and not self.in_kernel_taus:
+            if not self.in_kernel_taus:
                 taus = pol._draw_taus(E * N).contiguous()        # a test's tau_source replaces the draw
                 self._taus_keep = taus
-            hid = self.fc_w.shape[0] if self.need_q else self.h1
-            no = self.na + (self.nq if self.need_q else 0)
-            wout = self.out_w if self.need_q else self.adv_w
-            parts, pitch = C.c_int32(), C.c_int32()
-            check(lib.mirl_act_head_parts(hid, no, C.byref(parts), C.byref(pitch)))
-            x = self.h
-            if self.iqn:
-                x = self.xq
-                check(lib.mirl_act_embed(E, N, H, int(self.freq.shape[0]), _p(self.h), _p(self.freq), _p(taus), self.rng_seed, _p(self.rng_step),
-                                         _p(pol.quantile_layer.weight), _p(pol.quantile_layer.bias), _p(x), None, _stream()), "mirl_act_embed")
-            eps_p, expo_p = (None, None) if greedy else (_p(self.eps), _p(self.expo))
-            check(lib.mirl_act_head_hidden(E * N, H, hid, no, _p(x), _p(self.fc_w), _p(self.fc_b), _p(wout), _p(self.part), _stream()),
-                  "mirl_act_head_hidden")
-            check(lib.mirl_act_head_select(
-                E, N, self.A, parts.value, pitch.value, _p(self.part), _p(self.out_b), 1 if self.need_q else 0,
-                eps_p, expo_p, self.eps_min, self.rng_seed, _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()),
-                "mirl_act_head_select")
-            return
-        feat = self.h
-        if self.iqn:
+            check(lib.mirl_act_embed(E, N, H, int(self.freq.shape[0]), _p(self.h), _p(self.freq), _p(taus), self.rng_seed, _p(self.rng_step),
+                                     _p(pol.quantile_layer.weight), _p(pol.quantile_layer.bias), _p(self.xq), None, _stream()), "mirl_act_embed")
+            feat = self.xq
+        elif self.iqn:
             if self.in_kernel_taus:
                 phi = torch.empty((E * N, self.freq.shape[0]), dtype=torch.float32, device=self.dev)
                 check(lib.mirl_cos_embed_rng(E * N, self.freq.shape[0], self.rng_seed, _p(self.rng_step), _p(self.freq), _p(phi),
@@ -352,6 +342,19 @@ class FastActingStep:
             emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
             check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(emb), _stream()), "mirl_iqn_mul_fwd")   # in place
             feat = emb
+        if self.f_head:
+            hid = self.fc_w.shape[0] if self.need_q else self.h1
+            no = self.na + (self.nq if self.need_q else 0)
+            wout = self.out_w if self.need_q else self.adv_w
+            parts, pitch = C.c_int32(), C.c_int32()
+            check(lib.mirl_act_head_parts(hid, no, C.byref(parts), C.byref(pitch)))
+            check(lib.mirl_act_head_hidden(E * N, H, hid, no, _p(feat), _p(self.fc_w), _p(self.fc_b), _p(wout), _p(self.part), _stream()),
+                  "mirl_act_head_hidden")
+            check(lib.mirl_act_head_select(
+                E, N, self.A, parts.value, pitch.value, _p(self.part), _p(self.out_b), 1 if self.need_q else 0,
+                eps_p, expo_p, self.eps_min, self.rng_seed, _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()),
+                "mirl_act_head_select")
+            return
         if self.need_q:
             both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
             outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]

@@ -30,6 +30,7 @@
 // A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D: col = l & 15, row = 4 (l >> 4) + i.
 #include "common.hpp"
 #include "philox.hpp"
+#include <stdlib.h>
 
 namespace mirl {
 
@@ -116,6 +117,84 @@ k_act_conv(ActConvArgs a) {
         a.y[f * a.y_frame_pitch + p * 64 + co] = v > 0.f ? v : 0.f;
       }
     }
+}
+
+// The same layers for HUNDREDS of frames (one GPU acting for all 256 envs): there the 16-row workgroups above re-read the
+// layer's weights from L2 once per tile and the CU's L1 is what bounds them (measured 40 / 31 us at 256 frames against the
+// 9 / 6 us the f32 matrix pipe needs).  Here the weights — 64 x K floats, 131 / 147 KB: they fit a CU's LDS — are staged ONCE
+// per workgroup, one persistent workgroup per CU walks the pixel tiles, and a wave's K step is one 16-byte global load of
+// its own pixel rows + two conflict-free 16-byte LDS reads per MFMA quad: the pipe, not the memory system, sets the time.
+// Workgroup = 8 waves; wave w takes tile slot w >> 1 and channel half w & 1 (16 pixels x 32 channels).
+template <int CI, int KH, int KW, int S>
+__global__ void __launch_bounds__(512)
+k_act_conv_wlds(ActConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];       // [64][K + 4]
+  constexpr int K = KH * KW * CI, WP = K + 4, NS = CI / 16, TAPS = KH * KW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  {
+    // every lane's share of the weights is requested before the first LDS write (one round trip, not PER of them)
+    constexpr int PER = 64 * (K / 4) / 512;
+    static_assert(PER * 512 == 64 * (K / 4), "weights must split evenly over the workgroup");
+    an_f4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = *(const an_f4*)(a.w + 4 * (int64_t)(tid + 512 * k));     // (col, q) = linear: rows of K floats
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int idx = tid + 512 * k, col = idx / (K / 4), q = idx - col * (K / 4);
+      *(an_f4*)(wl + col * WP + 4 * q) = v[k];
+    }
+  }
+  __syncthreads();
+  const int HW = a.Ho * a.Wo;
+  const int64_t M = (int64_t)a.frames * HW;
+  const int64_t tiles = (M + 15) / 16;
+  const int half = wave & 1;
+  const float* wb = wl + (32 * half + r) * WP + 4 * g;                 // this lane's weight rows: columns 32 half + {r, 16 + r}
+  const float bs0 = a.bias[32 * half + r], bs1 = a.bias[32 * half + 16 + r];
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + (wave >> 1); tile < tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t m0 = tile * 16;
+    int64_t m = m0 + r; if (m >= M) m = M - 1;
+    const int f = (int)(m / HW), p = (int)(m - (int64_t)f * HW), oy = p / a.Wo, ox = p - oy * a.Wo;
+    const float* xp = a.x + (((int64_t)f * a.Hi + oy * S) * a.Wi + ox * S) * CI + 4 * g;
+    an_f4 acc0 = an_f4{0.f, 0.f, 0.f, 0.f}, acc1 = an_f4{0.f, 0.f, 0.f, 0.f};
+    // the pixel rows of tap t + AHEAD are requested while tap t multiplies (a ring of AHEAD + 1 register buffers)
+    constexpr int AHEAD = 3;
+    an_f4 av[AHEAD + 1][NS];
+#pragma unroll
+    for (int t = 0; t < AHEAD && t < TAPS; ++t) {
+      const int ky = t / KW, kx = t - ky * KW;
+#pragma unroll
+      for (int c = 0; c < NS; ++c) av[t][c] = *(const an_f4*)(xp + (ky * a.Wi + kx) * CI + 16 * c);
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      if (t + AHEAD < TAPS) {
+        const int ky = (t + AHEAD) / KW, kx = (t + AHEAD) - ky * KW;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) av[(t + AHEAD) % (AHEAD + 1)][c] = *(const an_f4*)(xp + (ky * a.Wi + kx) * CI + 16 * c);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NS; ++c) {
+        const an_f4 b0 = *(const an_f4*)(wb + t * CI + 16 * c), b1 = *(const an_f4*)(wb + 16 * WP + t * CI + 16 * c);
+        AN_MFMA4(acc0, av[t % (AHEAD + 1)][c], b0);
+        AN_MFMA4(acc1, av[t % (AHEAD + 1)][c], b1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t mm = m0 + 4 * g + i;
+      if (mm < M) {
+        const int64_t ff = mm / HW, pp = mm - ff * HW;
+        float* y = a.y + ff * a.y_frame_pitch + pp * 64 + 32 * half + r;
+        const float v0 = acc0[i] + bs0, v1 = acc1[i] + bs1;
+        y[0] = v0 > 0.f ? v0 : 0.f;
+        y[16] = v1 > 0.f ? v1 : 0.f;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -527,11 +606,31 @@ extern "C" int mirl_act_conv_fwd(int32_t layer, int64_t frames, int32_t Hi, int3
   if (y_frame_pitch < (int64_t)a.Ho * a.Wo * 64 || !an_al16(x) || !an_al16(w_taps))
     return fail(MIRL_ERR_ARG, "act_conv_fwd: 16-byte aligned x / w and a frame pitch >= Ho*Wo*64 are required");
   const int64_t M = frames * a.Ho * a.Wo;
-  const int rt = M > 8192 ? 2 : 1;                           // 16-row tiles while they are what fills the chip
-  const unsigned grid = (unsigned)((M + 16 * rt - 1) / (16 * rt));
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(layer == 2 ? "k_act_conv2" : "k_act_conv3", 4.0 * ((double)frames * Hi * Wi * Ci + (double)M * 64 + 64.0 * k * k * Ci), st,
                2.0 * (double)M * 64 * k * k * Ci);
+  static const int wlds_env = getenv("MIRL_ACT_CONV_WLDS") ? atoi(getenv("MIRL_ACT_CONV_WLDS")) : 1;
+  if (M >= 6144 && wlds_env) {
+    // hundreds of frames: weights resident in LDS, one persistent workgroup per CU (k_act_conv_wlds)
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t tiles = (M + 15) / 16;
+    unsigned grid = (unsigned)((tiles + 3) / 4); if (grid > (unsigned)cus) grid = (unsigned)cus;
+    const size_t lds = sizeof(float) * 64 * (size_t)(k * k * Ci + 4);
+    static bool raised[2] = {false, false};
+    if (layer == 2) {
+      if (!raised[0]) { MIRL_HIP(hipFuncSetAttribute((const void*)k_act_conv_wlds<32, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised[0] = true; }
+      hipLaunchKernelGGL((k_act_conv_wlds<32, 4, 4, 2>), dim3(grid), dim3(512), lds, st, a);
+    } else {
+      if (!raised[1]) { MIRL_HIP(hipFuncSetAttribute((const void*)k_act_conv_wlds<64, 3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised[1] = true; }
+      hipLaunchKernelGGL((k_act_conv_wlds<64, 3, 3, 1>), dim3(grid), dim3(512), lds, st, a);
+    }
+    MIRL_LAUNCH_CHECK();
+    return MIRL_OK;
+  }
+  const int rt = M > 8192 ? 2 : 1;                           // 16-row tiles while they are what fills the chip
+  const unsigned grid = (unsigned)((M + 16 * rt - 1) / (16 * rt));
   if (layer == 2) {
     if (rt == 1) hipLaunchKernelGGL((k_act_conv<32, 4, 4, 2, 1>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_act_conv<32, 4, 4, 2, 2>), dim3(grid), dim3(256), 0, st, a);
