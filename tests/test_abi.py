@@ -156,3 +156,48 @@ def test_conv_kernel_shape_gates_are_host_logic():
     need = C.c_int64()
     assert lib.mirl_conv1_u8_wrw_scratch_floats(C.byref(need)) == 0 and need.value == 512 * (32 * 4 * 8 * 8 + 32)     # 512 slabs of 8192 weight-gradient + 32 bias-gradient sums
     assert lib.mirl_conv1_u8_wrw_scratch_floats(None) < 0                 # null out pointer: error code, no crash
+
+
+def test_acting_network_shape_gates_are_host_logic():
+    """The shape gates and workspace sizes of the acting network's kernels (include/mirl.h: mirl_act_*_supported,
+    mirl_act_head_parts, mirl_act_lstm_workspace_bytes) are pure host code: callable without a GPU; launches with bad
+    arguments are refused before anything touches a device."""
+    import ctypes as C
+    from rltime_amd._lib import lib
+    assert lib.mirl_act_conv_supported(2, 32, 64, 4, 2, 20, 20) == 1 and lib.mirl_act_conv_supported(3, 64, 64, 3, 1, 9, 9) == 1
+    for bad in [(2, 64, 64, 4, 2, 20, 20), (2, 32, 32, 4, 2, 20, 20), (3, 64, 64, 3, 2, 9, 9), (1, 4, 32, 8, 4, 84, 84), (3, 64, 64, 3, 1, 2, 9)]:
+        assert lib.mirl_act_conv_supported(*bad) == 0, bad
+    assert lib.mirl_act_lstm_supported(32, 512, 3648) == 1 and lib.mirl_act_lstm_supported(64, 64, 3200) == 1
+    for bad in [(65, 512, 3648), (32, 508, 3648), (32, 512, 3640), (0, 512, 3648)]:
+        assert lib.mirl_act_lstm_supported(*bad) == 0, bad
+    need = C.c_int64()
+    assert lib.mirl_act_lstm_workspace_bytes(32, 512, 3648, C.byref(need)) == 0
+    assert need.value >= 4 * 4 * 64 * 32 * 32 + 4 * 64                       # 4 K slices x 64 column blocks x E x 32 floats + the arrival counters
+    assert lib.mirl_act_lstm_workspace_bytes(65, 512, 3648, C.byref(need)) < 0
+    assert lib.mirl_act_head_supported(32, 32, 512, 64, 1024, 7) == 1 and lib.mirl_act_head_supported(256, 1, 64, 0, 128, 19) == 1
+    for bad in [(32, 32, 500, 64, 1024, 7), (32, 32, 512, 80, 1024, 7), (32, 32, 512, 64, 1000, 7), (32, 32, 512, 64, 1024, 33),
+                (0, 32, 512, 64, 1024, 7), (32, 32, 192, 64, 1024, 7)]:
+        assert lib.mirl_act_head_supported(*bad) == 0, bad
+    parts, pitch = C.c_int32(), C.c_int32()
+    assert lib.mirl_act_head_parts(1024, 7, C.byref(parts), C.byref(pitch)) == 0 and (parts.value, pitch.value) == (16, 8)
+    assert lib.mirl_act_head_parts(272, 19, C.byref(parts), C.byref(pitch)) == 0 and (parts.value, pitch.value) == (5, 24)
+    assert lib.mirl_act_head_parts(0, 7, C.byref(parts), C.byref(pitch)) < 0
+    # refused before any launch: null operands / unsupported shapes
+    assert lib.mirl_act_conv_fwd(4, 1, 20, 20, None, None, None, None, 0, None) < 0
+    assert lib.mirl_act_lstm_fwd(32, 512, 3648, None, 3648, None, None, None, None, None, None, None) < 0
+    assert lib.mirl_act_head_hidden(1024, 500, 1024, 7, None, None, None, None, None, None) < 0
+    assert lib.mirl_act_head_select(32, 32, 6, 16, 8, None, None, 1, None, None, 0.0, 0, None, None, None, None) < 0
+
+
+def test_rollout_plan_refuses_before_bookkeeping():
+    """mirl_replay_ingest_plan (csrc/replay.hip): argument errors are MIRL_ERR_ARG and carry the library's code to Python
+    (MirlError.code), which is what FastActingStep.rollout's fallback keys on."""
+    from rltime_amd import _lib
+    assert _lib.MIRL_ERR_ARG == -1 and _lib.MIRL_ERR_STATE == -3
+    rc = _lib.lib.mirl_replay_ingest_plan(None, 4, 8, None, None)
+    assert rc == _lib.MIRL_ERR_ARG
+    try:
+        _lib.check(rc, "mirl_replay_ingest_plan")
+        raise AssertionError("check() must raise")
+    except _lib.MirlError as e:
+        assert e.code == _lib.MIRL_ERR_ARG

@@ -291,3 +291,48 @@ def test_synthetic_env_steps_are_a_function_of_seed_and_step():
     a.set_state(st)
     again = a.step_device(None)
     assert all(torch.equal(x, y) for x, y in zip(nxt[:3], again[:3]))
+
+
+def test_refused_rollout_plan_leaves_the_book_untouched():
+    """mirl_replay_ingest_plan is transactional (csrc/replay.hip): a call it refuses — more steps than the plan buffer was
+    sized for, an env id outside the shard — returns MIRL_ERR_ARG BEFORE the host bookkeeping moves (History.update's ring
+    heads, FIFO, free list: history.py:123-176), so per-step ingest can go on; a planned step then still lands where the
+    per-step path would have put it."""
+    from rltime_amd import _lib
+    from rltime_amd.history import PrioritizedReplayHistoryBuffer
+    E = 8
+    kw = dict(size=E * 30, train_frequency=4, nstep_target=2, nstep_train=4, prefix_steps=2, gamma=0.99, device_rng=True,
+              keep_policy_outputs=False, alpha=0.9, beta=0.6)
+    bufs = [PrioritizedReplayHistoryBuffer(**kw), PrioritizedReplayHistoryBuffer(**kw)]
+    example = {"x": np.zeros((4, 84, 84), np.uint8)}
+    for b in bufs:
+        b.configure(example, E, 0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def step():
+        return (torch.randint(0, 256, (E, 4, 84, 84), dtype=torch.uint8, device="cuda", generator=g),
+                torch.randint(0, 6, (E,), dtype=torch.int32, device="cuda", generator=g),
+                torch.randn(E, device="cuda", generator=g), (torch.rand(E, device="cuda", generator=g) < 0.1).to(torch.uint8))
+    steps = [step() for _ in range(12)]
+    a, b = bufs
+    a.plan_ingest(4, E)                                        # sizes the plan buffer: 64 steps of E transitions
+    for k in range(4):
+        a.ingest_planned(k, *steps[k])
+    before = a.stats()
+    for bad in (lambda: a.plan_ingest(100, E), lambda: a.plan_ingest(4, E, env_ids=np.arange(E) + 1)):
+        with pytest.raises(_lib.MirlError) as err:
+            bad()
+        assert err.value.code == _lib.MIRL_ERR_ARG
+        assert a.stats() == before
+    for k in range(4, 12):                                     # per-step ingest goes on after the refusals
+        a.update_batch(*steps[k])
+    for k in range(12):
+        b.update_batch(*steps[k])
+    assert a.stats() == b.stats()
+    for x, y in zip(a.tree_nodes(), b.tree_nodes()):
+        assert np.array_equal(x, y)
+    a._seed = b._seed = 5
+    ba, bb = a.get_train_data(4, 0.5), b.get_train_data(4, 0.5)
+    assert torch.equal(ba["states"]["x"], bb["states"]["x"]) and torch.equal(ba["returns"], bb["returns"])
+    for buf in bufs:
+        buf.close()
