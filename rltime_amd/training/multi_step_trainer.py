@@ -114,7 +114,8 @@ class MultiStepTrainer(PolicyTrainer):
     # at B = 512 every kernel fills the chip and two streams only interleave.
     def _passes_overlap(self, rows):
         mode = getattr(self, "overlap_passes", "auto")
-        if mode in (False, None, "off") or not self.policy.is_cuda() or self._ov is not None:
+        on_gpu = getattr(self.policy, "is_cuda", None)        # (a bare plugin policy without the method: one stream)
+        if mode in (False, None, "off") or on_gpu is None or not on_gpu() or getattr(self, "_ov", None) is not None:
             return False
         return mode is True or mode == "on" or rows <= 8192
 
