@@ -1,5 +1,5 @@
 """Correctness + time of csrc/gemm3.hip against the float64 product and the library f32 GEMM.
-usage: python tools/gemm3_probe.py [layout:MxNxK ...]   (layout in nt, nn, tn)"""
+usage: python tools/gemm3_probe.py [layout:MxNxK ...]   (layout in nt, nn, tn; also qp:RxNxK:n and head:MxNxK:O)"""
 import json
 import sys
 import os
@@ -54,12 +54,38 @@ def quantile_product_probe(spec, g):
     torch.cuda.empty_cache()
 
 
+def head_probe(spec, g):
+    """head:MxNxK:O — relu(x @ w^T + b) and the O output units behind it in one launch (mirl_gemm3_nt_head), with and
+    without the hidden activation written, timed beside the plain NT product of the same shape."""
+    _, dims, o = spec.split(":")
+    M, N, K = (int(v) for v in dims.split("x"))
+    O = int(o)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.05
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    w2 = torch.randn(O, N, device="cuda", generator=g) * 0.05
+    b2 = torch.randn(O, device="cuda", generator=g)
+    rec = {"layout": "nt_head", "M": M, "N": N, "K": K, "O": O, "supported": bool(gemm3.head_supported(x, w, b, w2))}
+    if rec["supported"]:
+        flop = 2.0 * M * N * K
+        rec["ms_plain_nt"] = round(timed(lambda: gemm3.gemm(gemm3.NT, x, w, bias=b, relu=True), 20), 4)
+        for keep in (False, True):
+            t = timed(lambda: gemm3.linear_relu_head(x, w, b, w2, b2, keep), 20)
+            rec["ms_keep%d" % keep] = round(t, 4)
+            rec["tflops_keep%d" % keep] = round(flop / t / 1e9, 1)
+    print(json.dumps(rec), flush=True)
+    torch.cuda.empty_cache()
+
+
 def main():
     specs = sys.argv[1:] or DEFAULT
     g = torch.Generator(device="cuda").manual_seed(0)
     for spec in specs:
         if spec.startswith("qp:"):
             quantile_product_probe(spec, g)
+            continue
+        if spec.startswith("head:"):
+            head_probe(spec, g)
             continue
         lay, dims = spec.split(":")
         M, N, K = (int(v) for v in dims.split("x"))
