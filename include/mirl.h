@@ -796,6 +796,21 @@ int mirl_emul_find(int64_t capacity, const double* node_value, const uint8_t* no
 int mirl_emul_seq_priority(int32_t nstep_train, double alpha, double max_weight_factor,
                            const float* loss_slots, double* value, uint8_t* kind);
 
+/* ---- the learner step's tail: global gradient norm -> clip -> Adam, in two launches (csrc/optim.hip) ----------------
+ * replaces rltime/training/torch_trainer.py:177-199 (clip_grad_norm_ + torch.optim.Adam.step(): amsgrad off, no weight
+ * decay) over `count` float32 tensors of numel[i] elements each; param / grad / exp_avg / exp_avg_sq [count] are HOST
+ * arrays of device pointers (element i of all four has the same memory layout), step [count] of device pointers to one
+ * float each (the per-parameter step counters of a capturable torch Adam: all advance by 1; the bias corrections use
+ * step[0] + 1 in float64).  coef = min(clip / (norm + 1e-6), 1) scales the gradients IN PLACE before the update
+ * (clip <= 0: no scaling); lr_dev (a device float) overrides lr when not NULL.  workspace: mirl_adam_clip_workspace_bytes,
+ * 8-byte aligned, private to the call until the stream has passed it.  norm_out (device, may be NULL) receives
+ * [norm, norm * coef].  Graph-capturable: the pointers are baked into the launches.                                  */
+int mirl_adam_clip_workspace_bytes(int32_t count, const int64_t* numel, int64_t* bytes);
+int mirl_adam_clip_step(int32_t count, float* const* param, float* const* grad, float* const* exp_avg,
+                        float* const* exp_avg_sq, float* const* step, const int64_t* numel, double lr,
+                        const float* lr_dev, double beta1, double beta2, double eps, double clip, void* workspace,
+                        int64_t workspace_bytes, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

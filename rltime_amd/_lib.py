@@ -207,6 +207,8 @@ _SIGNATURES = {
     "mirl_relu_bwd_bias_rows": [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_cos_embed": [_i64, _i32, _vp, _vp, _vp, _vp],
     "mirl_cos_embed_rng": [_i64, _i32, _u64, _vp, _vp, _vp, _vp, _vp],
+    "mirl_adam_clip_workspace_bytes": [_i32, _vp, _vp],
+    "mirl_adam_clip_step": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _f64, _f64, _f64, _f64, _vp, _i64, _vp, _vp],
     "mirl_iqn_mul_fwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "mirl_iqn_mul_bwd": [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],
     "mirl_dueling_tail_bwd": [_i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp],

@@ -7,7 +7,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../librltime_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
-UNITS="replay qmath lstm lstm_seq convert nnops acting actnet conv_in conv_mid gemm3 conv3 conv_wrw"
+UNITS="replay qmath lstm lstm_seq convert nnops acting actnet conv_in conv_mid gemm3 conv3 conv_wrw optim"
 newest_hdr=$(ls -t "$HERE"/*.h "$HERE"/*.hpp "$HERE"/../../include/*.h "$HERE/build.sh" | head -1)
 pids=()
 objs=()

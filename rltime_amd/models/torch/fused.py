@@ -33,7 +33,8 @@ _TAIL_WGRAD = os.environ.get("MIRL_TAIL_WGRAD", "1") != "0"
 _QP_EPILOGUE = os.environ.get("MIRL_QP_EPILOGUE", "1") != "0"
 _CONV3 = os.environ.get("MIRL_CONV3", "1") != "0"
 # multiply-adds below which a conv layer's forward stays on MIOpen; MIRL_CONV3_MIN_WORK=0 forces every supported shape
-_CONV3_MIN_WORK = int(os.environ.get("MIRL_CONV3_MIN_WORK", str(1 << 31)))
+# (512 frames: 35 us against 70 / 54 for MIOpen + the bias / ReLU pass, 256 frames: 33 against 54 / 41 — tools/conv3_probe.py)
+_CONV3_MIN_WORK = int(os.environ.get("MIRL_CONV3_MIN_WORK", "400000000"))
 
 
 def _lib():
@@ -465,13 +466,21 @@ class _QuantileProduct(torch.autograd.Function):
         only_placeholder = done is not None and grad.data_ptr() == fused.data_ptr() and all(s == 0 for s in grad.stride())
         if done is None or not only_placeholder:
             grad = grad.contiguous()
-            blocks = min(M, 2048)
-            d_pre = torch.empty_like(emb)
-            dx = torch.empty_like(x)
-            db = torch.empty(Cf, dtype=torch.float32, device=x.device)
-            partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
-            L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
-                                           blocks, _stream()), "mirl_iqn_mul_bwd")
+            if _pow2_quads(Cf):
+                blocks = min(M, 2048)
+                d_pre = torch.empty_like(emb)
+                dx = torch.empty_like(x)
+                db = torch.empty(Cf, dtype=torch.float32, device=x.device)
+                partial = torch.empty((blocks, Cf), dtype=torch.float32, device=x.device)
+                L.check(L.lib.mirl_iqn_mul_bwd(M, ctx.n, Cf, _p(grad), _p(emb), _p(x), _p(d_pre), _p(dx), _p(db), _p(partial),
+                                               blocks, _stream()), "mirl_iqn_mul_bwd")
+            else:
+                # feature widths the stand-alone kernel does not take (3136 = the conv stack's output without an FC layer in
+                # front of the product): only reached when no consumer ran this backward in its data-gradient GEMM
+                g3, e3 = grad.view(M, ctx.n, Cf), emb.view(M, ctx.n, Cf)
+                dx = (g3 * e3).sum(1)
+                d_pre = (g3 * x.unsqueeze(1)).masked_fill_(e3 <= 0, 0.0).view(M * ctx.n, Cf)
+                db = d_pre.sum(0)
             if done is not None:
                 d_pre += done[0]
                 dx += done[1]
@@ -484,9 +493,10 @@ class _QuantileProduct(torch.autograd.Function):
 
 def quantile_product(x, phi, weight, bias, n):
     """x (M, C), phi (M*n, D) -> (M*n, C): x[m] * relu(linear(phi))[m*n + j]   (iqn.py:82-102)."""
-    if (x.dim() == 2 and _fusable(x, phi, weight) and _pow2_quads(x.shape[1]) and x.is_contiguous()
-            and phi.is_contiguous() and not phi.requires_grad):
-        return _QuantileProduct.apply(x, phi, weight, bias, n, torch.is_grad_enabled())
+    if x.dim() == 2 and _fusable(x, phi, weight) and x.is_contiguous() and phi.is_contiguous() and not phi.requires_grad:
+        # any width the GEMM kernel's epilogue takes; the stand-alone multiply only 4 * 2^k columns
+        if _pow2_quads(x.shape[1]) or (_QP_EPILOGUE and gemm3.quantile_product_supported(x, phi, weight, bias, n)):
+            return _QuantileProduct.apply(x, phi, weight, bias, n, torch.is_grad_enabled())
     emb = linear_relu(phi, weight, bias)
     return (x.unsqueeze(1) * emb.reshape(x.shape[0], n, -1)).reshape(x.shape[0] * n, -1)
 

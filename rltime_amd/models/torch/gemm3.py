@@ -13,6 +13,11 @@ NT, NN, TN = 0, 1, 2
 # M*N*K below this stays on the library (launch-bound anyway).  MIRL_GEMM3_MIN_WORK=0 sends every product the
 # kernel takes through it (tests/test_e2e_gpu.py pins the reference trajectories that way).
 _MIN_WORK = int(os.environ.get("MIRL_GEMM3_MIN_WORK", str(1 << 31)))
+# NT / NN run one 256 x 256 output tile per workgroup over the whole K: with fewer than ~96 tiles most of the chip idles for
+# 0.104 us x K while the library's smaller tiles finish the product at ~120 TFLOP/s — 1024 x 1024 x 3136 (the 32-env acting
+# batch of the Rainbow-IQN head): 325 us here, 57 us there; break-even at M x N ~ 6e6 (profiles/r05_gemm3_small_m.jsonl).
+# Not applied when the work threshold is 0 (MIRL_GEMM3_MIN_WORK=0: everything the kernel takes goes through it).
+_MIN_AREA = int(os.environ.get("MIRL_GEMM3_MIN_AREA", "6000000"))
 _ws = {}
 
 
@@ -50,7 +55,8 @@ def supported(layout, a, b, min_work=None):
     else:
         K, M, N = a.shape[0], a.shape[1], b.shape[1]
         ok = b.shape[0] == K
-    if not ok or M * N * K < (_MIN_WORK if min_work is None else min_work):
+    floor = _MIN_WORK if min_work is None else min_work
+    if not ok or M * N * K < floor or (floor > 0 and layout != TN and M * N < _MIN_AREA):
         return False
     return bool(_lib().lib.mirl_gemm3_supported(layout, M, N, K))
 

@@ -1,5 +1,7 @@
 """TorchTrainer (reference rltime/training/torch/torch_trainer.py:6-199):
 optimizer, gradient-norm clipping, the n-step bootstrap target tail."""
+import os
+
 import torch
 
 from .multi_step_trainer import MultiStepTrainer
@@ -40,12 +42,24 @@ class TorchTrainer(MultiStepTrainer):
         super()._train(**kwargs)
 
     def train_init(self, lr):
-        """torch_trainer.py:80-83."""
+        """torch_trainer.py:80-83: Adam over the policy's parameters.  On a GPU it is `ClipAdam` — the same optimizer
+        (state, state_dict, param_groups) whose update takes the gradient clip with it in two launches
+        (csrc/optim.hip, train_batch below); MIRL_CLIP_ADAM=0 keeps torch.optim.Adam's own kernels."""
+        import os
         kw = {"lr": lr} if self._apply_initial_lr else {}
-        if getattr(self, "graph_learner_step", False) and self.policy.is_cuda():
+        graphed = getattr(self, "graph_learner_step", False) and self.policy.is_cuda()
+        if graphed:
             # the step counters and the learning rate live on the device: the update can be captured and replayed
             dev = next(self.policy.parameters()).device
-            kw = {"lr": torch.tensor(float(kw.get("lr", 1e-3)), dtype=torch.float32, device=dev), "capturable": True}
+            kw = {"lr": torch.tensor(float(kw.get("lr", 1e-3)), dtype=torch.float32, device=dev)}
+        if self.policy.is_cuda() and os.environ.get("MIRL_CLIP_ADAM", "1") != "0":
+            from rltime_amd.models.torch.optim import ClipAdam
+            self.optimizer = ClipAdam(self.policy.parameters(), eps=self.adam_epsilon, **kw)
+            return
+        if graphed:
+            # (torch's own `fused=True` form was tried here: under capture with a device learning rate its replays left the
+            # eager trajectory at the first replayed step — tools/graph_step_deviation.py — so the fallback is the for-each form)
+            kw["capturable"] = True
         self.optimizer = torch.optim.Adam(self.policy.parameters(), eps=self.adam_epsilon, **kw)
 
     def set_lr(self, lr):
@@ -117,6 +131,18 @@ class TorchTrainer(MultiStepTrainer):
             self.optimizer.zero_grad(set_to_none=True)
         self._compute_grads(*args, **kwargs)
         self._reduce_gradients()
+        opt = self.optimizer
+        if hasattr(opt, "step_clipped") and self.clip_grad_dynamic_alpha is None and opt.fused_step_ok():
+            # norm -> clip -> Adam as two launches (the clipped gradients are left in .grad like clip_grad_norm_ does)
+            if self.policy.is_cuda() and not torch.cuda.is_current_stream_capturing():
+                self._check_sweeps()
+            norms = opt.step_clipped(self.clip_grad if self.clip_grad else None)
+            self.value_log.log("grad_norm", norms[0], group="train")
+            if self.clip_grad:
+                self.value_log.log("grad_norm_clipped", norms[1], group="train")
+            return
+        if hasattr(opt, "why_not_fused") and os.environ.get("MIRL_CLIP_ADAM_WHY") == "1":
+            print("ClipAdam not used:", "dynamic clip" if self.clip_grad_dynamic_alpha is not None else opt.why_not_fused(), flush=True)
         params = [p for p in self.policy.parameters() if p.grad is not None]
         grads = [p.grad for p in params]
         norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2)), 2)

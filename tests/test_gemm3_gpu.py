@@ -376,3 +376,60 @@ def test_dueling_tail_runs_the_feature_products_backward(monkeypatch, second_con
         out[mode] = [xx.grad] + [p.grad for p in pq] + [p.grad for p in pt]
     for i, (got, ref) in enumerate(zip(out[True], out[False])):
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), i
+
+
+@pytest.mark.parametrize("second_consumer", [False, True])
+def test_feature_product_of_a_width_that_is_not_a_power_of_two(monkeypatch, second_consumer):
+    """The IQN head straight on the conv stack's output (no FC layer in front of the product: 3136 features in the
+    Rainbow-IQN config; 784 here): the product runs in the embedding GEMM's epilogue and its backward in the dueling
+    tail's data-gradient GEMM like the 512-wide one; a second consumer's share goes through plain tensor expressions
+    (the stand-alone kernel takes 4 * 2^k columns only).  Against the unfused expressions of iqn.py:82-102."""
+    from rltime_amd import _lib
+    from rltime_amd.models.torch import fused, gemm3
+    gen = torch.Generator(device="cuda").manual_seed(78)
+    M, n, D, Fd, H, A = 128 + 8, 32, 64, 784, 512, 6
+    x, phi, qp, tail, ga, gv = _iqn_head(gen, M, n, D, Fd, H, A)
+    side = torch.randn(M * n, Fd, device="cuda", generator=gen)
+    monkeypatch.setattr(gemm3, "_MIN_WORK", 0)
+    out = {}
+    for mode in ("fused", "plain"):
+        xx = x.clone().requires_grad_(True)
+        pq = [p.clone().requires_grad_(True) for p in qp]
+        pt = [p.clone().requires_grad_(True) for p in tail]
+        _lib.check(_lib.lib.mirl_profile_reset())
+        _lib.check(_lib.lib.mirl_profile_set(2))
+        try:
+            if mode == "fused":
+                prod = fused.quantile_product(xx, phi, pq[0], pq[1], n)
+                a, v = fused._DuelingTail.apply(prod.reshape(-1, Fd), *pt)
+            else:
+                emb = torch.relu(torch.nn.functional.linear(phi, pq[0], pq[1]))
+                prod = (xx.unsqueeze(1) * emb.view(M, n, Fd)).reshape(M * n, Fd)
+                h = torch.relu(torch.nn.functional.linear(prod, pt[0], pt[1]))
+                hv = torch.relu(torch.nn.functional.linear(prod, pt[4], pt[5]))
+                a, v = torch.nn.functional.linear(h, pt[2], pt[3]), torch.nn.functional.linear(hv, pt[6], pt[7])
+            outs, grads = [a, v], [ga, gv]
+            if second_consumer:
+                outs.append((prod * side).sum())
+                grads.append(torch.ones((), device="cuda"))
+            torch.autograd.backward(outs, grads)
+            torch.cuda.synchronize()
+            ran = {r["name"]: r["calls"] for r in _lib.profile_table()}
+        finally:
+            _lib.check(_lib.lib.mirl_profile_set(0))
+        if mode == "fused":
+            assert ran.get("k_gemm3_nt_mul") and ran.get("k_gemm3_nn_qp") and not ran.get("k_iqn_mul_bwd"), ran
+        out[mode] = [a.detach(), v.detach(), xx.grad] + [p.grad for p in pq] + [p.grad for p in pt]
+    for i, (got, ref) in enumerate(zip(out["fused"], out["plain"])):
+        # a ReLU whose pre-activation rounds to the other side of zero in one of the two paths (expected: about one of the
+        # 4.4 M hidden units here) moves ITS unit's row of dW1 / dWv and ITS sample's row of dx by one sample's term, and
+        # through that row of dx every other weight gradient by one sample's share of a 4352-sample sum: a handful of rows
+        # may leave the bar, which is 1e-4 of scale for the outputs and dx, 1e-3 for the weight gradients
+        scale = float(ref.abs().max())
+        off = (got - ref).abs() > (1e-4 if i <= 2 else 1e-3) * scale
+        bad = int(off.any(dim=-1).sum()) if off.dim() == 2 else int(off.sum())
+        assert bad <= (0 if i < 2 else 8), (i, bad)
+    with torch.no_grad():
+        again = fused.quantile_product(x, phi, qp[0], qp[1], n)
+        want = torch.relu(phi.double() @ qp[0].double().t() + qp[1].double()) * x.double().repeat_interleave(n, dim=0)
+    assert float((again.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())

@@ -11,7 +11,7 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0]))) if f else []
 steps = float(sys.argv[2])
 print("%8s %9s %9s  %s" % ("calls/st", "us/step", "avg_us", "kernel"))
-for r in rows[:40]:
+for r in rows[:70]:
     print("%8.2f %9.2f %9.2f  %s" % (int(r["Calls"]) / steps, float(r["TotalDurationNs"]) / 1e3 / steps, float(r["AverageNs"]) / 1e3, r["Name"][:100]))
 print("total us/step", sum(float(r["TotalDurationNs"]) for r in rows) / 1e3 / steps)
 PY
@@ -57,6 +57,12 @@ print("ms/step", round(d["ms_per_step"], 3), d["step_ms"], "roofline", d["roofli
 PY
       done;;
     prof)    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -70 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
+    profrainbow|profdqn)
+      c=rainbow_iqn; case $w in profdqn) c=dqn_uniform;; esac
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/${w}_stats" -o bench -- python "$R/bench.py" --config $c --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/$w.json" 2> "$R/$OUT/$w.err"); echo "$w rc=$?"; tail -c 300 "$OUT/$w.err"
+      stats "$OUT/${w}_stats" 120 | tee "$OUT/${w}_kernels.txt" | head -20
+      python tools/trace_window.py "$OUT/${w}_stats" > "$OUT/${w}_one_step_in_order.txt" 2>&1; head -150 "$OUT/${w}_one_step_in_order.txt"
+      find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$OUT/smoke.log";;
     *) echo "unknown: $w";;
   esac
