@@ -709,6 +709,11 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables, overlap=None):
 
     # ---- per-kernel pass (untimed): HIP events around every librltime_hip launch
     table, prof_step_ms = [], None
+    gstep = getattr(trainer, "_gstep", None)
+    graph_step = bool(gstep is not None and gstep.get("graph") is not None)
+    if graph_step and want_tables and args.profile_steps > 0:
+        # a replayed graph carries no per-launch events: the per-kernel passes issue the SAME step launch by launch
+        trainer._graph_capture, trainer._gstep = False, None
     if want_tables and args.profile_steps > 0:
         from rltime_amd import _lib
         _lib.check(_lib.lib.mirl_profile_reset())
@@ -742,9 +747,8 @@ def run_mode(args, scaling, rank, world, device, dp, want_tables, overlap=None):
 
     T, P, B = targs["nstep_train"], targs.get("burn_in_timesteps", 0), targs["mbatch_size"]
     n = targs.get("nstep_target") or targs["nstep_train"]
-    gstep = getattr(trainer, "_gstep", None)
     res = dict(scaling=scaling, dt=dt, step_ms=step_ms, launches=launches, gather_ms=gather_ms, acted=acted,
-               graph_step=bool(gstep is not None and gstep.get("graph") is not None),
+               graph_step=graph_step,
                table=table, prof_step_ms=prof_step_ms, lib_roof=lib_roof, T=T, P=P, n=n, B=B, rows=hist._rows, envs=envs, per=per,
                hist_stats=hist_stats, fill_s=fill_s, rccl=rccl, overlap=bool(targs.get("overlap_acting")) and not args.no_acting)
     trainer.actors = real_actors
@@ -938,6 +942,9 @@ def main():
             if overlapped["rccl"] is not None:
                 sub["rccl"] = overlapped["rccl"]
             out["overlapped_acting"] = sub
+        if res["graph_step"] and isinstance(out.get("roofline_all"), dict):
+            out["roofline_all"]["graphed_step"] = "the timed steps replay the learner step from a captured HIP graph (no per-launch events " \
+                                                  "inside a replay); the per-kernel figures here come from the same step issued launch by launch"
         if args.config == "iqn_lstm":
             out["config"]["lstm_state"] = "2x512 f32 per transition"
         if world == 1 and not args.no_cpu_baseline and args.config == "iqn_lstm":
