@@ -172,7 +172,13 @@ class DataParallel:
         for gi, group in enumerate(groups):
             lo = at
             for p in group:
-                p.grad = flat[at:at + p.numel()].view_as(p)
+                seg = flat[at:at + p.numel()]
+                if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+                    # an NHWC conv weight: the gradient gets the parameter's own element order (autograd's layout contract;
+                    # the two-launch optimizer tail walks parameter and gradient as the same flat range, csrc/optim.hip)
+                    p.grad = seg.view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+                else:
+                    p.grad = seg.view_as(p)
                 at += p.numel()
                 self._bucket_of[id(p)] = gi
             self._buckets.append({"lo": lo, "hi": at, "count": len(group), "left": len(group), "work": None, "done": False})

@@ -43,6 +43,13 @@ def _worker(rank, world, port, out):
     reduced = [p.grad.clone() for p in net.parameters()]
     # 3. lock-step guard: ready only when every rank is
     guard = (dp.all_ready(True), dp.all_ready(rank == 0), dp.all_ready(False))
+    # an NHWC conv weight's .grad view has the parameter's own element order (the optimizer kernels walk both as one flat range)
+    conv = torch.nn.Conv2d(3, 4, 2).to(memory_format=torch.channels_last)
+    dp2 = DataParallel()
+    flat2 = dp2.attach(conv)
+    assert conv.weight.grad.stride() == conv.weight.stride() != conv.weight.contiguous().stride()
+    conv(torch.randn(2, 3, 5, 5, generator=g)).sum().backward()
+    assert conv.weight.grad.untyped_storage().data_ptr() == flat2.untyped_storage().data_ptr() and float(flat2.abs().sum()) > 0
     # 2. importance weights: every rank holds a shard of priorities, samples some
     beta = 0.6
     rs = np.random.RandomState(7)

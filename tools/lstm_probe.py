@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time one LSTM sweep (T steps, B sequences, H units) three ways: persistent kernel
-(csrc/lstm_seq.hip), rocBLAS GEMM + cell kernel per step, one-launch step kernel.
+"""Time one LSTM sweep (T steps, B sequences, H units) two ways: persistent kernel
+(csrc/lstm_seq.hip) and rocBLAS GEMM + cell kernel per step.
 Prints one JSON line per variant: microseconds per time step (HIP events, 10 sweeps)."""
 import json
 import os
@@ -43,7 +43,7 @@ def main():
                     torch.cuda.synchronize()
                     total += e0.elapsed_time(e1)
                 ms = total / reps
-                if need_grad and not step and lstm_seq.lib.mirl_lstm_seq_bwd_supported(T, B, H):
+                if need_grad and pers and lstm_seq.lib.mirl_lstm_seq_bwd_supported(T, B, H):
                     out, hm, cm, c_all, _, _ = lstm_seq._forward_sweep(gates, w, h0, c0, keep, True)
                     d_out = torch.randn_like(out)
                     saved = gates.clone()

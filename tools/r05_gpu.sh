@@ -56,12 +56,16 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("ms/step", round(d["ms_per_step"], 3), d["step_ms"], "roofline", d["roofline"]["frac"], "roofline_step", (d.get("roofline_step") or {}).get("frac"))
 PY
       done;;
-    prof)    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -70 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
+    prof)    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -70 "$OUT/summary.txt"; python tools/trace_window.py "$OUT/stats" > "$OUT/headline_one_step_in_order.txt" 2>&1; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     profrainbow|profdqn)
       c=rainbow_iqn; case $w in profdqn) c=dqn_uniform;; esac
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/${w}_stats" -o bench -- python "$R/bench.py" --config $c --steps 100 --warmup 20 --no-cpu-baseline --profile-steps 0 > "$R/$OUT/$w.json" 2> "$R/$OUT/$w.err"); echo "$w rc=$?"; tail -c 300 "$OUT/$w.err"
       stats "$OUT/${w}_stats" 120 | tee "$OUT/${w}_kernels.txt" | head -20
       python tools/trace_window.py "$OUT/${w}_stats" > "$OUT/${w}_one_step_in_order.txt" 2>&1; head -150 "$OUT/${w}_one_step_in_order.txt"
+      find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
+    profshare8)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/${w}_stats" -o bench -- python "$R/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --profile-steps 0 --mbatch 64 --envs 32 --replay-size 125000 > "$R/$OUT/$w.json" 2> "$R/$OUT/$w.err"); echo "$w rc=$?"; tail -c 300 "$OUT/$w.err"
+      python tools/trace_window.py "$OUT/${w}_stats" > "$OUT/${w}_one_step_in_order.txt" 2>&1; head -3 "$OUT/${w}_one_step_in_order.txt"
       find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
     smoke)   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -3 "$OUT/smoke.log";;
     *) echo "unknown: $w";;
