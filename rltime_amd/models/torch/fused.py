@@ -140,11 +140,47 @@ def conv3_bias_relu(x, weight, bias, stride, relu=True):
     return y
 
 
+# no-grad conv layers 2-3 below the implicit GEMM's work threshold (the acting batch of the non-recurrent policies, whose
+# actor runs the generic graph): csrc/actnet.hip's kernels, one launch with bias + ReLU instead of MIOpen's fill + implicit
+# GEMM + the bias pass (32 frames: ~10 us against 25 / 19).  0: the library.
+_ACT_CONV = os.environ.get("MIRL_ACT_CONV", "1") != "0"
+
+
+def act_conv_layer(x, weight, bias, stride):
+    """2 / 3 when csrc/actnet.hip's conv kernel of that layer takes this NHWC forward as stored, else 0."""
+    if not (_ACT_CONV and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is not None
+            and x.is_contiguous(memory_format=torch.channels_last) and weight.is_contiguous(memory_format=torch.channels_last)
+            and stride[0] == stride[1] and weight.shape[2] == weight.shape[3] and bias.is_contiguous()
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and x.shape[0] > 0):
+        return 0
+    f, c, k, _ = weight.shape
+    layer = 2 if (c, k, int(stride[0])) == (32, 4, 2) else 3 if (c, k, int(stride[0])) == (64, 3, 1) else 0
+    if layer and _lib().lib.mirl_act_conv_supported(layer, c, f, k, int(stride[0]), x.shape[2], x.shape[3]):
+        return layer
+    return 0
+
+
+def act_conv_bias_relu(layer, x, weight, bias, stride):
+    L = _lib()
+    n, c, h, w = x.shape
+    f, _, k, _ = weight.shape
+    s = int(stride[0])
+    ho, wo = (h - k) // s + 1, (w - k) // s + 1
+    y = torch.empty((n, f, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    # an NHWC weight's memory IS (Co, kh, kw, Ci): the kernel's tap-major operand without a copy
+    L.check(L.lib.mirl_act_conv_fwd(layer, n, h, w, _p(x), _p(weight), _p(bias), _p(y), ho * wo * f, _stream()), "mirl_act_conv_fwd")
+    return y
+
+
 class _ConvBiasReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride):
+    def forward(ctx, x, weight, bias, stride, track=True):
+        # track = the caller's torch.is_grad_enabled(): ctx.needs_input_grad mirrors requires_grad even under no_grad
+        layer = 0
         if conv3_supported(x, weight, stride):
             y = conv3_bias_relu(x, weight, bias, stride)    # implicit GEMM on the bf16 pipe, bias + ReLU in its epilogue
+        elif not (track and any(ctx.needs_input_grad)) and (layer := act_conv_layer(x, weight, bias, stride)):
+            y = act_conv_bias_relu(layer, x, weight, bias, stride)
         else:
             y = F.conv2d(x, weight, None, stride)
             if not y.is_contiguous(memory_format=torch.channels_last):
@@ -179,7 +215,7 @@ class _ConvBiasReLU(torch.autograd.Function):
             g, x, weight, None, list(ctx.stride), [0, 0], [1, 1], False, [0, 0], 1, [need_x, need_w, False]) \
             if (need_x or need_w) else (None, None, None)
         return (dx if dx is not None else lib_dx), (dw if dw is not None else lib_dw), \
-            (db if ctx.needs_input_grad[2] else None), None
+            (db if ctx.needs_input_grad[2] else None), None, None
 
 
 _CONV2_BWD = os.environ.get("MIRL_CONV2_BWD", "1") != "0"   # 0: MIOpen data gradient for the second conv layer
@@ -282,7 +318,7 @@ def conv_bias_relu(x, conv):
     if (_fusable(x, conv.weight) and conv.bias is not None and conv.padding == (0, 0) and conv.dilation == (1, 1)
             and conv.groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and conv.weight.is_contiguous(memory_format=torch.channels_last)):
-        return _ConvBiasReLU.apply(x, conv.weight, conv.bias, tuple(conv.stride))
+        return _ConvBiasReLU.apply(x, conv.weight, conv.bias, tuple(conv.stride), torch.is_grad_enabled())
     return F.relu(conv(x))
 
 

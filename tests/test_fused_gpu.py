@@ -46,6 +46,34 @@ def test_conv_bias_relu_matches_relu_conv(n, cin, hw, cout, k, s, need_x):
     _close(res[0][3], res[1][3], "db")
 
 
+@pytest.mark.parametrize("n", [1, 32, 100])
+@pytest.mark.parametrize("cin,hw,k,s", [(32, 20, 4, 2), (64, 9, 3, 1)])
+def test_no_grad_small_batches_of_conv_2_and_3_run_on_the_acting_kernels(n, cin, hw, k, s):
+    """Under no_grad and below the implicit GEMM's work threshold (the generic actor graph of the non-recurrent policies)
+    conv layers 2-3 run on csrc/actnet.hip's kernel — the NHWC weight as stored is its tap-major operand — and give the
+    library's relu(conv(x)) to f32 rounding; with gradients enabled the stored-activation path is unchanged."""
+    from rltime_amd import _lib
+    from rltime_amd.models.torch.fused import conv_bias_relu
+    torch.manual_seed(n + cin)
+    conv = nn.Conv2d(cin, 64, k, s).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(n, cin, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+    _lib.check(_lib.lib.mirl_profile_reset())
+    _lib.check(_lib.lib.mirl_profile_set(2))
+    try:
+        with torch.no_grad():
+            y = conv_bias_relu(x, conv)
+        torch.cuda.synchronize()
+        ran = {r["name"]: r["calls"] for r in _lib.profile_table()}
+    finally:
+        _lib.check(_lib.lib.mirl_profile_set(0))
+    assert any(name.startswith("k_act_conv") for name in ran), ran
+    want = F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), s))
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    y2 = conv_bias_relu(x, conv)                                   # grad mode: MIOpen + the in-place bias / ReLU pass
+    assert y2.requires_grad and float((y2.detach() - y).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
 def test_mask_and_bias_gradient_pass_is_deterministic_and_exact():
     from rltime_amd.models.torch.fused import relu_bwd_bias_rows
     g = torch.Generator(device="cuda").manual_seed(1)
