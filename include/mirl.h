@@ -800,8 +800,8 @@ int mirl_emul_seq_priority(int32_t nstep_train, double alpha, double max_weight_
  * replaces rltime/training/torch_trainer.py:177-199 (clip_grad_norm_ + torch.optim.Adam.step(): amsgrad off, no weight
  * decay) over `count` float32 tensors of numel[i] elements each; param / grad / exp_avg / exp_avg_sq [count] are HOST
  * arrays of device pointers (element i of all four has the same memory layout), step [count] of device pointers to one
- * float each (the per-parameter step counters of a capturable torch Adam: all advance by 1; the bias corrections use
- * step[0] + 1 in float64).  coef = min(clip / (norm + 1e-6), 1) scales the gradients IN PLACE before the update
+ * float each (the per-parameter step counters of a capturable torch Adam: each advances by 1 and its tensor's bias
+ * corrections use its new value, in float64).  coef = min(clip / (norm + 1e-6), 1) scales the gradients IN PLACE before the update
  * (clip <= 0: no scaling); lr_dev (a device float) overrides lr when not NULL.  workspace: mirl_adam_clip_workspace_bytes,
  * 8-byte aligned, private to the call until the stream has passed it.  norm_out (device, may be NULL) receives
  * [norm, norm * coef].  Graph-capturable: the pointers are baked into the launches.                                  */

@@ -8,11 +8,12 @@
 // the T = 1 configs (DQN B = 256: ~1 ms per learner step) that was a quarter of the step.
 //
 //   k_adam_sqsum   one workgroup per 4096-element chunk of the gradients: sum of squares (f32 per lane over its 16
-//                  elements, f64 across the workgroup) -> partial[chunk]; workgroup 0 also latches step + 1.
+//                  elements, f64 across the workgroup) -> partial[chunk]; a tensor's first workgroup also latches that
+//                  tensor's step + 1 (torch keeps one counter per parameter: a parameter that skipped steps has its own).
 //   k_adam_update  every workgroup adds the partials in the same fixed order (f64) -> norm -> coef = min(clip /
 //                  (norm + 1e-6), 1) as clip_grad_norm_ computes it -> scales its chunk of the gradient (written back:
 //                  the reference leaves clipped gradients in .grad), updates exp_avg, exp_avg_sq and the parameter
-//                  with the bias corrections evaluated in f64 from the latched step (what the default, host-side Adam
+//                  with the bias corrections evaluated in f64 from its tensor's latched step (what the default, host-side Adam
 //                  does; a `capturable` torch Adam evaluates them in f32 on the device).
 // Tensor pointers travel by value in the kernel arguments (<= 32 tensors per launch), so a captured graph replays them
 // as they were at capture time — the .grad tensors of a captured backward have fixed addresses.  HBM-bound: 7 streams
@@ -30,12 +31,13 @@ struct AdamTensors {
   int chunk0[ADAM_MAXT + 1];       // first chunk of tensor t within this launch
   int count;
   int chunk_base;                  // this launch's first chunk in the step-wide partial array
+  int tensor_base;                 // ... and its first tensor
 };
 
 struct AdamHyper {
   double lr; const float* lr_dev; double beta1, beta2, eps, clip;
   int total_chunks;
-  double* partial;                 // [total_chunks] sums of squares, then [1] the latched step
+  double* partial;                 // [total_chunks] sums of squares, then [tensors] the latched steps
   float* norm_out;                 // [2]: norm, norm * coef (may be NULL)
 };
 
@@ -65,7 +67,7 @@ k_adam_sqsum(AdamTensors t, AdamHyper h) {
   for (int w = 128; w > 0; w >>= 1) { if (tid < w) red[tid] += red[tid + w]; __syncthreads(); }
   if (tid == 0) {
     h.partial[t.chunk_base + b] = red[0];
-    if (t.chunk_base + b == 0) h.partial[h.total_chunks] = (double)t.step[0][0] + 1.0;
+    if (b == t.chunk0[k]) h.partial[h.total_chunks + t.tensor_base + k] = (double)t.step[k][0] + 1.0;
   }
 }
 
@@ -81,7 +83,7 @@ k_adam_update(AdamTensors t, AdamHyper h) {
   const float norm = (float)sqrt(red[0]);
   float coef = 1.f;
   if (h.clip > 0.0) { coef = (float)h.clip / (norm + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
-  const double step = h.partial[h.total_chunks];
+  const double step = h.partial[h.total_chunks + t.tensor_base + k];
   const double lr = h.lr_dev ? (double)h.lr_dev[0] : h.lr;
   const double bc1 = 1.0 - pow(h.beta1, step), bc2 = 1.0 - pow(h.beta2, step);
   const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), eps = (float)h.eps;
@@ -132,7 +134,7 @@ extern "C" int mirl_adam_clip_workspace_bytes(int32_t count, const int64_t* nume
   using namespace mirl;
   if (count < 1 || !numel || !bytes) return fail(MIRL_ERR_ARG, "bad adam_clip_workspace_bytes arguments");
   for (int i = 0; i < count; ++i) if (numel[i] < 1) return fail(MIRL_ERR_ARG, "adam_clip: empty tensor");
-  *bytes = (adam_chunks(count, numel) + 1) * (int64_t)sizeof(double);
+  *bytes = (adam_chunks(count, numel) + count) * (int64_t)sizeof(double);
   return MIRL_OK;
 }
 
@@ -150,7 +152,7 @@ extern "C" int mirl_adam_clip_step(int32_t count, float* const* param, float* co
       return fail(MIRL_ERR_ARG, "adam_clip_step: null tensor / empty tensor");
   const int64_t total = adam_chunks(count, numel);
   if (total >= (1LL << 31)) return fail(MIRL_ERR_ARG, "adam_clip_step: too many elements");
-  if (workspace_bytes < (total + 1) * (int64_t)sizeof(double) || ((uintptr_t)workspace & 7))
+  if (workspace_bytes < (total + count) * (int64_t)sizeof(double) || ((uintptr_t)workspace & 7))
     return fail(MIRL_ERR_ARG, "adam_clip_step: workspace smaller than mirl_adam_clip_workspace_bytes / misaligned");
   hipStream_t st = (hipStream_t)stream;
   AdamHyper h;
@@ -165,6 +167,7 @@ extern "C" int mirl_adam_clip_step(int32_t count, float* const* param, float* co
       AdamTensors t;
       t.count = count - t0 < ADAM_MAXT ? count - t0 : ADAM_MAXT;
       t.chunk_base = chunk_base;
+      t.tensor_base = t0;
       int c = 0;
       for (int i = 0; i < t.count; ++i) {
         t.p[i] = param[t0 + i]; t.g[i] = grad[t0 + i]; t.m[i] = exp_avg[t0 + i]; t.v[i] = exp_avg_sq[t0 + i];

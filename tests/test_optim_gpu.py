@@ -37,15 +37,19 @@ def test_clip_and_adam_in_two_launches_follow_torch(clip, lr_tensor, many):
             a.grad, b.grad = g.clone(memory_format=torch.preserve_format), g.clone(memory_format=torch.preserve_format)
             if a.shape == (1, 517):                                         # a row of a wider matrix: same element order
                 a.grad = torch.cat([a.grad, a.grad], 1)[:, :517]
+        if step == 2:                                                       # a parameter that sits a step out keeps its own counter
+            mine[1].grad = ref[1].grad = None
         assert opt.fused_step_ok()
         before = [a._version for a in mine]
         norms = opt.step_clipped(clip)
-        assert all(a._version > v for a, v in zip(mine, before))           # version-keyed caches of derived weights see the update
-        want_norm = torch.linalg.vector_norm(torch.stack([b.grad.norm() for b in ref]))
+        # version-keyed caches of derived weights see the update (and only the tensors that were updated move)
+        assert all((a._version > v) == (a.grad is not None) for a, v in zip(mine, before))
+        want_norm = torch.linalg.vector_norm(torch.stack([b.grad.norm() for b in ref if b.grad is not None]))
         if clip is not None:
             coef = torch.clamp(clip / (want_norm + 1e-6), max=1.0)
             for b in ref:
-                b.grad.mul_(coef)
+                if b.grad is not None:
+                    b.grad.mul_(coef)
         opt_ref.step()
         assert abs(float(norms[0]) - float(want_norm)) <= 2e-6 * float(want_norm)
         if clip is not None:
@@ -53,9 +57,10 @@ def test_clip_and_adam_in_two_launches_follow_torch(clip, lr_tensor, many):
         for i, (a, b) in enumerate(zip(mine, ref)):
             # one rounding of the update (|lr| per element at most) on top of the parameter's own
             assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 2e-7 * (step + 1), (step, i)
-            assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max()) + 1e-12, (step, i)
+            if b.grad is not None:
+                assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max()) + 1e-12, (step, i)
             sa, sb = opt.state[a], opt_ref.state[b]
-            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            assert float(sa["step"]) == float(sb["step"]) == step + 1 - (1 if (i == 1 and step >= 2) else 0)
             assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 2e-6 * float(sb["exp_avg"].abs().max())
             assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 2e-6 * float(sb["exp_avg_sq"].abs().max())
 
