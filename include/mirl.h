@@ -695,7 +695,8 @@ int mirl_stack_shift(int32_t E, int32_t P, int32_t plane_bytes, const uint8_t* i
  * initials = done (the transition's stored recurrent state), rewards_out (clipped when
  * clip_rewards), dones_out (uint8), the mirl_episode_track accumulators (optional) and
  * *rng_step = step — or, with step = MIRL_STEP_ADVANCE, *rng_step + 1: the counter then lives on
- * the device alone and the call can be replayed from a captured graph.                     */
+ * the device alone and the call can be replayed from a captured graph.  H = 0: a policy
+ * without a recurrent layer (h, c, xh_tail, c_in, state_pack may then be NULL).               */
 #define MIRL_STEP_ADVANCE (~0ull)
 int mirl_actor_pre(int32_t E, int32_t H, int32_t A, const float* rewards_raw, const uint8_t* dones,
                    const int32_t* actions, const float* h, const float* c, float* xh_tail, int64_t xh_pitch,

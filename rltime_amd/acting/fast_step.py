@@ -1,4 +1,4 @@
-"""The device-resident actor's vector step for the CNN -> LSTM -> FC (dueling DQN / IQN)
+"""The device-resident actor's vector step for the CNN -> [LSTM ->] FC (DQN / IQN, dueling or not)
 policies, with the launch count cut to what the network itself needs.
 
 Reference order of one vector step (rltime/acting/actor.py:108-147): policy forward on
@@ -76,25 +76,50 @@ class IngestedSamples:
 
 class FastActingStep:
     @staticmethod
+    def _parts(pol):
+        """-> (cnn, lstm or None, the last layer's Linear, dueling) for CNN -> [LSTM ->] one Linear+ReLU policies, else None."""
+        from rltime_amd.models.torch.modules import CNN, FC, LSTM
+        model = pol.model
+        layers = list(model.layers)
+        if len(layers) == 3:
+            cnn, lstm, fc = layers
+            if not isinstance(lstm, LSTM) or not lstm.fused or lstm.lstm_cell.bias_ih is None:
+                return None
+        elif len(layers) == 2:
+            (cnn, fc), lstm = layers, None
+        else:
+            return None
+        if not (isinstance(cnn, CNN) and isinstance(fc, FC)) or model.extra_input_layer is not None:
+            return None
+        dueling = getattr(pol, "value_layer", None) is not None
+        if dueling:
+            lin = pol._fused_tail_layer()
+        else:
+            blocks = getattr(fc, "layers", None)
+            lin = blocks[0][0] if (getattr(fc, "fuse_relu", False) and blocks is not None and len(blocks) == 1 and len(blocks[0]) == 1) else None
+            if lin is not None and not (lin.weight.is_cuda and lin.weight.dtype == torch.float32 and lin.bias is not None):
+                lin = None
+        if lin is None or pol.out_layer.in_features != lin.out_features:
+            return None
+        return cnn, lstm, lin, dueling
+
+    @staticmethod
     def supports(actor):
-        """CNN (NHWC, input layer straight from uint8) -> LSTM -> one Linear+ReLU, dueling head,
-        IQN quantile layer (if any) injected before the last layer, epsilon-greedy or greedy."""
+        """CNN (NHWC, input layer straight from uint8) -> [LSTM ->] one Linear+ReLU, plain or dueling head, IQN quantile
+        layer (if any) injected before the last layer, epsilon-greedy or greedy."""
         pol = actor._policy
         try:
-            from rltime_amd.models.torch.modules import CNN, FC, LSTM
-            model = pol.model
-            if len(model.layers) != 3 or model.extra_input_layer is not None or not pol.is_cuda():
+            if not pol.is_cuda():
                 return False
-            cnn, lstm, fc = model.layers
-            if not (isinstance(cnn, CNN) and isinstance(lstm, LSTM) and isinstance(fc, FC)):
+            parts = FastActingStep._parts(pol)
+            if parts is None:
                 return False
-            if not (cnn.channels_last and cnn.direct_u8 and cnn.scale and lstm.fused and len(cnn.layers) >= 1):
+            cnn = parts[0]
+            if not (cnn.channels_last and cnn.direct_u8 and cnn.scale and len(cnn.layers) >= 1):
                 return False
-            if pol._fused_tail_layer() is None or lstm.lstm_cell.bias_ih is None:
-                return False
-            pre = model.layer_pre_processors
+            pre = pol.model.layer_pre_processors
             iqn = hasattr(pol, "num_sampling_quantiles")
-            if (iqn and set(pre) != {2}) or (not iqn and pre):
+            if (iqn and set(pre) != {len(pol.model.layers) - 1}) or (not iqn and pre):
                 return False
             expl = actor._exploration
             if expl is not None and not hasattr(expl, "_device_exponents"):
@@ -112,14 +137,16 @@ class FastActingStep:
         self.actor = actor
         self.need_q = bool(need_q)
         pol = self.pol = actor._policy
-        self.cnn, self.lstm, self.fc_layer = pol.model.layers
-        self.fc = pol._fused_tail_layer()
+        self.cnn, self.lstm, self.fc, self.dueling = self._parts(pol)
+        self.fc_layer = pol.model.layers[-1]
         self.iqn = hasattr(pol, "num_sampling_quantiles")
         self.N = pol.num_sampling_quantiles if self.iqn else 1
         dev = self.dev = pol.device()
         E = self.E = actor._num_envs
-        H = self.H = self.lstm.num_units
-        F = self.F = self.lstm.inp_size
+        # without a recurrent layer (H = 0) the head reads the conv features themselves
+        H = self.H = self.lstm.num_units if self.lstm is not None else 0
+        F = self.F = self.lstm.inp_size if self.lstm is not None else self.fc.in_features
+        W = self.W = H if self.lstm is not None else F            # width of the head's input rows
         A = self.A = actor._action_space.n
         f32 = dict(dtype=torch.float32, device=dev)
         c1 = self.cnn.layers[0]
@@ -144,16 +171,16 @@ class FastActingStep:
         self.rng_step = torch.zeros(1, dtype=torch.int64, device=dev)
         self.step_no = 0
         self.rng_seed = (int(torch.initial_seed()) ^ (int(actor._base_env_id) << 32) ^ 0xAC7) & 0x7FFFFFFFFFFFFFFF
-        cell = self.lstm.lstm_cell
-        self.bias_sum = torch.empty(4 * H, **f32)
-        self.wcat = torch.empty((4 * H, F + H), **f32)
-        h1, hv = self.fc.out_features, pol.value_hidden_layer.out_features
+        if self.lstm is not None:
+            self.bias_sum = torch.empty(4 * H, **f32)
+            self.wcat = torch.empty((4 * H, F + H), **f32)
+        h1, hv = self.fc.out_features, (pol.value_hidden_layer.out_features if self.dueling else 0)
         self.h1 = h1
         self.fc_w = torch.empty((h1 + hv, self.fc.in_features), **f32)
         self.fc_b = torch.empty(h1 + hv, **f32)
         # advantage and value outputs as ONE GEMM over the joint hidden activation: block-diagonal weights
-        self.na, self.nq = pol.out_layer.out_features, pol.value_layer.out_features
-        assert self.na == A and self.nq == 1
+        self.na, self.nq = pol.out_layer.out_features, (pol.value_layer.out_features if self.dueling else 0)
+        assert self.na == A and self.nq == (1 if self.dueling else 0)
         self.out_w = torch.zeros((self.na + self.nq, h1 + hv), **f32)
         self.out_b = torch.zeros(self.na + self.nq, **f32)
         self.adv_w = torch.zeros((self.na, h1), **f32)           # advantage stream alone (need_q=False)
@@ -167,7 +194,9 @@ class FastActingStep:
         small = mode == "2" or E <= 64
         convs = list(self.cnn.layers)
         self.f_conv = False
-        if fused and len(convs) == 3:          # any batch: 16-pixel tiles below ~100 frames, LDS-resident weights above
+        # (without a recurrent layer the features go to the head in the reference's (C, H, W) order: the shared conv path +
+        # one reordering copy, models/torch/fused.conv_bias_relu — the same kernels under no_grad)
+        if fused and len(convs) == 3 and self.lstm is not None:          # any batch: 16-pixel tiles below ~100 frames, LDS-resident weights above
             c2, c3 = convs[1], convs[2]
             h1o, w1o = self.y1.shape[2], self.y1.shape[3]
             k2, s2 = c2.kernel_size[0], c2.stride[0]
@@ -182,13 +211,13 @@ class FastActingStep:
                 self.w2p = torch.empty((64, k2 * k2 * c2.in_channels), **f32)
                 self.w3p = torch.empty((64, k3 * k3 * c3.in_channels), **f32)
                 self.conv_dims = (h1o, w1o, h2o, w2o, h3o, w3o)
-        self.f_lstm = fused and bool(lib.mirl_act_lstm_supported(E, H, F + H))
+        self.f_lstm = fused and self.lstm is not None and bool(lib.mirl_act_lstm_supported(E, H, F + H))
         D = int(self.freq.shape[0]) if self.iqn else 0
-        self.f_head = fused and (mode == "2" or E * self.N <= 2048) and self.fc.in_features == H \
-            and bool(lib.mirl_act_head_supported(E, self.N, H, D, h1 + hv, self.na + self.nq))
+        self.f_head = fused and (mode == "2" or E * self.N <= 2048) and self.fc.in_features == W and self.dueling \
+            and bool(lib.mirl_act_head_supported(E, self.N, W, D, h1 + hv, self.na + self.nq))
         # the quantile product as one launch at any batch (cos features + embedding product + ReLU + feature multiply)
-        self.f_embed = fused and self.iqn and H % 16 == 0 and D % 16 == 0 and 0 < D <= 64 and E * self.N <= (1 << 24)
-        self.xq = torch.empty((E * self.N, H), **f32) if self.f_embed else None      # quantile product rows
+        self.f_embed = fused and self.iqn and W % 16 == 0 and D % 16 == 0 and 0 < D <= 64 and E * self.N <= (1 << 24)
+        self.xq = torch.empty((E * self.N, W), **f32) if self.f_embed else None      # quantile product rows
         if self.f_head:
             parts, pitch = C.c_int32(), C.c_int32()
             check(lib.mirl_act_head_parts(h1 + hv, self.na + self.nq, C.byref(parts), C.byref(pitch)))
@@ -219,48 +248,53 @@ class FastActingStep:
         self._rollouts = {}              # (iters, keep_policy, clip, sink id) -> [calls so far, CUDAGraph or None]
         self.rollout_graphs = os.environ.get("MIRL_ROLLOUT_GRAPH", "1") != "0"
         self.rollout_eager_calls = int(os.environ.get("MIRL_ROLLOUT_EAGER_CALLS", "0"))
-        assert cell.weight_ih.shape == (4 * H, F)
+        assert self.lstm is None or self.lstm.lstm_cell.weight_ih.shape == (4 * H, F)
         # the reference's first input state: every env starts an episode (actor.py:78-89)
         self.refresh()
         self._pre(torch.zeros(E, **f32), torch.ones(E, dtype=torch.uint8, device=dev), track=False)
-        self.example = {"x": obs0[0].cpu().numpy(), "layer0_state": {},
-                        "layer1_state": {"hx": np.zeros(H, np.float32), "cx": np.zeros(H, np.float32), "initials": np.float32(1.0)},
-                        "layer2_state": {}}
+        if self.lstm is not None:
+            self.example = {"x": obs0[0].cpu().numpy(), "layer0_state": {},
+                            "layer1_state": {"hx": np.zeros(H, np.float32), "cx": np.zeros(H, np.float32), "initials": np.float32(1.0)},
+                            "layer2_state": {}}
+        else:
+            self.example = {"x": obs0[0].cpu().numpy(), "layer0_state": {}, "layer1_state": {}}
         self._capture()
 
     # -- weight-only quantities, once per get_samples call -------------------------------
     def refresh(self):
-        pol, cell, F = self.pol, self.lstm.lstm_cell, self.F
+        pol, F = self.pol, self.F
         with torch.no_grad():
-            torch.add(cell.bias_ih, cell.bias_hh, out=self.bias_sum)
-            if self.f_conv:
-                # layer 3 writes its NHWC rows straight into xh: W_ih's columns follow (same products, modules.LSTM._flat_input)
-                c2, c3 = self.cnn.layers[1], self.cnn.layers[2]
-                h3o, w3o = self.conv_dims[4], self.conv_dims[5]
-                self.wcat[:, :F].view(-1, h3o, w3o, 64).copy_(cell.weight_ih.view(-1, 64, h3o, w3o).permute(0, 2, 3, 1))
-                self.w2p.view(64, c2.kernel_size[0], c2.kernel_size[1], c2.in_channels).copy_(c2.weight.permute(0, 2, 3, 1))
-                self.w3p.view(64, c3.kernel_size[0], c3.kernel_size[1], c3.in_channels).copy_(c3.weight.permute(0, 2, 3, 1))
-            else:
-                self.wcat[:, :F].copy_(cell.weight_ih)
-            self.wcat[:, F:].copy_(cell.weight_hh)
-            self.fc_w[:self.h1].copy_(self.fc.weight)
-            self.fc_w[self.h1:].copy_(pol.value_hidden_layer.weight)
-            self.fc_b[:self.h1].copy_(self.fc.bias)
-            self.fc_b[self.h1:].copy_(pol.value_hidden_layer.bias)
+            if self.lstm is not None:
+                cell = self.lstm.lstm_cell
+                torch.add(cell.bias_ih, cell.bias_hh, out=self.bias_sum)
+                if self.f_conv:
+                    # layer 3 writes its NHWC rows straight into xh: W_ih's columns follow (same products, modules.LSTM._flat_input)
+                    c2, c3 = self.cnn.layers[1], self.cnn.layers[2]
+                    h3o, w3o = self.conv_dims[4], self.conv_dims[5]
+                    self.wcat[:, :F].view(-1, h3o, w3o, 64).copy_(cell.weight_ih.view(-1, 64, h3o, w3o).permute(0, 2, 3, 1))
+                    self.w2p.view(64, c2.kernel_size[0], c2.kernel_size[1], c2.in_channels).copy_(c2.weight.permute(0, 2, 3, 1))
+                    self.w3p.view(64, c3.kernel_size[0], c3.kernel_size[1], c3.in_channels).copy_(c3.weight.permute(0, 2, 3, 1))
+                else:
+                    self.wcat[:, :F].copy_(cell.weight_ih)
+                self.wcat[:, F:].copy_(cell.weight_hh)
             na = self.na
-            self.out_w[:na, :self.h1].copy_(pol.out_layer.weight)
-            self.adv_w.copy_(pol.out_layer.weight)
-            self.out_w[na:, self.h1:].copy_(pol.value_layer.weight)
-            self.out_b[:na].copy_(pol.out_layer.bias)
-            self.out_b[na:].copy_(pol.value_layer.bias)
+            # one multi-tensor copy for the head's buffers instead of a launch each (the T = 1 configs refresh every learner step)
+            dst = [self.fc_w[:self.h1], self.fc_b[:self.h1], self.out_w[:na, :self.h1], self.adv_w, self.out_b[:na]]
+            src = [self.fc.weight, self.fc.bias, pol.out_layer.weight, pol.out_layer.weight, pol.out_layer.bias]
+            if self.dueling:
+                dst += [self.fc_w[self.h1:], self.fc_b[self.h1:], self.out_w[na:, self.h1:], self.out_b[na:]]
+                src += [pol.value_hidden_layer.weight, pol.value_hidden_layer.bias, pol.value_layer.weight, pol.value_layer.bias]
+            torch._foreach_copy_(dst, [t.detach() for t in src])
 
     def set_eps(self, eps):
         self.eps.fill_(eps)
 
     # -- pieces ------------------------------------------------------------------------------
     def _pre_args(self, tr, row, clip):
-        return (self.H, self.A, _p(self.actions), _p(self.h), _p(self.c),
-                C.c_void_p(self.xh.data_ptr() + 4 * self.F), self.F + self.H, _p(self.c_in), _p(self.state_pack), _p(self.initials),
+        rec = self.H > 0
+        return (self.H, self.A, _p(self.actions), _p(self.h) if rec else None, _p(self.c) if rec else None,
+                C.c_void_p(self.xh.data_ptr() + 4 * self.F) if rec else None, self.F + self.H,
+                _p(self.c_in) if rec else None, _p(self.state_pack) if rec else None, _p(self.initials),
                 _p(self.rewards), _p(self.dones), 1 if clip else 0,
                 _p(tr.ep_reward) if tr is not None else None, _p(tr.ep_len) if tr is not None else None,
                 _p(tr.out_reward[row]) if tr is not None else None, _p(tr.out_len[row]) if tr is not None else None,
@@ -316,20 +350,21 @@ class FastActingStep:
         if self.f_lstm:
             check(lib.mirl_act_lstm_fwd(E, H, F + H, _p(self.xh), F + H, _p(self.wcat), _p(self.bias_sum), _p(self.c_in), _p(self.h),
                                         _p(self.c), _p(self.lstm_ws), _stream()), "mirl_act_lstm_fwd")
-        else:
+        elif self.lstm is not None:
             torch.addmm(self.bias_sum, self.xh, self.wcat.t(), out=self.gates)
             check(lib.mirl_lstm_cell_fwd(E, H, _p(self.gates), _p(self.c_in), None, None, None, _p(self.h), _p(self.c), _stream()),
                   "mirl_lstm_cell_fwd")
         greedy = self.expo is None
         eps_p, expo_p = (None, None) if greedy else (_p(self.eps), _p(self.expo))
-        feat = self.h
+        feat = self.h if self.lstm is not None else self.xh       # (E, W) rows
+        H = self.W                                                # from here on: the head's input width
         if self.f_embed:
             # quantile fractions -> cos features -> embedding product + ReLU -> x features: one launch at any batch
             taus = None
             if not self.in_kernel_taus:
                 taus = pol._draw_taus(E * N).contiguous()        # a test's tau_source replaces the draw
                 self._taus_keep = taus
-            check(lib.mirl_act_embed(E, N, H, int(self.freq.shape[0]), _p(self.h), _p(self.freq), _p(taus), self.rng_seed, _p(self.rng_step),
+            check(lib.mirl_act_embed(E, N, H, int(self.freq.shape[0]), _p(feat), _p(self.freq), _p(taus), self.rng_seed, _p(self.rng_step),
                                      _p(pol.quantile_layer.weight), _p(pol.quantile_layer.bias), _p(self.xq), None, _stream()), "mirl_act_embed")
             feat = self.xq
         elif self.iqn:
@@ -340,8 +375,12 @@ class FastActingStep:
             else:                                            # a test's tau_source replaces the draw
                 phi = cos_embed(pol._draw_taus(E * N), self.freq)
             emb = torch._addmm_activation(pol.quantile_layer.bias, phi, pol.quantile_layer.weight.t(), use_gelu=False)
-            check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(emb), _stream()), "mirl_iqn_mul_fwd")   # in place
+            if H % 4 == 0 and 256 % (H // 4) == 0:
+                check(lib.mirl_iqn_mul_fwd(E, N, H, _p(feat), _p(emb), _p(emb), _stream()), "mirl_iqn_mul_fwd")   # in place
+            else:
+                emb = (emb.view(E, N, H) * feat.view(E, 1, H)).view(E * N, H)
             feat = emb
+        use_val = self.need_q and self.dueling
         if self.f_head:
             hid = self.fc_w.shape[0] if self.need_q else self.h1
             no = self.na + (self.nq if self.need_q else 0)
@@ -355,7 +394,7 @@ class FastActingStep:
                 eps_p, expo_p, self.eps_min, self.rng_seed, _p(self.rng_step), _p(self.actions), _p(self.qvalues), _stream()),
                 "mirl_act_head_select")
             return
-        if self.need_q:
+        if use_val:
             both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
             outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
             pitch, val = self.na + self.nq, C.c_void_p(outs.data_ptr() + 4 * self.na)
@@ -411,7 +450,9 @@ class FastActingStep:
             self._pre(rewards if rewards.dtype == torch.float32 else rewards.float(), dones_u8, clip=clip)
         fields = None
         if sink is not None:
-            sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
+            rec = self.H > 0
+            sink.update_batch(obs, self.actions, self.rewards, self.dones, state=self.state_pack if rec else None,
+                              initials=self.initials if rec else None,
                               policy=self.qvalues if keep_policy else None, transient=True,
                               # acting-time priority init reads whole stored stacks through the verifying ingest
                               newest_plane_only=(bool(getattr(sink, "_dedup", False)) and self.trusted_stack
@@ -419,8 +460,10 @@ class FastActingStep:
         else:
             if self.env_into and obs is self.obs_buf:
                 obs = obs.clone()                 # the caller keeps it; the static block is rewritten by the next env step
-            fields = dict(frames=obs, state=self.state_pack.clone(), initials=self.initials.clone(), actions=self.actions.clone(),
+            fields = dict(frames=obs, actions=self.actions.clone(),
                           policy=self.qvalues.clone(), rewards=self.rewards.clone(), dones=self.dones.clone(), episode_stats=None)
+            if self.H > 0:
+                fields.update(state=self.state_pack.clone(), initials=self.initials.clone())
         self.last_obs = obs
         self._conv1(obs, packed=True)
         self.graph.replay()
@@ -442,7 +485,9 @@ class FastActingStep:
         self._rollouts.clear()
 
     def can_rollout(self, iters, sink):
-        return (self.rollout_graphs and self.env_into and sink is not None and iters >= 2 and self.tracker is not None
+        # (a single step too: for the T = 1 configs, whose learner step is one graph launch, the per-step path's handful of
+        # host launches per acting call is what the GPU would wait for)
+        return (self.rollout_graphs and self.env_into and sink is not None and iters >= 1 and self.tracker is not None
                 and iters <= self.tracker.ROWS and getattr(sink, "supports_planned_ingest", lambda: False)())
 
     def _rollout_body(self, iters, sink, keep_policy, clip):
@@ -452,8 +497,9 @@ class FastActingStep:
             else:
                 obs, rewards, dones = self.env_step()
                 self._pre(rewards, dones, clip=clip, row=k)
-            sink.ingest_planned(k, obs, self.actions, self.rewards, self.dones, state=self.state_pack, initials=self.initials,
-                                policy=self.qvalues if keep_policy else None)
+            rec = self.H > 0
+            sink.ingest_planned(k, obs, self.actions, self.rewards, self.dones, state=self.state_pack if rec else None,
+                                initials=self.initials if rec else None, policy=self.qvalues if keep_policy else None)
             self._conv1(obs, packed=True)
             self._body()
 

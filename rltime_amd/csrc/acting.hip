@@ -217,7 +217,8 @@ static int fill_pre(mirl::ActorPreArgs& p, int32_t E, int32_t H, int32_t A, cons
                     float* xh_tail, int64_t xh_pitch, float* c_in, float* state_pack, float* initials, float* rewards_out,
                     uint8_t* dones_out, int32_t clip_rewards, float* ep_reward, int32_t* ep_len, float* out_reward, int32_t* out_len,
                     int32_t* action_counts, uint64_t* rng_step, uint64_t step) {
-  if (E <= 0 || H <= 0 || !h || !c || !xh_tail || !c_in || !state_pack || !initials || !rewards_out ||
+  // H == 0: a policy without a recurrent layer (nothing to mask or store; the state pointers may be NULL)
+  if (E <= 0 || H < 0 || (H > 0 && (!h || !c || !xh_tail || !c_in || !state_pack)) || !initials || !rewards_out ||
       !dones_out || (ep_reward && (!ep_len || !out_reward || !out_len)))
     return mirl::fail(MIRL_ERR_ARG, "bad actor_pre arguments");
   p.H = H; p.A = A; p.actions = actions; p.h = h; p.c = c; p.xh_tail = xh_tail; p.xh_pitch = xh_pitch; p.c_in = c_in;

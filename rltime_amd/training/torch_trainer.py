@@ -265,8 +265,8 @@ class TorchTrainer(MultiStepTrainer):
                     st["losses"], self._defer_losses = self._defer_losses, None
                 st["graph"] = graph
             st["graph"].replay()
-            for p in self.policy.parameters():                        # a replay moved the data, not the version counters
-                torch.autograd.graph.increment_version(p)
+            # a replay moved the data, not the version counters
+            torch.autograd.graph.increment_version(list(self.policy.parameters()))
             if st["losses"]:
                 for idx, losses in st["losses"]:
                     self._pre_update_losses()

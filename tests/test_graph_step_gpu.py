@@ -118,13 +118,15 @@ def test_iqn_prioritized_learner_step_from_a_graph_is_the_eager_step(determinist
 
 
 def test_two_launch_adam_and_torch_adam_walk_the_same_trajectory(deterministic_library, monkeypatch):
-    """The graphed DQN step with csrc/optim.hip (norm -> clip -> Adam in two launches) against the same step with
-    torch.optim.Adam(capturable=True) + the clip as tensor ops: float32 rounding of the bias corrections apart (float64
-    here, float32 there) — the first steps to 1e-5, then the statistics of the run."""
+    """The graphed DQN step with csrc/optim.hip (norm -> clip -> Adam in two launches, bias corrections in float64) against
+    the eager step with torch.optim.Adam as the reference uses it (bias corrections on the host in double) + the clip as
+    tensor ops: the first steps to 1e-4 (what is left is the learning rate as a float32 device word against a double, and
+    the net grows a last-bit difference 2.6x per step), then the statistics of the run.  (A `capturable` torch Adam is NOT the
+    yardstick: it evaluates 1 - 0.999^step in float32, 1.3e-5 off at step 1.)"""
     a = _series("dqn", True)
     monkeypatch.setenv("MIRL_CLIP_ADAM", "0")
-    b = _series("dqn", True)
-    assert a["captured"] and b["captured"]
+    b = _series("dqn", False)
+    assert a["captured"] and not b["captured"]
     for key in ("qloss", "grad_norm"):
-        np.testing.assert_allclose(a[key][:5], b[key][:5], rtol=1e-5, err_msg=key)
+        np.testing.assert_allclose(a[key][:5], b[key][:5], rtol=1e-4, err_msg=key)
         assert abs(a[key][-50:].mean() - b[key][-50:].mean()) <= 0.35 * abs(b[key][-50:].mean()), key
