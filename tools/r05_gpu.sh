@@ -50,7 +50,7 @@ for k in d["roofline_all"]["kernels"][:14]:
 PY
       ;;
     bench)   timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_iqn_lstm.json" 2> "$OUT/bench_iqn_lstm.err"; echo "bench rc=$?"; tail -c 800 "$OUT/bench_iqn_lstm.err"; head -c 3000 "$OUT/bench_iqn_lstm.json"; echo;;
-    bench23) for c in rainbow_iqn dqn_uniform; do timeout 600 python bench.py --config $c --steps 50 --warmup 10 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"; tail -c 400 "$OUT/bench_$c.err"; python - "$OUT/bench_$c.json" <<'PY'
+    bench23) for c in rainbow_iqn dqn_uniform; do timeout 600 python bench.py --config $c --steps 200 --warmup 20 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"; tail -c 400 "$OUT/bench_$c.err"; python - "$OUT/bench_$c.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("ms/step", round(d["ms_per_step"], 3), d["step_ms"], "roofline", d["roofline"]["frac"], "roofline_step", (d.get("roofline_step") or {}).get("frac"))
