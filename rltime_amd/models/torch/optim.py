@@ -50,6 +50,11 @@ class ClipAdam(torch.optim.Adam):
                 return "parameter %d %s %s %s is not a packed float32 device tensor" % (i, tuple(p.shape), p.stride(), p.dtype)
             if not _dense_like(p.grad, p):
                 return "gradient %d %s %s does not share its parameter's layout %s" % (i, tuple(p.grad.shape), p.grad.stride(), p.stride())
+            st = self.state.get(p)
+            if st:       # (a state loaded from another optimizer's checkpoint: the caller then keeps torch's own step)
+                if not (_dense_like(st["exp_avg"], p) and _dense_like(st["exp_avg_sq"], p) and torch.is_tensor(st["step"])
+                        and st["step"].is_cuda and st["step"].dtype == torch.float32):
+                    return "optimizer state %d does not share its parameter's layout / device" % i
         return None
 
     @torch.no_grad()
@@ -61,8 +66,7 @@ class ClipAdam(torch.optim.Adam):
         params, grads, ms, vs, _mx, steps = [], [], [], [], [], []
         self._init_group(group, params, grads, ms, vs, _mx, steps)
         for p, m, v, s in zip(params, ms, vs, steps):
-            if not (_dense_like(m, p) and _dense_like(v, p) and s.is_cuda and s.dtype == torch.float32):
-                raise RuntimeError("ClipAdam: optimizer state does not match its parameter's layout (loaded from another optimizer?)")
+            assert _dense_like(m, p) and _dense_like(v, p) and s.is_cuda and s.dtype == torch.float32      # fused_step_ok()
         n = len(params)
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])                   # noqa: E731
         numel = (C.c_int64 * n)(*[p.numel() for p in params])

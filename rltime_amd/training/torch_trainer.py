@@ -34,7 +34,6 @@ class TorchTrainer(MultiStepTrainer):
         # captured HIP graph (see _learner_step_graphed).  For the launch-bound T = 1 configs, where the ~150 launches of a
         # step cost more host time than GPU time; needs static batch buffers and a capturable optimizer, so it is decided
         # here, before train_init.  MIRL_GRAPH_STEP=0 switches it off.
-        import os
         # ("no-capture": the same set-up — static batches, capturable Adam — with every step issued eagerly: the A/B of the tests)
         self.graph_learner_step = bool(graph_learner_step) and os.environ.get("MIRL_GRAPH_STEP", "1") != "0"
         self._graph_capture = graph_learner_step != "no-capture"
@@ -45,7 +44,6 @@ class TorchTrainer(MultiStepTrainer):
         """torch_trainer.py:80-83: Adam over the policy's parameters.  On a GPU it is `ClipAdam` — the same optimizer
         (state, state_dict, param_groups) whose update takes the gradient clip with it in two launches
         (csrc/optim.hip, train_batch below); MIRL_CLIP_ADAM=0 keeps torch.optim.Adam's own kernels."""
-        import os
         kw = {"lr": lr} if self._apply_initial_lr else {}
         graphed = getattr(self, "graph_learner_step", False) and self.policy.is_cuda()
         if graphed:
@@ -164,7 +162,6 @@ class TorchTrainer(MultiStepTrainer):
         step k+1's optimizer is enqueued and before anything of it is logged or checkpointed (policy_trainer.py checks
         again behind its own synchronisation).  MIRL_STRICT_SWEEP_CHECK=1 waits for THIS step's backward instead — no
         invalid gradient can reach the optimizer at all, at the price of a drained launch queue per step."""
-        import os
         from rltime_amd.models.torch import lstm_seq
         if os.environ.get("MIRL_STRICT_SWEEP_CHECK", "0") == "1":
             torch.cuda.current_stream().synchronize()
@@ -197,9 +194,9 @@ class TorchTrainer(MultiStepTrainer):
     # a replay (the actor's "weights unchanged" stamp reads them); (iii) the persistent-LSTM status check runs after the
     # replay instead of inside train_batch.  The first three steps of a batch shape run eagerly (lazy library state, Adam's
     # state tensors), the fourth is captured and replayed.  Same arithmetic, same order: bit-identical to the same set-up
-    # issued eagerly (tests/test_graph_step_gpu.py).  Against the DEFAULT eager step the trajectory differs by float32
-    # rounding only: a capturable Adam evaluates its bias corrections on the device in float32, the default one on the host
-    # in double (first loss identical, 1e-7 relative per step after that).
+    # issued eagerly (tests/test_graph_step_gpu.py: every loss, gradient norm and final weight of a whole run).  Against the
+    # eager step with torch.optim.Adam the trajectory differs by float32 rounding only (the learning rate is a float32 device
+    # word here, a double there; csrc/optim.hip evaluates the bias corrections in float64 like the host-side Adam does).
     def _graph_step_ok(self, train_data, burn_in_timesteps, epochs, minibatches):
         if not getattr(self, "graph_learner_step", False) or not self.policy.is_cuda():
             return False
