@@ -378,6 +378,11 @@ int mirl_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, float* gx, const float* w
                       const float* c0, const float* keep, float* out, float* c_all, float* hm, float* cm,
                       float* h_last, float* c_last, int32_t save_gates, void* workspace, void* stream);
 int mirl_lstm_seq_status(int32_t* status);
+/* Launch geometry of the forward sweep for (B, H): the workgroups that must all be resident at once, their
+ * dynamic LDS, the device's compute units and how many such workgroups one unit holds.  Two sweeps issued on
+ * two streams only make progress together when 2 x workgroups <= compute_units x per_compute_unit.        */
+int mirl_lstm_seq_fwd_grid(int32_t B, int32_t H, int32_t* workgroups, int64_t* lds_bytes, int32_t* compute_units,
+                           int32_t* per_compute_unit);
 /* The backward sweep of the same layer in ONE persistent launch (replaces the T-step loop of
  * mirl_lstm_cell_bwd + one recurrent GEMM per step): gates [T][B][4H] holds the activated gates
  * on entry and d loss / d pre-activation on exit; c_all / cm as mirl_lstm_seq_fwd wrote them,

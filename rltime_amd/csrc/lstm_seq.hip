@@ -820,6 +820,36 @@ extern "C" int mirl_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, float* gx, con
   return seq_launch<128>(a, workspace, st);
 }
 
+// The forward sweep's launch geometry (what seq_launch picks): how many workgroups must be CO-RESIDENT for the sweep's
+// exchange to make progress, their LDS, and how many of them one compute unit can hold.  Callers that want two sweeps in
+// flight at once (two streams) use it to check that both grids fit the chip together.
+extern "C" int mirl_lstm_seq_fwd_grid(int32_t B, int32_t H, int32_t* workgroups, int64_t* lds_bytes, int32_t* compute_units,
+                                      int32_t* per_compute_unit) {
+  if (!workgroups || !lds_bytes || !compute_units || !per_compute_unit || !mirl_lstm_seq_supported(2, B, H))
+    return fail(MIRL_ERR_ARG, "bad lstm_seq_fwd_grid arguments");
+  int rc = seq_init();
+  if (rc) return rc;
+  const int NCG = H / 16, nrb = (B + 63) / 64;
+  static const int narrow_env = getenv("MIRL_LSTM_SEQ_NARROW") ? atoi(getenv("MIRL_LSTM_SEQ_NARROW")) : -1;
+  const bool narrow = (narrow_env != 0) && (nrb * (H / 4) <= g_seq_cus);
+  int64_t lds;
+  if (narrow) {
+    *workgroups = nrb * (H / 4);
+    lds = (int64_t)(16 * (H + 4) + 4 * 64) * (int64_t)sizeof(float);
+  } else {
+    int ncl = g_seq_cus / NCG;
+    if (ncl > nrb) ncl = nrb;
+    *workgroups = ncl * NCG;
+    lds = (int64_t)(64 * (H + 4) + 4 * 16 * SQ_TP) * (int64_t)sizeof(float);
+  }
+  *lds_bytes = lds;
+  *compute_units = g_seq_cus;
+  int64_t per = (160 * 1024) / (lds > 0 ? lds : 1);
+  if (per > 8) per = 8;                       // 32 waves per compute unit, 4 per workgroup
+  *per_compute_unit = (int32_t)per;
+  return MIRL_OK;
+}
+
 extern "C" int mirl_lstm_seq_status(int32_t* status) {
   if (!status) return fail(MIRL_ERR_ARG, "bad lstm_seq_status arguments");
   *status = g_seq_status ? *(volatile int*)g_seq_status : 0;

@@ -1318,7 +1318,9 @@ extern "C" int mirl_replay_ingest_plan(mirl_replay* h, int32_t steps, int32_t co
     if (bytes) memcpy(buf.data() + at, src, bytes);
     return (int64_t)at;
   };
-  auto broken = [h](int code) -> int { h->book_broken = true; return code; };
+  // whatever failed, the caller sees MIRL_ERR_STATE from here on (never MIRL_ERR_ARG, which means "refused before
+  // anything moved, fall back to per-step ingest"): the message of the original failure stays in mirl_last_error()
+  auto broken = [h](int) -> int { h->book_broken = true; return MIRL_ERR_STATE; };
   for (int s = 0; s < steps; ++s) {
     rc = h->book.ingest(K, env_ids_host, h->plan);
     if (rc) { last_error_ref() = h->book.err; return broken(rc); }     // a reference assert (ring overflow, no free index): fatal anyway

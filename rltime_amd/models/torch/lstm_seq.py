@@ -63,6 +63,17 @@ def persistent_supported(T, B, H):
     return _PERSISTENT and T >= 2 and bool(lib.mirl_lstm_seq_supported(T, B, H))
 
 
+def two_sweeps_fit(B, H):
+    """Can two forward sweeps of this shape run on two streams at once?  The persistent kernel spins on peer workgroups
+    and needs its whole grid resident; two grids that do not fit the chip together would starve each other until the
+    bounded spin gives up.  True for shapes the per-step path serves (no residency assumption there)."""
+    if not (_PERSISTENT and lib.mirl_lstm_seq_supported(2, B, H)):
+        return True
+    wg, lds, cus, per = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
+    check(lib.mirl_lstm_seq_fwd_grid(B, H, C.byref(wg), C.byref(lds), C.byref(cus), C.byref(per)), "mirl_lstm_seq_fwd_grid")
+    return 2 * wg.value <= cus.value * per.value
+
+
 def _forward_sweep(gates, w, h0, c0, keep, need_grad):
     """The time loop over `gates` (T, B, 4H) = the input projection (+ biases), in place.
     Returns (out, hm, cm, c_all, h_last, c_last); hm / cm / c_all are None unless need_grad

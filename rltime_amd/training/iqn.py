@@ -20,7 +20,8 @@ class IQN(DQN):
             # the selection pass only feeds argmax_a mean_N Z: with a dueling head that is the advantage stream's
             # arg-max (DQNPolicy.predict_selection) — the value-hidden half of the head's widest GEMM is skipped
             fwd = (getattr(sel, "predict_selection", None) if getattr(self, "selection_advantage_only", True) else None) or sel.predict
-            if sel is not self.target_policy and self._passes_overlap(returns.shape[0]):
+            if sel is not self.target_policy and self._passes_overlap(
+                    returns.shape[0], returns.shape[0] // int(timesteps) if int(timesteps) >= 2 else None):
                 # two different networks on the same states: the target pass on the second stream (multi_step_trainer.py
                 # _side_by_side); the target net's fractions are drawn first, as in the reference
                 def no_grad(f):

@@ -92,7 +92,7 @@ class MultiStepTrainer(PolicyTrainer):
                 for name, value in fresh.items():
                     states[key][name][P] = policy.make_tensor(value)
         rows = train_data["returns"].shape[0] * train_data["returns"].shape[1]
-        if len(todo) == 2 and todo[0][0] is not todo[1][0] and self._passes_overlap(rows) and not aliased \
+        if len(todo) == 2 and todo[0][0] is not todo[1][0] and self._passes_overlap(rows, train_data["returns"].shape[1]) and not aliased \
                 and not getattr(self, "burn_in_full_forward", False):
             # the online and the target net's prefix passes share nothing but the (read-only) converted frames: side by side
             self._side_by_side(lambda: one(*todo[1], prefixes[1]), lambda: one(*todo[0], prefixes[0]))
@@ -112,12 +112,24 @@ class MultiStepTrainer(PolicyTrainer):
     # persistent sweeps' exchange buffers per call): identical results; the quantile fractions are still drawn in the
     # reference's order (the host issues torch.rand in program order).  "auto": only where a pass is small (<= 8 192 rows);
     # at B = 512 every kernel fills the chip and two streams only interleave.
-    def _passes_overlap(self, rows):
+    def _passes_overlap(self, rows, batch=None):
+        """batch: sequences per pass (the B of a (T, B) block).  Whatever the mode, two passes only go side by side when
+        the persistent LSTM sweeps of BOTH fit the chip together (models/torch/lstm_seq.py two_sweeps_fit): each sweep
+        spins on peer workgroups that must all be resident — at B = 512, H = 512 one sweep owns every compute unit."""
         mode = getattr(self, "overlap_passes", "auto")
         on_gpu = getattr(self.policy, "is_cuda", None)        # (a bare plugin policy without the method: one stream)
         if mode in (False, None, "off") or on_gpu is None or not on_gpu() or getattr(self, "_ov", None) is not None:
             return False
-        return mode is True or mode == "on" or rows <= 8192
+        if not (mode is True or mode == "on" or rows <= 8192):
+            return False
+        if batch:
+            from rltime_amd.models.torch import lstm_seq
+            for pol in (self.policy, self.target_policy):
+                for layer in getattr(getattr(pol, "model", None), "layers", []):
+                    units = getattr(layer, "num_units", None)
+                    if units and getattr(layer, "fused", False) and not lstm_seq.two_sweeps_fit(int(batch), int(units)):
+                        return False
+        return True
 
     def _side_by_side(self, on_side, on_main):
         """Run on_side() on the second stream while on_main() runs on the current one; returns their results."""

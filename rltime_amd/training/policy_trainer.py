@@ -194,6 +194,11 @@ class PolicyTrainer:
         if path is None:
             raise ValueError("full_checkpoints needs a directory logger (train.py --log-dir)")
         self._resolve_gpu_spans()
+        if getattr(self.policy, "is_cuda", lambda: False)():
+            import torch
+            from rltime_amd.models.torch import lstm_seq
+            torch.cuda.synchronize()
+            lstm_seq.check_status()          # weights updated from a failed sweep's gradients must not become the resume point
         resume.save(self, path)
         if self.data_parallel is not None:
             self.data_parallel.barrier()         # the checkpoint is complete only when every rank's files are

@@ -99,7 +99,15 @@ def load(trainer, base_dir):
     trainer.policy.load_state_dict(state["policy"])
     if state["target"] is not None and trainer.target_policy is not trainer.policy:
         trainer.target_policy.load_state_dict(state["target"])
+    # load_state_dict replaces param_groups wholesale, and map_location="cpu" turns a device learning rate (graphed
+    # learner step: train_init keeps it in a 0-dim device tensor that the captured update reads) into a CPU tensor that
+    # set_lr would then fill without the device ever seeing it: keep the ORIGINAL device words and fill them
+    device_lrs = [g["lr"] if (torch.is_tensor(g["lr"]) and g["lr"].is_cuda) else None for g in trainer.optimizer.param_groups]
     trainer.optimizer.load_state_dict(state["optimizer"])
+    for g, word in zip(trainer.optimizer.param_groups, device_lrs):
+        if word is not None:
+            word.fill_(float(g["lr"]))
+            g["lr"] = word
     c = state["counters"]
     trainer.steps = c["steps"]
     trainer.clock.acted, trainer.clock.trained, trainer.clock.learner_steps = c["acted"], c["trained"], c["learner_steps"]

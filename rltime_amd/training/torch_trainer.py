@@ -160,8 +160,12 @@ class TorchTrainer(MultiStepTrainer):
         enqueues about a step ahead of the GPU.  Default: wait for the event recorded after the PREVIOUS step's backward
         (the GPU still holds a whole step of queued work, so it never idles), then read: a failed step k raises before
         step k+1's optimizer is enqueued and before anything of it is logged or checkpointed (policy_trainer.py checks
-        again behind its own synchronisation).  MIRL_STRICT_SWEEP_CHECK=1 waits for THIS step's backward instead — no
-        invalid gradient can reach the optimizer at all, at the price of a drained launch queue per step."""
+        again behind its own synchronisation).  At the point of that raise step k's OWN update has already been applied
+        (the fused clip + Adam is enqueued right after this look, and a graphed step contains it): the weights and Adam
+        moments in memory are then invalid and the run must be restarted from its last checkpoint — which is intact,
+        because log rows and both kinds of checkpoint sit behind a synchronised check_status() (policy_trainer.py).
+        MIRL_STRICT_SWEEP_CHECK=1 waits for THIS step's backward instead — no invalid gradient can reach the optimizer
+        at all, at the price of a drained launch queue per step."""
         from rltime_amd.models.torch import lstm_seq
         if os.environ.get("MIRL_STRICT_SWEEP_CHECK", "0") == "1":
             torch.cuda.current_stream().synchronize()
@@ -242,6 +246,11 @@ class TorchTrainer(MultiStepTrainer):
             self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap)
         else:
             if st["graph"] is None:
+                for g in self.optimizer.param_groups:
+                    # a host learning rate would be baked into the captured update as a launch argument
+                    if not (torch.is_tensor(g["lr"]) and g["lr"].is_cuda):
+                        raise RuntimeError("graph_learner_step: the optimizer's learning rate must be a device tensor "
+                                           "(train_init creates it; a checkpoint load must keep it: training/resume.py)")
                 logs, real_log = st["logs"], self.value_log.log
 
                 def tap(key, value, *a, **k):

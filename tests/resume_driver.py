@@ -17,7 +17,18 @@ CNN = {"type": "cnn", "args": {"channels_last": True, "layers": [{"filters": 8, 
                                                                 {"filters": 8, "kernel": 3, "stride": 1}]}}
 
 
-def config(total, stop, full, overlap=False):
+def config(total, stop, full, overlap=False, graph=False):
+    cfg = _config(total, stop, full, overlap)
+    if graph:
+        # the T = 1 learner step replayed from a captured HIP graph (training/torch_trainer.py): feed-forward net, fixed
+        # clip, the learning rate a device word that lr_anneal refills every step — and that a resume must keep on the device
+        cfg["model"]["args"]["layer_configs"] = [CNN, {"type": "fc", "args": {"fc_size": 32}}]
+        t = cfg["training"]["args"]
+        t.update(nstep_train=1, burn_in_timesteps=0, rnn_bootstrap=False, clip_grad_dynamic_alpha=None, graph_learner_step=True)
+    return cfg
+
+
+def _config(total, stop, full, overlap=False):
     return {
         "acting": {"actor_envs": 8, "exploration": {"type": "epsilon_greedy", "args": {
             "eps_start": 1.0, "eps_final": 0.05, "exploration_fraction": 0.5}}},
@@ -46,12 +57,13 @@ def main():
     ap.add_argument("--resume", default=None)
     ap.add_argument("--out", required=True)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=0)
     a = ap.parse_args()
     torch.backends.cudnn.deterministic = True          # MIOpen: no atomically-accumulating solvers
     random.seed(1); np.random.seed(2); torch.manual_seed(3)   # noqa: E702
     from rltime_amd.general.loggers import DirectoryLogger
     from rltime_amd.train import train
-    series = {"qloss": [], "grad_norm": [], "steps_at": []}
+    series = {"qloss": [], "grad_norm": [], "steps_at": [], "lr": [], "lr_word": []}
 
     def hook(trainer):
         orig = trainer.value_log.log
@@ -61,10 +73,15 @@ def main():
                 series[key].append(float(value.item() if hasattr(value, "item") else value))
                 if key == "qloss":
                     series["steps_at"].append(trainer.steps)
+            if key == "lr" and kw.get("group") == "train":
+                # what the trainer set, and the word the (captured) update actually reads
+                word = trainer.optimizer.param_groups[0]["lr"]
+                series["lr"].append(float(value))
+                series["lr_word"].append([float(word), bool(torch.is_tensor(word) and word.is_cuda)])
             return orig(key, value, *args, **kw)
         trainer.value_log.log = tap
 
-    cfg = config(a.total, a.stop, bool(a.full), a.overlap)
+    cfg = config(a.total, a.stop, bool(a.full), a.overlap, bool(a.graph))
     dp, rank = None, 0
     if "WORLD_SIZE" in os.environ:
         # one rank of a torch.distributed.run launch: both ranks share GPU 0, so gloo (RCCL refuses
@@ -81,6 +98,8 @@ def main():
         logger = DirectoryLogger(os.path.join(a.log_dir, a.name), echo=False)
     trainer = train(cfg, logger, resume=a.resume, on_trainer=hook, data_parallel=dp)
     series["final_steps"] = trainer.steps
+    gstep = getattr(trainer, "_gstep", None)
+    series["graph_replayed"] = bool(gstep is not None and gstep.get("graph") is not None)
     series["param_sum"] = float(sum(p.double().sum().item() for p in trainer.policy.parameters()))
     json.dump(series, open(a.out if dp is None else a.out.replace(".json", "_rank%d.json" % rank), "w"))
     if dp is not None:

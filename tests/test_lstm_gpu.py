@@ -223,6 +223,38 @@ def test_persistent_sweep_under_uneven_load_and_back_to_back(T, B, H):
     assert st.value == 0
 
 
+def test_two_sweeps_side_by_side_only_where_both_grids_fit():
+    """The independent no-grad passes of a learner step go on two streams (multi_step_trainer.py _side_by_side); their
+    persistent sweeps spin on peer workgroups, so the pair must fit the chip together.  B = 64 (narrow form: 128
+    workgroups of ~34 KB LDS) does; B = 512 (one 135 KB workgroup per compute unit) does not, whatever
+    `overlap_passes` says — and where the pair fits, two concurrent sweeps give the results of two sequential ones."""
+    from types import SimpleNamespace
+    from rltime_amd.models.torch import lstm_seq
+    from rltime_amd.training.multi_step_trainer import MultiStepTrainer
+    assert lstm_seq.two_sweeps_fit(64, 512) and lstm_seq.two_sweeps_fit(32, 128)
+    assert not lstm_seq.two_sweeps_fit(512, 512)
+    layer = SimpleNamespace(num_units=512, fused=True)
+    pol = SimpleNamespace(is_cuda=lambda: True, model=SimpleNamespace(layers=[layer]))
+    fake = SimpleNamespace(overlap_passes=True, policy=pol, target_policy=pol, _ov=None)
+    assert MultiStepTrainer._passes_overlap(fake, 8192, 64)
+    assert not MultiStepTrainer._passes_overlap(fake, 8192, 512)          # forced on, still refused
+    assert MultiStepTrainer._passes_overlap(fake, 8192, None)             # no sequence pass involved
+    T, B, H = 16, 64, 512
+    a_in, b_in = _sweep_inputs(T, B, H, 3), _sweep_inputs(T, B, H, 4)
+    seq = [lstm_seq._forward_sweep(x[0].clone(), *x[1:], False) for x in (a_in, b_in)]
+    side = torch.cuda.Stream()
+    for _ in range(6):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pa = lstm_seq._forward_sweep(a_in[0].clone(), *a_in[1:], False)
+        pb = lstm_seq._forward_sweep(b_in[0].clone(), *b_in[1:], False)
+        torch.cuda.current_stream().wait_stream(side)
+        for got, want in ((pa, seq[0]), (pb, seq[1])):
+            assert torch.equal(got[0], want[0]) and torch.equal(got[4], want[4]) and torch.equal(got[5], want[5])
+    torch.cuda.synchronize()
+    lstm_seq.check_status()
+
+
 @pytest.mark.parametrize("T,B", [(80, 512), (9, 256), (5, 48), (33, 1024)])
 def test_persistent_backward_sweep_equals_the_per_step_path(T, B, monkeypatch):
     """mirl_lstm_seq_bwd (one launch: cell backward in registers, the recurrent contraction split by

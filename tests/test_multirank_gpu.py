@@ -1,10 +1,15 @@
 """GPU: the N>1 path of THE LOOP, executed for real — two ranks, each a full
 trainer process (device actor, its own replay shard, sampling, gather, burn-in,
 IQN targets, forward/backward, gradient all-reduce, clip + Adam, priority
-update), both on cuda:0 over gloo (RCCL refuses two ranks on one device).  The
-trainer-side code path is the one RCCL serves on a multi-GPU node:
-rltime_amd/parallel.py only uses all_reduce / broadcast; under gloo the device
-tensors are staged through the host inside DataParallel._all_reduce.
+update).  Transport (`_join`): on a box with at least as many GPUs as ranks every
+rank takes its OWN device and the group is "nccl" = RCCL over xGMI, with the gloo
+side group bench.py / rltime_amd.train use for the host-side lock-step flag — the
+bucketed async ReduceOp.AVG from autograd's hooks, the (R, 3) weight exchange and
+mirl_replay_sample_global then run over real RCCL with the same assertions.  On a
+one-GPU box both ranks share cuda:0 over gloo (RCCL refuses two ranks on one
+device): rltime_amd/parallel.py only uses all_reduce / broadcast, and under gloo
+the device tensors are staged through the host inside DataParallel._all_reduce.
+MIRL_TEST_BACKEND=gloo|nccl forces one of the two.
 
 Checked:
   (i)  the parameters are bit-identical across the ranks after every learner step
@@ -59,23 +64,39 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, out_dir, global_sampling=False):
+def _join(rank, world, port):
+    """Process group of one test rank -> (DataParallel, device index, backend name)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on these hosts (RCCL needs it)
     sys.path.insert(0, ROOT)
     import datetime
+    import torch
+    import torch.distributed as dist
+    from rltime_amd.parallel import DataParallel
+    backend = os.environ.get("MIRL_TEST_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    limit = datetime.timedelta(seconds=120)
+    if backend == "nccl":
+        assert torch.cuda.device_count() >= world, "RCCL needs one device per rank"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=limit, device_id=torch.device("cuda", rank))
+        return DataParallel(host_group=dist.new_group(backend="gloo", timeout=limit)), rank, backend
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
+    return DataParallel(), 0, backend
+
+
+def _rank_main(rank, world, port, out_dir, global_sampling=False):
     import faulthandler
     import random
     faulthandler.dump_traceback_later(240, exit=True)        # a stuck rank reports where, instead of hanging the suite
+    dp, dev, backend = _join(rank, world, port)
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from rltime_amd.general.loggers import NullLogger
     from rltime_amd.general.type_registry import get_registered_type
-    from rltime_amd.parallel import DataParallel, shard_config
+    from rltime_amd.parallel import shard_config
     from rltime_amd.train import create_actors
-    dp = DataParallel()
     cfg = shard_config(copy.deepcopy(CONFIG), rank, world, "strong")
     assert cfg["acting"]["actor_envs"] == 4 and cfg["training"]["args"]["mbatch_size"] == 4
     if global_sampling:
@@ -131,7 +152,7 @@ def _rank_main(rank, world, port, out_dir, global_sampling=False):
              hash=np.array(rec["hash"]), target_hash=np.array(rec["target_hash"]),
              w=np.stack(rec["w"]), slots=np.stack(rec["slots"]), leaf_v=np.stack(rec["leaf_v"]),
              leaf_k=np.stack(rec["leaf_k"]), active=np.array(rec["active"]), beta=np.array(rec["beta"]),
-             steps=trainer.steps)
+             steps=trainer.steps, backend=backend, overlapped=dp.buckets_overlapped)
     hist.close()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
@@ -222,20 +243,13 @@ GS_B, GS_DRAWS = 8, 6
 
 
 def _global_rank(rank, world, port, out_dir, imbalance=1.0):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    sys.path.insert(0, ROOT)
-    import datetime
     import faulthandler
     faulthandler.dump_traceback_later(240, exit=True)
+    dp, dev, backend = _join(rank, world, port)
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from rltime_amd.history import PrioritizedReplayHistoryBuffer
-    from rltime_amd.parallel import DataParallel
     from tests.golden.streams import StreamSpec, vector_steps, as_reference_samples
-    dp = DataParallel()
     E = 5
     spec = StreamSpec(seed=80 + rank, num_envs=E, frame_shape=(1, 8, 8), lstm_units=4, n_actions=4,
                       done_prob=0.05, env_base=rank * E)

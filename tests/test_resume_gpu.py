@@ -78,6 +78,35 @@ def test_resumed_run_continues_the_uninterrupted_series(tmp_path, overlap):
     print("kernels deterministic run-to-run: %s; resumed %d + %d learner steps" % (deterministic, nb, len(c["qloss"])))
 
 
+def test_resume_with_graphed_learner_step_keeps_the_device_learning_rate(tmp_path):
+    """graph_learner_step + lr_anneal: the captured Adam update reads the learning rate from a device word that set_lr
+    refills every step.  A checkpoint load (torch.load(map_location="cpu") + optimizer.load_state_dict) must leave that
+    word on the device — otherwise set_lr fills a CPU copy and every replay keeps the value it was captured with."""
+    tmp = str(tmp_path)
+    a = _run(tmp, "a", full=0, graph=1)
+    a2 = _run(tmp, "a2", full=0, graph=1)
+    b = _run(tmp, "b", stop=H, full=1, graph=1)
+    c = _run(tmp, "c", resume=os.path.join(tmp, "b"), full=0, graph=1)
+    assert a["graph_replayed"] and c["graph_replayed"]
+    nb = len(b["qloss"])
+    assert 10 < nb < len(a["qloss"]) and nb + len(c["qloss"]) == len(a["qloss"])
+    # the word the update reads follows the schedule on the device, before and after the resume
+    for run in (a, c):
+        assert all(on_dev for _, on_dev in run["lr_word"])
+        np.testing.assert_allclose([w for w, _ in run["lr_word"]], run["lr"], rtol=1e-6)
+    assert c["lr"][0] < 0.75e-3 and c["lr"][-1] < c["lr"][0]          # annealing went on after the resume
+    np.testing.assert_allclose(b["lr"] + c["lr"], a["lr"], rtol=1e-12)
+    deterministic = a["qloss"] == a2["qloss"] and a["grad_norm"] == a2["grad_norm"]
+    for key in ("qloss", "grad_norm"):
+        joined = b[key] + c[key]
+        if deterministic:
+            assert joined == a[key], key
+        else:
+            np.testing.assert_allclose(joined, a[key], rtol=1e-5, atol=1e-7, err_msg=key)
+    if deterministic:
+        assert c["param_sum"] == a["param_sum"]
+
+
 def test_two_rank_job_checkpoints_and_resumes(tmp_path):
     """A 2-rank job (torch.distributed.run, both ranks on this GPU over gloo): every rank
     writes ITS replay shard / optimizer / RNG files into the run directory rank 0 created
