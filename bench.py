@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true", help="print the N-rank launch command as JSON and exit")
     ap.add_argument("--master-port", type=int, default=None)
     ap.add_argument("--share-gpu", action="store_true", help="launcher check on a box with fewer GPUs than ranks: ranks share "
-                    "the visible GPUs (rank % device_count) and talk over gloo (RCCL refuses two ranks per device); not a scaling number")
+                    "the visible GPUs (rank %% device_count) and talk over gloo (RCCL refuses two ranks per device); not a scaling number")
     ap.add_argument("--mbatch", type=int, default=None, help="override mbatch_size (whole job under --scaling strong)")
     ap.add_argument("--nstep-train", type=int, default=None)
     ap.add_argument("--burn-in", type=int, default=None)
@@ -109,8 +109,15 @@ def parse():
     ap.add_argument("--amp", default="none", choices=["none", "bf16"], help="autocast dtype of the network (none = fp32, the parity precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
-    ap.add_argument("--cpu-linearity-check", action="store_true", help="cpu_baseline: one extra 1-thread learner step at B=64 (~20 s) "
-                    "to check the linear-in-B extrapolation from B=16 that the headline cpu_baseline figure uses")
+    ap.add_argument("--no-cpu-linearity-check", dest="cpu_linearity_check", action="store_false",
+                    help="cpu_baseline: skip the one extra 1-thread learner step at B=64 (~20 s) that checks the linear-in-B "
+                         "extrapolation from B=16 the headline cpu_baseline figure uses (on by default)")
+    ap.add_argument("--cpu-linearity-check", dest="cpu_linearity_check", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(cpu_linearity_check=True)
+    ap.add_argument("--no-other-configs", action="store_true", help="default N=1 run: skip the `other_configs` sub-records "
+                    "(BASELINE configs[1] DQN + uniform replay B=256 and configs[2] Rainbow-IQN B=512, each with its own "
+                    "gather roofline and CPU baseline)")
+    ap.add_argument("--other-steps", type=int, default=200, help="timed learner steps of each `other_configs` run (20 warm-up)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps after the timed region with per-kernel HIP events (roofline_all); 0 = skip")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen benchmarks its solvers "
                     "per conv shape instead of taking the immediate-mode pick (experiment)")
@@ -324,6 +331,125 @@ class CpuPath:
         for _ in range(reps):
             self.policy.actor_predict(act_state, 1)
         return reps * EA / (time.time() - t2)
+
+
+class CpuPathT1:
+    """The oracle's T = 1 path for BASELINE configs[1] / [2] — per-transition records, uniform (replay_history.py:93-140)
+    or stratified sum-tree sampling (prioritized_replay_history.py:281-356), np.stack batch assembly, torch-CPU
+    forward / backward of the nature CNN + FC512 (+ dueling IQN head), Adam, update_losses — at the FULL batch size:
+    one learner step here is seconds, so nothing is extrapolated."""
+
+    E, A = 8, 6
+
+    def __init__(self, name, fill_steps=600):
+        from oracle import replay as orc
+        from rltime_amd.general.config import load_config
+        from rltime_amd.general.type_registry import get_registered_type
+        from rltime_amd.spaces import Box, Discrete
+        spec = CONFIGS[name]
+        config = load_config(spec["file"])
+        ta = config["training"]["args"]
+        self.iqn = config["training"]["type"] == "iqn"
+        self.B, self.n = ta["mbatch_size"], ta.get("nstep_target") or 1
+        self.double_q, self.gamma = bool(ta.get("double_q")), ta["gamma"]
+        self.per = ta["history_mode"]["type"] == "prioritized_replay"
+        torch.set_num_threads(1)
+        pol_cls = get_registered_type("trainers", config["training"]["type"]).create_policy
+        mk = lambda: pol_cls(model_config=config["model"], observation_space=Box(0, 255, (4, 84, 84), np.uint8),  # noqa: E731
+                             action_space=Discrete(self.A), cuda=False, **config.get("policy_args", {}))
+        self.policy, self.target = mk(), mk()
+        self.opt = torch.optim.Adam(self.policy.parameters(), eps=ta.get("adam_epsilon", 1e-8))
+        self.clip = ta.get("clip_grad")
+        hist = dict(size=self.E * fill_steps, train_frequency=8, nstep_target=self.n, nstep_train=1, prefix_steps=0,
+                    discount_function=orc.make_discount(self.gamma))
+        if self.per:
+            hargs = ta["history_mode"]["args"]
+            self.buf = orc.OraclePrioritizedReplay(alpha=hargs["alpha"], beta=hargs["beta"], beta_anneal=hargs.get("beta_anneal", False), **hist)
+        else:
+            self.buf = orc.OracleReplay(**hist)
+        rng = self.rng = np.random.RandomState(0)
+        frame_pool = [rng.randint(0, 256, (4, 84, 84)).astype(np.uint8) for _ in range(64)]
+        t0 = time.time()
+        for s in range(fill_steps):
+            self.buf.update([{
+                "policy_output": {"actions": int(rng.randint(self.A))},
+                "next_state": {"x": frame_pool[(s * self.E + e) % 64].copy(), "layer0_state": {}, "layer1_state": {}},
+                "reward": float(rng.choice([-1.0, 0.0, 1.0], p=[.1, .8, .1])), "done": bool(rng.rand() < 0.002),
+                "info": {}, "env_id": e} for e in range(self.E)])
+        self.ingest_rate = self.E * fill_steps / (time.time() - t0)
+
+    def learner_step(self):
+        """-> seconds spent in (get_train_data, targets + forward / backward + Adam, update_losses)."""
+        from oracle import qmath
+        from oracle.replay import tree_map
+        from rltime_amd.models.torch.utils import make_tensor
+        buf, policy, target = self.buf, self.policy, self.target
+        f32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.float32))  # noqa: E731
+        flat = lambda x: x.reshape((x.shape[0] * x.shape[1],) + x.shape[2:])  # noqa: E731
+        buf.train_quota = 0
+        t0 = time.time()
+        batch = buf.get_train_data(self.B, 0.5)
+        data = tree_map(batch, flat)
+        t1 = time.time()
+        tt = lambda tree: make_tensor(tree, "cpu")  # noqa: E731
+        with torch.no_grad():
+            if self.iqn:
+                z_t = target.predict(tt(data["target_states"]), 1)[0]
+                z_s = (policy if self.double_q else target).predict(tt(data["target_states"]), 1)[0]
+                boot = qmath.iqn_bootstrap(z_t, z_s)
+            else:
+                q_t = target.predict(tt(data["target_states"]), 1)
+                boot = qmath.dqn_bootstrap(q_t, policy.predict(tt(data["target_states"]), 1) if self.double_q else q_t)
+            y = qmath.nstep_target(boot, f32(data["returns"]), f32(data["target_masks"]), f32(data["nsteps"]), self.gamma, None)
+        self.opt.zero_grad()
+        actions = torch.from_numpy(data["policy_outputs"]["actions"])
+        w = f32(data["extra_data"]["importance_weights"]) if "importance_weights" in data.get("extra_data", {}) else None
+        if self.iqn:
+            z, taus = policy.predict(tt(data["states"]), 1)
+            loss, rep = qmath.iqn_loss(z, taus, actions, y, w, 1.0, 1, "mean", None)
+        else:
+            loss, rep = qmath.dqn_loss(policy.predict(tt(data["states"]), 1), actions, y, w, 1.0, "huber", 1, "mean", None)
+        loss.backward()
+        if self.clip:
+            torch.nn.utils.clip_grad_norm_(policy.parameters(), self.clip)
+        self.opt.step()
+        t2 = time.time()
+        if self.per:
+            buf.update_losses(data["extra_data"]["loss_indices"], rep.detach().numpy())
+        return t1 - t0, t2 - t1, time.time() - t2
+
+    def acting_rate(self, EA=32, reps=5):
+        act_state = {"x": self.rng.randint(0, 256, (EA, 4, 84, 84)).astype(np.uint8), "layer0_state": {}, "layer1_state": {}}
+        self.policy.actor_predict(act_state, 1)
+        t0 = time.time()
+        for _ in range(reps):
+            self.policy.actor_predict(act_state, 1)
+        return reps * EA / (time.time() - t0)
+
+
+def cpu_baseline_t1(name, seconds=12.0):
+    """CpuPathT1 at the config's full batch, 1 torch thread (what the reference runs with): median of up to 5 steps."""
+    cpu = CpuPathT1(name)
+    cpu.learner_step()                                    # untimed warm-up
+    runs, spent = [], 0.0
+    while len(runs) < 5 and (spent < seconds or len(runs) < 2):
+        parts = cpu.learner_step()
+        runs.append(parts)
+        spent += sum(parts)
+    med = [float(np.median([r[i] for r in runs])) for i in range(3)]
+    step_s = sum(med)
+    act_rate = cpu.acting_rate()
+    acted = cpu.B / 8.0                                   # train_frequency = 8 trained samples per acted one
+    extra = acted / cpu.ingest_rate + acted / act_rate
+    return {"value": cpu.B / (step_s + extra), "unit": "transitions/s", "cores": 1, "kind": "port",
+            "learner_steps_per_sec": 1.0 / (step_s + extra), "host_nproc": os.cpu_count() or 1,
+            "ms_get_train_data": med[0] * 1e3, "ms_targets_forward_backward_adam": med[1] * 1e3, "ms_update_losses": med[2] * 1e3,
+            "runs": len(runs),
+            "sample": "oracle (reference algorithm restated) at the FULL batch B=%d, T=1, n=%d, %s, torch-CPU fp32 with 1 thread like the "
+                      "reference's torch.set_num_threads(1): median of %d learner steps (%.1f s of CPU work); + acting %.0f and ingest "
+                      "%.0f transitions/s for the step's %d acted transitions.  Sanity anchor (BASELINE.md section 2, the unmodified "
+                      "reference in the survey container): get_train_data 13.6 ms uniform B=256 / 44.2 ms + 7.0 ms update_losses PER B=512"
+                      % (cpu.B, cpu.n, "sum-tree PER" if cpu.per else "uniform replay", len(runs), spent, act_rate, cpu.ingest_rate, acted)}
 
 
 def cpu_baseline(args, seconds):
@@ -774,6 +900,63 @@ def summary(res, world, steps):
             "acted_transitions_per_step_per_gpu": res["acted"] / steps}
 
 
+def gather_roofline(res, frame_dedup=False):
+    """The frame gather of one run_mode result: algorithmic bytes per launch (every gathered row read once and
+    written once = 2 x state rows x B x F) over the mean launch duration (HIP events on the launch stream, timed region)."""
+    F = 4 * 84 * 84
+    rows, B = res["rows"], res["B"]
+    algo = 2.0 * rows * B * F
+    if frame_dedup:            # every stack written once, every distinct plane of a window read once
+        algo = rows * B * F + B * (rows + 3) * (F / 4.0)
+    launches, ms = res["launches"], res["gather_ms"]
+    avg_ms = ms / max(launches, 1)
+    achieved = algo / (avg_ms * 1e-3) / 1e9 if launches else None
+    return algo, avg_ms, achieved
+
+
+def other_config_record(args, name, rank, world, device):
+    """BASELINE configs[1] / [2] as a sub-record of the default line: the same run_mode protocol (1M-transition replay
+    pre-filled, warm-up, K timed steps between synchronisations), its gather roofline and its CPU baseline."""
+    import argparse as ap
+    sub = ap.Namespace(**vars(args))
+    sub.config, sub.steps, sub.warmup = name, args.other_steps, 20
+    sub.mbatch = sub.nstep_train = sub.burn_in = sub.nstep_target = sub.envs = None
+    sub.train_arg, sub.frame_dedup, sub.replay_size, sub.no_acting = [], False, 1000000, False
+    res = run_mode(sub, "strong", rank, world, device, None, want_tables=False)
+    head = summary(res, world, sub.steps)
+    algo, avg_ms, achieved = gather_roofline(res)
+    rec = {"metric": CONFIGS[name]["metric"], "workload": CONFIGS[name]["workload"],
+           "value": head["value"], "unit": "transitions/s", "learner_steps_per_sec": head["learner_steps_per_sec"],
+           "ms_per_step": head["ms_per_step"], "step_ms": head["step_ms"], "steps": sub.steps, "warmup": sub.warmup,
+           "mbatch": res["B"], "nstep_train": res["T"], "nstep_target": res["n"], "envs": res["envs"],
+           "replay_transitions": res["hist_stats"]["total_items"], "tree_capacity": res["hist_stats"]["tree_capacity"] if res["per"] else None,
+           "acted_transitions_per_step": res["acted"] / sub.steps, "learner_step_hip_graph": res["graph_step"],
+           "roofline": {"kernel": "k_gather_rows (frames)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "algorithmic_bytes_per_launch": algo,
+                        "avg_launch_ms": avg_ms, "launches": res["launches"], "traffic": None}}
+    if not args.no_cpu_baseline:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_t1(name)
+            rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+        except Exception as e:
+            rec["cpu_baseline"] = {"error": repr(e)}
+    return rec
+
+
+def file_date(path):
+    """Collection date of an evidence file: its own "collected" field, else its modification time."""
+    try:
+        d = json.load(open(path))
+        if isinstance(d, dict) and d.get("collected"):
+            return d["collected"]
+    except Exception:
+        pass
+    try:
+        return time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+    except OSError:
+        return None
+
+
 def main():
     args = parse()
     launched = "WORLD_SIZE" in os.environ
@@ -822,20 +1005,14 @@ def main():
         T, P, n, B = res["T"], res["P"], res["n"], res["B"]
         per, hist_stats, envs = res["per"], res["hist_stats"], res["envs"]
         table, launches, gather_ms = res["table"], res["launches"], res["gather_ms"]
-        F = 4 * 84 * 84
-        rows = res["rows"]
-        algo_bytes = 2.0 * rows * B * F
-        if args.frame_dedup:           # every stack written once, every distinct plane of a window read once
-            algo_bytes = rows * B * F + B * (rows + 3) * (F / 4.0)
-        avg_ms = gather_ms / max(launches, 1)
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else None
+        algo_bytes, avg_ms, achieved = gather_roofline(res, args.frame_dedup)
         traffic, traffic_src = None, None
         if args.config == "iqn_lstm" and world == 1 and os.path.isfile(args.pmc_traffic):
             try:
                 traffic = json.load(open(args.pmc_traffic)).get("hbm_bytes_per_launch")
                 traffic_src = "profiles/gather_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate runs) over " \
                               "tools/gather_probe.py with the same 1M-transition replay and B/T/P/n, collected by " \
-                              "`tools/gpu_round.sh <tag> pmc` — NOT measured in this run"
+                              "`tools/gpu_round.sh <tag> pmc` on %s — NOT measured in this run" % file_date(args.pmc_traffic)
             except Exception:
                 traffic = None
         kernels, ideal_ours_ms = kernel_table(table, args.profile_steps)
@@ -851,6 +1028,14 @@ def main():
             "ms_per_step": head["ms_per_step"], "step_ms": head["step_ms"],
             "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None,
             "dtype": "f32" if args.amp == "none" else "bf16(network autocast)+f32(hot path)",
+            "dtype_note": "f32 operands, f32 accumulation and f32 results everywhere (sum tree: the reference's f32 / f64 scalar kinds; "
+                          "n-step returns f64 -> f32).  The WIDE f32 products (head / LSTM-projection GEMMs, conv layers 2-3, the conv "
+                          "backward) run on the bf16 matrix pipe as split-bf16: every f32 operand is split exactly into three bf16 "
+                          "parts and SIX of the nine part products are accumulated in f32, smallest first; the three dropped ones "
+                          "(mid.lo, lo.mid, lo.lo) are each below 2^-23 |a||b|, the size of one f32 rounding — results stay within the "
+                          "library f32 kernels' own distance from float64 (tests/test_gemm3_gpu.py); non-finite inputs become NaN "
+                          "(inf - inf in the split) instead of propagating as inf.  MIRL_GEMM3=0 MIRL_CONV1_BF16=0 MIRL_CONV3=0 selects "
+                          "the f32 MFMA pipe only",
             "data": "synthetic",
             "config": {
                 "workload": spec["workload"] + " [%s]" % mode_text[res["scaling"]],
@@ -953,6 +1138,26 @@ def main():
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:            # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
+        elif world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_t1(args.config)
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        plain = all(v is None for v in (args.mbatch, args.nstep_train, args.burn_in, args.nstep_target, args.envs)) \
+            and not (args.train_arg or args.frame_dedup or args.no_acting or args.amp != "none" or args.replay_size != 1000000)
+        if world == 1 and dp is None and args.config == "iqn_lstm" and plain and not args.no_other_configs:
+            # BASELINE configs[1] and [2] ride along in the driver's line (same protocol, own roofline and CPU baseline)
+            out["other_configs"] = {}
+            for name in ("dqn_uniform", "rainbow_iqn"):
+                try:
+                    out["other_configs"][name] = other_config_record(args, name, rank, world, device)
+                except Exception as e:        # never sink the headline
+                    out["other_configs"][name] = {"error": repr(e)}
+        out["evidence_dates"] = {
+            "profiles/gather_traffic.json": file_date(args.pmc_traffic),
+            "gemm3 PMC (profiles/r06_gemm3_pmc_round5_kernels_nt_head_tn.json)": file_date(os.path.join(ROOT, "profiles", "r06_gemm3_pmc_round5_kernels_nt_head_tn.json")),
+            "this line": time.strftime("%Y-%m-%d", time.gmtime())}
         print(json.dumps(out), flush=True)
     if dp is not None:
         if world > 1:

@@ -64,6 +64,7 @@ struct G3Args {
   //   C[row][col] = e > 0 ? d * x : 0;   gsum[row >> 5][col] = sum over the group's 32 rows of d * e;
   //   part[2 it + wm][col] = this wave's 128-row column sum of C   (the embedding layer's bias gradient, summed by the caller)
   float* gsum; int64_t ldgsum;
+  int prio;              // experiment switch (MIRL_GEMM3_PRIO): 1 = s_setprio 1 around every MFMA block, 2 = waves 4-7 raised once
 };
 
 
@@ -183,6 +184,7 @@ k_gemm3(G3Args g) {
   const int b_off = (wn * 64 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
   const bool stage_first = (wu >> 2) & 1;      // waves w and w + 4 share a SIMD and take opposite orders
 
+  if (g.prio == 2 && wu >= 4) __builtin_amdgcn_s_setprio(1);
   // first tile of this workgroup
   int e = l, it = 0, jt = 0;
   if (g.splits > 1) {
@@ -227,7 +229,9 @@ k_gemm3(G3Args g) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
       }
+      if (g.prio == 1) __builtin_amdgcn_s_setprio(1);
       g3_compute<TI>(cur, acc, a_off, b_off);
+      if (g.prio == 1) __builtin_amdgcn_s_setprio(0);
       if (!stage_first) {
         if (k + 1 < nk) { la.store(nxt, va); lb.store(nxt + 3 * G3_PLANE, vb); }
         if (k + 2 < nk) { la.load(va); lb.load(vb); }
@@ -559,6 +563,8 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
   g.w2 = w2; g.part = part; g.gsum = gsum; g.ldgsum = ldgsum;
+  static const int prio_env = getenv("MIRL_GEMM3_PRIO") ? atoi(getenv("MIRL_GEMM3_PRIO")) : 0;
+  g.prio = prio_env;
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
   g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!w2 || !((uintptr_t)w2 % 16)) && (!bias || !((uintptr_t)bias % 16)) &&
              (!mul || ((ldmul % 4 == 0) && !((uintptr_t)mul % 16))) && (!pre || ((ldpre % 4 == 0) && !((uintptr_t)pre % 16)));

@@ -54,10 +54,15 @@ def _check_windows(tag, buf, gold, last_batch):
         assert np.array_equal(buf.last_sample["slot"].cpu().numpy(), gold[tag + ".slots"]), tag
 
 
+@pytest.mark.parametrize("feed", sorted(scenario.FEEDS))
 @pytest.mark.parametrize("name", scenario.SCENARIOS)
-def test_golden_scenarios(name):
+def test_golden_scenarios(name, feed):
+    """Every reference-generated scenario through each of the three hand-overs the build has: the reference's per-env
+    dict lists (actor.py:132-145 -> history.py:123-176), the device actor's DeviceSamples, and the fused rollout's
+    planned ingest (mirl_replay_ingest_plan + mirl_replay_ingest_planned) — same golden batches, windows, tree kinds
+    and free-list order after every operation."""
     scenario.run(name, _make, exact_dtypes=False, per_state=_per_state,
-                 on_round=_check_windows)
+                 on_round=_check_windows, feeder=scenario.FEEDS[feed])
 
 
 def test_tree_cases_on_device():
