@@ -102,3 +102,24 @@ def iqn_loss(z, taus, actions, targets, weights=None, kappa=1.0,
     if weights is not None:
         rows = rows * weights
     return aggregate(rows, timesteps, batch_mode, time_mode), report.detach()
+
+
+def gae_bootstrap_discount(values, nsteps, gamma, lam):
+    """a2c.py:68-71."""
+    return (gamma ** nsteps) * (lam ** (nsteps - 1)) * values
+
+
+def actor_critic_loss(log_probs, values, entropy, targets, acting_values, old_log_probs, vf_coef, entropy_factor,
+                      adv_norm, clip_value=None):
+    """a2c.py:101-133 with the action gain of a2c.py:90-99 (clip_value None) or ppo.py:39-56.
+    -> (total loss, value loss, action gain)."""
+    adv = targets - acting_values
+    if adv_norm:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-5)
+    if clip_value is None:
+        gain = (log_probs * adv).mean()
+    else:
+        ratio = torch.exp(log_probs - old_log_probs)
+        gain = torch.min(ratio * adv, torch.clamp(ratio, 1.0 - clip_value, 1.0 + clip_value) * adv).mean()
+    value_loss = (targets - values).pow(2).mean()
+    return value_loss * vf_coef - gain - entropy_factor * entropy.mean(), value_loss, gain

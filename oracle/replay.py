@@ -226,6 +226,64 @@ class OracleHistory:
 
 
 # ----------------------------------------------------------------------------
+# Online (on-policy) history (online_history.py) — BASELINE configs[0] plumbing
+# ----------------------------------------------------------------------------
+class OracleOnline(OracleHistory):
+    """online_history.py:4-120."""
+
+    def __init__(self, max_delayed_steps=5000, fixed_target=True, **kw):
+        super().__init__(**kw)
+        self.max_delayed_steps = max_delayed_steps
+        self.fixed_target = fixed_target
+        self.last_env = None
+
+    def _enough(self, mbatch):
+        """online_history.py:49-59."""
+        return sum(int(len(r) / self.nstep_train) for r in self.rings.values()) >= mbatch
+
+    def update(self, new_samples):
+        """online_history.py:61-73."""
+        out = super().update(new_samples)
+        lost = 0
+        for env, ring in self.rings.items():
+            if len(ring) > self.max_delayed_steps:
+                extra = len(ring) - self.max_delayed_steps
+                self._drop_oldest(env, extra)
+                lost += extra
+        out['discarded_steps'] = lost
+        return out
+
+    def needed_feed_count(self, mbatch_size, num_envs):
+        """online_history.py:75-79."""
+        return None if self._enough(mbatch_size) else num_envs
+
+    def get_train_data(self, mbatch_size, train_progress=None):
+        """online_history.py:81-120."""
+        assert self.prefix_steps == 0
+        if not self._enough(mbatch_size):
+            return None
+        ids = sorted(self.rings)
+        k = 0 if not self.last_env else (ids.index(self.last_env) + 1) % len(ids)   # :101-103
+        windows = []
+        while len(windows) < mbatch_size:
+            env = ids[k]
+            if len(self.rings[env]) >= self.nstep_train:
+                windows.append(self._window(env, 0, self.nstep_train, self.fixed_target))
+                self._drop_oldest(env, self.nstep_train)
+                self.last_env = env
+            k = (k + 1) % len(ids)
+        return self._assemble(windows)
+
+
+def make_gae_discount(gamma, lam):
+    """a2c.py:48-66: k-th term of a truncated GAE(lambda) return."""
+    def discount(nstep, reward, policy_output):
+        v = policy_output['values']
+        return (gamma ** nstep) * (lam ** (nstep - 1)) * (v + lam * (reward - v))
+    return discount
+
+
+# ----------------------------------------------------------------------------
 # Uniform replay (replay_history.py)
 # ----------------------------------------------------------------------------
 class OracleReplay(OracleHistory):

@@ -563,7 +563,7 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
   g.relu = relu ? 1 : 0;
   g.mul = mul; g.ldmul = ldmul; g.mul_shift = mul_shift; g.pre = pre; g.ldpre = ldpre;
   g.w2 = w2; g.part = part; g.gsum = gsum; g.ldgsum = ldgsum;
-  static const int prio_env = getenv("MIRL_GEMM3_PRIO") ? atoi(getenv("MIRL_GEMM3_PRIO")) : 0;
+  static const int prio_env = getenv("MIRL_GEMM3_PRIO") ? atoi(getenv("MIRL_GEMM3_PRIO")) : 1;
   g.prio = prio_env;
   static const int vec_env = getenv("MIRL_GEMM3_VEC") ? atoi(getenv("MIRL_GEMM3_VEC")) : 1;
   g.vec_ok = vec_env && (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C % 16) && (!w2 || !((uintptr_t)w2 % 16)) && (!bias || !((uintptr_t)bias % 16)) &&

@@ -24,10 +24,15 @@ from rltime_amd.general.utils import deep_dictionary_update
 
 
 def make_vec_env(env, env_args, num_envs, device, seed=0):
+    if isinstance(env, str) and env.startswith("CartPole-"):
+        # the CPU plumbing config (BASELINE configs[0]): the build's own cart-pole, v0 = 200-step episodes, v1 = 500
+        from rltime_amd.acting.cartpole_env import CartPoleVecEnv
+        limit = (env_args or {}).get("max_episode_steps", 500 if env.endswith("v1") else 200)
+        return CartPoleVecEnv(num_envs, max_episode_steps=limit, seed=seed)
     if env != "synthetic-atari":
         raise ValueError(
-            "rltime_amd ships only the synthetic vector env ('synthetic-atari'): real "
-            "emulators are CPU code outside the scope of this backend (DESIGN.md)")
+            "rltime_amd ships the synthetic vector env ('synthetic-atari') and its own CartPole ('CartPole-v0/-v1'): "
+            "real emulators are CPU code outside the scope of this backend (DESIGN.md)")
     from rltime_amd.acting.synthetic_env import SyntheticAtariVecEnv
     args = dict(env_args or {})
     args["frame_shape"] = tuple(args.get("frame_shape", (4, 84, 84)))
@@ -40,6 +45,13 @@ def create_actors(config, device="cuda", device_acting=True, use_graph=False):
     acting = config.get("acting", {})
     n = acting.get("actor_envs", 1)
     env = make_vec_env(config.get("env"), config.get("env_args"), n, device)
+    if device_acting:
+        # the device-resident actor needs a GPU policy and an env that steps on the device; a host env / CPU policy
+        # (policy_args.cuda false: the cartpole configs) takes the reference's per-env dict path (actor.py:97-149)
+        import torch
+        cuda = config.get("policy_args", {}).get("cuda", "auto")
+        on_gpu = torch.cuda.is_available() if cuda == "auto" else bool(cuda)
+        device_acting = on_gpu and hasattr(env, "step_device")
     return Actor(env, exploration_config=acting.get("exploration"), device=device_acting, use_graph=use_graph,
                  base_env_id=acting.get("env_base", 0), total_env_ids=acting.get("total_envs"))
 
@@ -106,8 +118,8 @@ def train_from_config(path, num_envs=None, env=None, conf_update=None, log_dir=N
         import random
         import numpy as np
         random.seed(seed + rank); np.random.seed(seed + rank); torch.manual_seed(seed + rank)
-    if seed is not None:
-        hm = config["training"]["args"].setdefault("history_mode", {}).setdefault("args", {})
+    if seed is not None and config["training"]["args"].get("history_mode", {}).get("type") in ("replay", "prioritized_replay"):
+        hm = config["training"]["args"]["history_mode"].setdefault("args", {})
         hm.setdefault("seed", seed)          # device-RNG sampling stream (the shard mixes its env_base in)
     logger = make_logger(rank, dp, log_dir, log_name)
     try:

@@ -105,7 +105,7 @@ class TorchTrainer(MultiStepTrainer):
                 returns, target_masks, nsteps = (t.unsqueeze(-1) for t in (returns, target_masks, nsteps))
             return self._vf_scale(returns + self._discount_bootstrap_target_value(v, nsteps) * target_masks)
 
-    def _clip_value(self, norm):
+    def _get_grad_norm_clip_value(self, norm):
         """torch_trainer.py:153-175: fixed clip or clip_grad x EMA(norm); the EMA
         lives on the device."""
         if not self.clip_grad:
@@ -145,7 +145,7 @@ class TorchTrainer(MultiStepTrainer):
         grads = [p.grad for p in params]
         norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2)), 2)
         self.value_log.log("grad_norm", norm, group="train")
-        clip = self._clip_value(norm)
+        clip = self._get_grad_norm_clip_value(norm)
         if clip is not None:
             coef = torch.clamp(clip / (norm + 1e-6), max=1.0)     # torch.nn.utils.clip_grad_norm_
             torch._foreach_mul_(grads, coef)

@@ -1002,6 +1002,16 @@ SIGNATURE_TARGETS = {
     "acting.Actor": ("rltime.acting.actor", "Actor", ["get_samples", "update_state", "set_actor_policy"]),
     "models.SequentialModel": ("rltime.models.torch.sequential", "SequentialModel",
                                ["make_input_state", "forward", "set_layer_preprocessor"]),
+    # BASELINE configs[0] (cartpole_ppo.json): the on-policy plumbing chain
+    "history.OnlineHistoryBuffer": ("rltime.history.online_history", "OnlineHistoryBuffer",
+                                    ["__init__", "update", "needed_feed_count", "get_train_data"]),
+    "policies.ActorCriticPolicy": ("rltime.policies.torch.actor_critic", "ActorCriticPolicy",
+                                   ["__init__", "actor_predict", "get_state_value", "evaluate_actions",
+                                    "get_dist_and_state_value"]),
+    "training.A2C": ("rltime.training.torch.a2c", "A2C",
+                     ["_train", "create_policy", "_get_discount_function", "_discount_bootstrap_target_value",
+                      "_get_bootstrap_target_value", "_calc_action_gain", "_compute_grads"]),
+    "training.PPO": ("rltime.training.torch.ppo", "PPO", ["_train", "_calc_action_gain"]),
 }
 
 
@@ -1024,6 +1034,85 @@ def run_signature_cases():
     print("signature cases: %d classes" % len(out))
 
 
+# --------------------------------------------------------------------------
+# On-policy plumbing (BASELINE configs[0], cartpole_ppo.json): OnlineHistoryBuffer batches with the GAE discount of
+# a2c.py:48-66, targets through calc_target_values and the PPO loss / gradients through PPO._compute_grads of the
+# unmodified reference on a seeded-weight 2x16 MLP ActorCriticPolicy
+# --------------------------------------------------------------------------
+def run_online_ppo_case():
+    import gym
+    from rltime.history.online_history import OnlineHistoryBuffer
+    from rltime.training.torch.ppo import PPO
+    from rltime.policies.torch.actor_critic import ActorCriticPolicy
+    from tests.golden.streams import ONLINE_CASE as case, online_vector_steps, seeded_weights
+    T, gamma, lam = case["nstep_train"], case["gamma"], case["advlam"]
+    tr = PPO.__new__(PPO)
+    tr.gamma, tr.advlam, tr.vf_coef, tr.adv_norm = gamma, lam, case["vf_coef"], True
+    tr.entropy_factor, tr.entropy_anneal = case["entropy_factor"], None
+    tr._clip_value, tr._clip_anneal = case["clip_value"], None
+    tr.vf_scale_epsilon = None
+    tr.steps, tr.total_steps = 0, 1
+    tr.value_log = ValueLog()
+    policy = ActorCriticPolicy.create(
+        model_config=case["model"], observation_space=gym.spaces.Box(-10, 10, (case["obs_dim"],), np.float32),
+        action_space=gym.spaces.Discrete(case["n_actions"]), cuda=False)
+    policy.load_state_dict(seeded_weights(policy.state_dict(), case["weights_seed"]))
+    tr.policy = tr.target_policy = policy
+    ref = OnlineHistoryBuffer(nstep_target=T, nstep_train=T, discount_function=tr._get_discount_function(gamma),
+                              state_store=StateStore("cpu"))
+    mine = orc.OracleOnline(nstep_target=T, nstep_train=T, discount_function=orc.make_gae_discount(gamma, lam))
+    out, step_no, rnd = {}, 0, 0
+    for op in case["script"]:
+        if op[0] == "feed":
+            for a, b in zip(online_vector_steps(case, op[1], step_no), online_vector_steps(case, op[1], step_no)):
+                assert ref.update(a) == mine.update(b)
+            step_no += op[1]
+            continue
+        tag = "r%d" % rnd
+        rnd += 1
+        B = op[1]
+        assert ref.needed_feed_count(B, case["num_envs"]) == mine.needed_feed_count(B, case["num_envs"])
+        out[tag + ".feed_count"] = np.array(-1 if ref.needed_feed_count(B, case["num_envs"]) is None else case["num_envs"])
+        got, got_mine = ref.get_train_data(B), mine.get_train_data(B)
+        out[tag + ".is_none"] = np.array(got is None)
+        assert (got is None) == (got_mine is None)
+        if got is None:
+            continue
+        deep_equal(got, got_mine, tag)
+        assert ref.last_env == mine.last_env
+        flat = {}
+        flatten("", got, flat)
+        for k, v in flat.items():
+            out[tag + ".batch." + k] = v
+        # multi_step_trainer.py:290-320: flatten (T, B) -> (T*B), targets, one training pass over the whole batch
+        f = lambda x: x.reshape((x.shape[0] * x.shape[1],) + tuple(x.shape[2:]))                # noqa: E731
+        data = {k: orc.tree_map(v, f) for k, v in got.items() if k != "extra_data"}
+        targets = tr.calc_target_values(data["returns"], data["target_states"], data["target_masks"], data["nsteps"], 1)
+        policy.zero_grad()
+        tr._compute_grads(data["states"], targets, data["policy_outputs"], {}, 1)
+        out[tag + ".targets"] = targets.detach().numpy()
+        for name, prm in policy.named_parameters():
+            out[tag + ".grad." + name] = prm.grad.detach().numpy().copy()
+        log = tr.value_log.get()["train"]
+        for key in ("value_loss", "policy_loss", "policy_entropy", "state_value_mean"):
+            out[tag + ".log." + key] = np.array(log[key])
+        # the oracle's arithmetic (oracle/qmath.py) on the same tensors
+        with torch.no_grad():
+            boot = policy.get_state_value(policy.make_tensor(data["target_states"]), 1)
+            mk = policy.make_tensor
+            y = mk(data["returns"]) + qmath.gae_bootstrap_discount(boot, mk(data["nsteps"]), gamma, lam) * mk(data["target_masks"])
+        assert torch.equal(y, targets)
+        lp, vals, ent = policy.evaluate_actions(policy.make_tensor(data["states"]), 1, data["policy_outputs"]["actions"])
+        total, vloss, gain = qmath.actor_critic_loss(
+            lp, vals, ent, y, mk(data["policy_outputs"]["values"]), mk(data["policy_outputs"]["action_log_probs"]),
+            case["vf_coef"], case["entropy_factor"], True, case["clip_value"])
+        assert abs(float(vloss) - float(log["value_loss"])) <= 1e-6 * abs(float(vloss))
+        assert abs(-float(gain) - float(log["policy_loss"])) <= 1e-6
+    out["rounds"] = np.array(rnd)
+    np.savez_compressed(os.path.join(HERE, "online_ppo.npz"), **out)
+    print("online / PPO plumbing case: %d draws, %d keys" % (rnd, len(out)))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_tree_cases()
@@ -1038,4 +1127,5 @@ if __name__ == "__main__":
     run_schedule_cases()
     run_config_cases()
     run_signature_cases()
+    run_online_ppo_case()
     print("golden fixtures written to", HERE)

@@ -150,3 +150,36 @@ def seeded_weights(state_dict, seed):
         bound = 0.05 if len(shape) == 1 else float(1.0 / np.sqrt(np.prod(shape[1:])))
         out[key] = torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32))
     return out
+
+
+# --------------------------------------------------------------------------
+# On-policy stream for the online-history / PPO plumbing fixture (BASELINE configs[0])
+# --------------------------------------------------------------------------
+ONLINE_CASE = {
+    "seed": 23, "num_envs": 3, "obs_dim": 4, "n_actions": 2, "done_prob": 0.12,
+    "nstep_train": 5, "gamma": 0.99, "advlam": 0.95, "vf_coef": 0.5, "entropy_factor": 1e-2, "clip_value": 0.2,
+    "weights_seed": 5,
+    "model": {"type": "sequential", "args": {"layer_configs": [{"type": "fc", "args": {"fc_size": 16}},
+                                                               {"type": "fc", "args": {"fc_size": 16}}]}},
+    # feed N vector steps / draw a batch of B sequences (None expected where the buffer cannot serve it)
+    "script": [["feed", 4], ["draw", 2], ["feed", 3], ["draw", 3], ["draw", 1], ["feed", 9], ["draw", 4], ["draw", 2],
+               ["feed", 11], ["draw", 6]],
+}
+
+
+def online_vector_steps(case, count, start_step=0):
+    """`count` vector steps of the on-policy case as the reference's per-env sample dicts (acting_interface.py:83-90 with
+    an actor-critic policy_output, actor_critic.py:63-71): float32 vector observations, unit rewards (CartPole's), the
+    acting-time action / log-probability / value estimate drawn from the seed instead of a policy."""
+    E = case["num_envs"]
+    for s in range(start_step, start_step + count):
+        rng = np.random.RandomState((case["seed"] * 1000003 + s) % (2 ** 31))
+        obs = rng.randn(E, case["obs_dim"]).astype(np.float32)
+        dones = rng.rand(E) < case["done_prob"]
+        actions = rng.randint(0, case["n_actions"], size=E)
+        logp = np.log(rng.uniform(0.2, 0.8, size=E)).astype(np.float32)
+        values = (rng.randn(E) * 3 + 10).astype(np.float32)
+        rewards = np.where(rng.rand(E) < 0.9, 1.0, 0.5)
+        yield [{"policy_output": {"actions": actions[e], "action_log_probs": logp[e], "values": values[e]},
+                "next_state": {"x": obs[e], "layer0_state": {}, "layer1_state": {}},
+                "reward": rewards[e], "done": dones[e], "info": {}, "env_id": e} for e in range(E)]

@@ -84,6 +84,10 @@ _MIRROR = {
     "acting.ActingInterface": ("rltime_amd.acting.acting_interface", "ActingInterface"),
     "acting.Actor": ("rltime_amd.acting.actor", "Actor"),
     "models.SequentialModel": ("rltime_amd.models.torch.sequential", "SequentialModel"),
+    "history.OnlineHistoryBuffer": ("rltime_amd.history.online_history", "OnlineHistoryBuffer"),
+    "policies.ActorCriticPolicy": ("rltime_amd.policies.actor_critic", "ActorCriticPolicy"),
+    "training.A2C": ("rltime_amd.training.a2c", "A2C"),
+    "training.PPO": ("rltime_amd.training.ppo", "PPO"),
 }
 # where the mirror deliberately differs from the reference's parameter list
 _KNOWN = {
