@@ -13,6 +13,13 @@
 // registers), K in steps of 16 floats; the A row pointer jumps by (W - KW) * C floats after every KW * C (a multiple of
 // 16).  LDS: two stages of [A 256 rows | B 64 rows] x 3 bf16 parts = 61 440 bytes (two workgroups per CU); the epilogue
 // transposes each wave's block through 4 608 bytes of it into 16-byte row stores.
+//
+// What bounds it (round 6, profiles/r06_conv3_fwd_register_A_experiment.jsonl): with only F <= 64 columns the split of
+// the A tile (4 096 floats per K-step, ~6 VALU operations each) is amortised over 96 MFMAs — ~520 VALU cycles per SIMD
+// beside 768 MFMA cycles, from the same waves — and the two together hold the clock at ~1.5 GHz.  A variant whose A
+// operand never touches LDS (fragments loaded straight from global memory, split in registers, 32 floats = whole 128-byte
+// lines per iteration) measured the SAME 124-132 TFLOP/s and was removed: not LDS traffic, not L1 line splitting, not the
+// barrier.  (131 TFLOP/s is 0.83 of the f32-input MFMA peak: an unsplit f32 kernel could not be faster either.)
 #include "common.hpp"
 #include "split3.hpp"
 #include <stdlib.h>

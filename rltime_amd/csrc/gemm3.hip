@@ -126,7 +126,10 @@ struct G3Loader {
 
 // 48 MFMAs of one K-step on this wave's 128 x 64 block: fragments of tile (i, j) are rows wm*128 + i*32 + (lane & 31)
 // of A and rows wn*64 + j*32 + (lane & 31) of B, k = 8 (lane >> 5) .. +7.  (Issuing all 18 fragment reads before the
-// first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.)
+// first MFMA instead of per A half measured 3 % slower: 7.56 vs 7.17 ms at 1 310 720 x 1024 x 512.  Round 6: the
+// second half's six reads requested under the first half's MFMAs — both halves' fragments live, 256 VGPRs — measured
+// no faster on the plain forms and 3-15 % slower on the epilogue forms, profiles/r06_gemm3_pipelined_fragments_experiment.jsonl;
+// the two waves of a SIMD already cover each other's fragment waits.  s_setprio 1 around this block: +1-2 %, kept.)
 template <int TI>
 __device__ __forceinline__ void g3_compute(const char* stage, g3_f32x16 (&acc)[TI][2], int a_off, int b_off) {
   const char* pa = stage + a_off;

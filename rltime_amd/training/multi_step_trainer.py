@@ -502,7 +502,7 @@ class MultiStepTrainer(PolicyTrainer):
         rnn_steps_train = rnn_steps_train or nstep_train
         if getattr(self, "_graph_step_ok", None) is not None and self._graph_step_ok(train_data, burn_in_timesteps, epochs, minibatches):
             self._start_timer("train")
-            self._learner_step_graphed(train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap)
+            self._learner_step_graphed(train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap, burn_in_timesteps)
             return
         self._prepare_frames(train_data)
         if burn_in_timesteps:

@@ -119,7 +119,11 @@ class PolicyTrainer:
 
     def _gpu_timing(self):
         pol = getattr(self, "policy", None)
-        return pol is not None and hasattr(pol, "is_cuda") and pol.is_cuda()
+        if not (pol is not None and hasattr(pol, "is_cuda") and pol.is_cuda()):
+            return False
+        import torch
+        # (a phase timed while the stream is capturing would record its events INTO the graph: nothing to resolve later)
+        return not torch.cuda.is_current_stream_capturing()
 
     def _resolve_gpu_spans(self, count=None):
         spans = self._gpu_spans if count is None else self._gpu_spans[:count]

@@ -205,7 +205,9 @@ class TorchTrainer(MultiStepTrainer):
         if not getattr(self, "graph_learner_step", False) or not self.policy.is_cuda():
             return False
         dp = getattr(self, "data_parallel", None)
-        return (burn_in_timesteps == 0 and epochs * minibatches == 1 and (dp is None or not dp.active) and self._ov is None
+        # (burn-in included since round 6: the prefix passes, the recurrent state substitution and the row drop are
+        # tensor ops on the static batch buffers; the persistent LSTM sweeps capture like any other kernel)
+        return (epochs * minibatches == 1 and (dp is None or not dp.active) and self._ov is None
                 and self.clip_grad_dynamic_alpha is None and getattr(self.history_buffer, "static_batches", False))
 
     @staticmethod
@@ -221,10 +223,12 @@ class TorchTrainer(MultiStepTrainer):
             out.append(tree)
         return out
 
-    def _graph_step_body(self, train_data, nstep_target, rnn_steps_train, rnn_bootstrap):
+    def _graph_step_body(self, train_data, nstep_target, rnn_steps_train, rnn_bootstrap, burn_in_timesteps=0):
         from .multi_step_trainer import _flat
         from rltime_amd.general.utils import deep_apply
         self._prepare_frames(train_data)
+        if burn_in_timesteps:
+            train_data = self._burn_in(train_data, burn_in_timesteps, do_target_states=rnn_bootstrap)
         self._share_online_features(train_data, nstep_target)
         flat = deep_apply(train_data, _flat)
         flat["targets"] = self.calc_target_values(
@@ -232,18 +236,18 @@ class TorchTrainer(MultiStepTrainer):
             timesteps=1 if not rnn_bootstrap else rnn_steps_train)
         self.train_batch(flat["states"], flat["targets"], flat["policy_outputs"], flat["extra_data"], rnn_steps_train)
 
-    def _learner_step_graphed(self, train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap):
+    def _learner_step_graphed(self, train_data, nstep_train, nstep_target, rnn_steps_train, rnn_bootstrap, burn_in_timesteps=0):
         from rltime_amd.general.utils import quiet_gc
         from rltime_amd.models.torch import gemm3, lstm_seq
         st = self._gstep
         sig = tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in self._leaves(train_data))
         if st is None or st["sig"] != sig:
             st = self._gstep = {"sig": sig, "eager": 0, "graph": None, "logs": [], "losses": None, "data": None}
-        batch_size = train_data["returns"].shape[0] * train_data["returns"].shape[1]
+        batch_size = (train_data["returns"].shape[0] - burn_in_timesteps) * train_data["returns"].shape[1]
         self.get_train_indexes(batch_size, batch_size, nstep_train)          # the reference's np.random.shuffle is consumed
         if st["graph"] is None and (st["eager"] < 3 or not self._graph_capture):
             st["eager"] += 1
-            self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap)
+            self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap, burn_in_timesteps)
         else:
             if st["graph"] is None:
                 for g in self.optimizer.param_groups:
@@ -262,9 +266,12 @@ class TorchTrainer(MultiStepTrainer):
                 self._defer_losses = []
                 gemm3.REFRESH_ALWAYS = True
                 graph = torch.cuda.CUDAGraph()
+                # the eager steps' cached blocks go back to the driver first: the capture's private pool holds a whole
+                # step's intermediates for good (tens of GB at B = 512, T = 80) and must not sit NEXT to a cache of the same size
+                torch.cuda.empty_cache()
                 try:
                     with quiet_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap)
+                        self._graph_step_body(dict(train_data), nstep_target, rnn_steps_train, rnn_bootstrap, burn_in_timesteps)
                 finally:
                     gemm3.REFRESH_ALWAYS = False
                     self.value_log.log = real_log

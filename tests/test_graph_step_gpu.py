@@ -29,7 +29,18 @@ def _series(kind, graphed, steps=600):
     common = {"clip_rewards": True, "gamma": 0.99, "mbatch_size": 32, "nstep_train": 1, "nstep_target": 3, "lr": 1e-3, "lr_anneal": True,
               "double_q": True, "clip_grad": 10.0, "target_update_freq": 24, "total_steps": steps, "log_freq": 10 ** 9, "warmup_steps": 96,
               "graph_learner_step": graphed}
-    if kind == "dqn":
+    if kind == "iqn_lstm":
+        # the RECURRENT step (BASELINE configs[3] in small): burn-in prefix passes with the stored-state substitution,
+        # rnn_bootstrap target pass, persistent LSTM forward sweeps (H = 128, B = 16), per-step backward, sequence priorities
+        cfg["model"]["args"]["layer_configs"] = [CNN, {"type": "lstm", "args": {"num_units": 128}}, {"type": "fc", "args": {"fc_size": 64}}]
+        cfg["acting"]["actor_envs"] = 16
+        cfg["policy_args"] = {"dueling": True, "embedding_dim": 16, "num_sampling_quantiles": 8}
+        cfg["training"] = {"type": "iqn", "args": dict(
+            common, mbatch_size=16, nstep_train=8, burn_in_timesteps=4, nstep_target=2, rnn_bootstrap=True, vf_scale_epsilon=1e-3,
+            clip_rewards=False, warmup_steps=480, total_steps=max(steps, 1600),
+            history_mode={"type": "prioritized_replay", "args": {
+                "size": 1600, "train_frequency": 4, "alpha": 0.9, "beta": 0.6, "max_weight_factor": 0.9, "device_rng": True}})}
+    elif kind == "dqn":
         cfg["policy_args"] = {"dueling": True}
         cfg["training"] = {"type": "dqn", "args": dict(common, history_mode={"type": "replay", "args": {
             "size": 400, "train_frequency": 8, "device_rng": True}})}
@@ -62,7 +73,7 @@ def _series(kind, graphed, steps=600):
     out["target"] = [p.detach().cpu().clone() for p in tr.target_policy.parameters()]
     out["captured"] = tr._gstep is not None and tr._gstep["graph"] is not None
     out["steps"] = tr.ts_learner_steps if hasattr(tr, "ts_learner_steps") else None
-    tree = tr.history_buffer.tree_nodes() if kind == "iqn" else None
+    tree = tr.history_buffer.tree_nodes() if kind in ("iqn", "iqn_lstm") else None
     out["tree"] = tree
     tr.history_buffer.close()
     return out
@@ -112,6 +123,19 @@ def test_iqn_prioritized_learner_step_from_a_graph_is_the_eager_step(determinist
     a, b = _series("iqn", True), _series("iqn", "no-capture")
     assert a["captured"] and not b["captured"]
     assert len(a["qloss"]) == len(b["qloss"]) > 100
+    _identical(a, b)
+    for x, y in zip(a["tree"], b["tree"]):
+        np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_recurrent_learner_step_from_a_graph_is_the_eager_step(deterministic_library):
+    """The recurrent IQN step — burn-in prefix passes of both networks with the stored recurrent state replaced at the
+    first trained row (multi_step_trainer.py:90-131), rnn_bootstrap target pass, persistent LSTM sweeps, training pass,
+    clip + Adam — captured once and replayed: every loss, gradient norm, the final weights and the priority tree
+    bit-identical to the same set-up issued launch by launch."""
+    a, b = _series("iqn_lstm", True), _series("iqn_lstm", "no-capture")
+    assert a["captured"] and not b["captured"]
+    assert len(a["qloss"]) == len(b["qloss"]) > 30
     _identical(a, b)
     for x, y in zip(a["tree"], b["tree"]):
         np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
