@@ -1157,6 +1157,8 @@ def main():
         out["evidence_dates"] = {
             "profiles/gather_traffic.json": file_date(args.pmc_traffic),
             "gemm3 PMC (profiles/r06_gemm3_pmc_round5_kernels_nt_head_tn.json)": file_date(os.path.join(ROOT, "profiles", "r06_gemm3_pmc_round5_kernels_nt_head_tn.json")),
+            "conv PMC (profiles/r06_conv_mfma_util_pmc.json, r06_conv3_pmc.json)": file_date(os.path.join(ROOT, "profiles", "r06_conv3_pmc.json")),
+            "rocprofv3 --kernel-trace --stats (profiles/r06_rocprofv3_kernel_stats_summary.txt)": file_date(os.path.join(ROOT, "profiles", "r06_rocprofv3_kernel_stats_summary.txt")),
             "this line": time.strftime("%Y-%m-%d", time.gmtime())}
         print(json.dumps(out), flush=True)
     if dp is not None:

@@ -6,7 +6,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../librltime_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function ${MIRL_EXTRA_HIPCC_FLAGS:-}"
 UNITS="replay qmath lstm lstm_seq convert nnops acting actnet conv_in conv_mid gemm3 conv3 conv_wrw optim"
 newest_hdr=$(ls -t "$HERE"/*.h "$HERE"/*.hpp "$HERE"/../../include/*.h "$HERE/build.sh" | head -1)
 pids=()

@@ -33,6 +33,9 @@ for w in "$@"; do
       timeout 600 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --mbatch $((512/N)) --envs $((256/N)) --replay-size $((1000000/N)) ${SHARE_FLAGS:-} > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; echo "$w rc=$?"; tail -c 400 "$OUT/bench_$w.err"; short "$OUT/bench_$w.json" | head -14;;
     bench23) for c in rainbow_iqn dqn_uniform; do timeout 600 python bench.py --config $c --steps 200 --warmup 20 > "$OUT/bench_$c.json" 2> "$OUT/bench_$c.err"; echo "bench $c rc=$?"; tail -c 400 "$OUT/bench_$c.err"; short "$OUT/bench_$c.json" | head -8; done;;
     prof)    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$OUT/stats" -o bench -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --profile-steps 0 > "$R/$OUT/bench_under_rocprof.json" 2> "$R/$OUT/bench_under_rocprof.err"); echo "prof rc=$?"; python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1; head -60 "$OUT/summary.txt"; find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*.db" -delete;;
+    rebuildall:*) # rebuildall:<-DFLAG=V,...>: the whole library rebuilt on the box with extra compiler flags (objects do not travel)
+             fl=$(echo "$w" | cut -d: -f2 | tr ',' ' '); rm -f rltime_amd/csrc/*.o
+             MIRL_EXTRA_HIPCC_FLAGS="$fl" bash rltime_amd/csrc/build.sh > "$OUT/rebuild.log" 2>&1; echo "rebuildall [$fl] rc=$?"; tail -2 "$OUT/rebuild.log";;
     rebuild:*) # rebuild:<unit>:<-DFLAG=V,...>: recompile ONE translation unit on the box with extra flags and relink (same-box A/B of a compile-time switch)
              u=$(echo "$w" | cut -d: -f2); fl=$(echo "$w" | cut -d: -f3 | tr ',' ' ')
              ( cd rltime_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $fl -c $u.hip -o $u.o \
