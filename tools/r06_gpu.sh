@@ -43,6 +43,7 @@ for w in "$@"; do
     c3:*)    # c3:<name>:<ENV=V,...>: tools/conv3_probe.py under environment switches
              n=$(echo "$w" | cut -d: -f2); ev=$(echo "$w" | cut -d: -f3 | tr ',' ' ')
              env $ev timeout 300 python tools/conv3_probe.py ${CONV3_FRAMES:-41472} > "$OUT/conv3_$n.jsonl" 2> "$OUT/conv3_$n.err"; echo "c3 $n rc=$?"; cat "$OUT/conv3_$n.jsonl"; tail -3 "$OUT/conv3_$n.err";;
+    variants) for v in no-acting no-policy-outputs; do timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --profile-steps 0 --$v > "$OUT/bench_$v.json" 2> "$OUT/bench_$v.err"; echo "variant $v rc=$?"; short "$OUT/bench_$v.json" | head -1; done;;
     smoke)   timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3;;
     *)       echo "unknown item $w";;
   esac
