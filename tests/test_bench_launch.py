@@ -45,3 +45,25 @@ def test_world_size_mismatch_is_a_message_not_an_assert():
     assert r.returncode != 0
     assert "AssertionError" not in r.stderr
     assert "WORLD_SIZE=4" in r.stderr
+
+
+def test_default_line_options_and_the_t1_cpu_baseline_path(monkeypatch):
+    """The driver's default command keeps the CPU linearity check and the `other_configs` sub-records on; the full-batch
+    CPU baseline of BASELINE configs[1] (oracle uniform replay + torch-CPU DQN step, bench.CpuPathT1) runs on a host
+    without a GPU and reports every field the bench line quotes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", [BENCH])
+    args = bench.parse()
+    assert args.cpu_linearity_check and not args.no_other_configs and args.gpus == 1 and args.other_steps == 200
+    monkeypatch.setattr(sys, "argv", [BENCH, "--no-cpu-linearity-check", "--no-other-configs"])
+    args = bench.parse()
+    assert not args.cpu_linearity_check and args.no_other_configs
+    cpu = bench.CpuPathT1("dqn_uniform", fill_steps=80)
+    assert cpu.B == 256 and not cpu.per and not cpu.iqn
+    parts = cpu.learner_step()
+    assert len(parts) == 3 and all(p >= 0 for p in parts) and parts[1] > 0
+    assert cpu.acting_rate(EA=8, reps=1) > 0
+    assert bench.file_date(os.path.join(ROOT, "profiles", "gather_traffic.json")).startswith("2026-10-01")
