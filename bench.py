@@ -610,7 +610,7 @@ def copy_peak(device, stream_ptr_fn):
 #   bf16x6  six exact-split bf16 MFMAs per f32 product block (csrc/gemm3.hip, conv3.hip)  -> 2.5 PF / 6
 #   bf16x3  uint8 pixel x three-way split weight (csrc/conv_in.hip forward)                 -> 2.5 PF / 3
 #   f32     v_mfma_f32_16x16x4_f32 (input layer's weight gradient, layer 2's data gradient, LSTM sweeps)
-PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nt_head": "bf16x6", "k_gemm3_ps": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
+PIPE_OF = {"k_gemm3_nt": "bf16x6", "k_gemm3_nt_mid": "bf16x6", "k_gemm3_nt_head": "bf16x6", "k_gemm3_ps": "bf16x6", "k_gemm3_nn": "bf16x6", "k_gemm3_tn": "bf16x6", "k_gemm3_nt_mul": "bf16x6", "k_conv3_fwd": "bf16x6",
            "k_conv1_u8_fwd": "bf16x3", "k_conv1_u8_wrw": "f32", "k_conv1_u8_wrw_b3": "bf16x3", "k_conv2_bwd_data": "f32", "k_conv2_bwd_data_b3": "bf16x6", "k_conv3_bwd_data_b3": "bf16x6", "k_conv_wrw_b3": "bf16x6", "k_gemm3_nn_qp": "bf16x6",
            "k_lstm_seq_fwd": "f32", "k_lstm_seq_bwd": "f32", "k_lstm_step_fwd": "f32"}
 # launch / dependency-latency bound by construction (one workgroup of bookkeeping, one tree level per barrier, 256-row

@@ -546,6 +546,10 @@ int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, 
  *   C[r][c] = f(A B^T + bias)[r][c] * mul[r >> group_shift][c],  f = ReLU if relu
  * and, if `pre` is given, pre[r][c] = f(...)[r][c] (what the backward needs).  Rows of one state are
  * 2^group_shift consecutive rows.  Removes the separate multiply pass over the (rows, N) embedding. */
+/* Plain NT products with too few 256 x 256 tiles to fill the chip take a 256 x 128 tile (k_gemm3_mid; the acting batch's
+ * hidden layer at 256 envs: 8 192 x 1 024 x 512 in 55 us against 71 with the big tile and 73 on the library).  Process-wide
+ * switch for in-process A/B runs: -1 = the MIRL_GEMM3_MID environment default (on), 0 = always the big tile, 1 = on.        */
+int mirl_gemm3_mid_set(int32_t mode);
 int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu,
                       const float* mul, int64_t ldmul, int32_t group_shift, float* pre, int64_t ldpre,

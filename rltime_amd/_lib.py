@@ -156,6 +156,7 @@ _SIGNATURES = {
     "mirl_lstm_seq_workspace_bytes": [_i32, _i32, _P(_i64)],
     "mirl_lstm_seq_fwd": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "mirl_lstm_seq_status": [_P(_i32)],
+    "mirl_gemm3_mid_set": [_i32],
     "mirl_lstm_seq_fwd_grid": [_i32, _i32, _P(_i32), _P(_i64), _P(_i32), _P(_i32)],
     "mirl_lstm_seq_bwd_supported": [_i32, _i32, _i32],
     "mirl_lstm_seq_bwd_workspace_bytes": [_i32, _i32, _P(_i64)],

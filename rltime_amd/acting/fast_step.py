@@ -42,6 +42,7 @@ import torch
 from rltime_amd._lib import lib, check
 from rltime_amd.general.utils import deep_apply, quiet_gc
 from rltime_amd.models.torch.fused import conv_bias_relu, conv_u8_supported, cos_embed
+from rltime_amd.models.torch import gemm3
 
 
 def _p(t):
@@ -395,7 +396,10 @@ class FastActingStep:
                 "mirl_act_head_select")
             return
         if use_val:
-            both = torch._addmm_activation(self.fc_b, feat, self.fc_w.t(), use_gelu=False)
+            # the joint [last FC | value-hidden] layer: at 256 envs (8 192 quantile rows) the split-bf16 kernel's 256 x 128
+            # tile fills the chip (csrc/gemm3.hip k_gemm3_mid: 55 us against the library's 73); smaller batches stay on
+            # the library through linear_fwd's own gates
+            both = gemm3.linear_fwd(feat, self.fc_w, self.fc_b, relu=True)
             outs = torch.addmm(self.out_b, both, self.out_w.t())          # (rows, A + 1): [advantages | value]
             pitch, val = self.na + self.nq, C.c_void_p(outs.data_ptr() + 4 * self.na)
         else:

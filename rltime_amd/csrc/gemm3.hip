@@ -479,6 +479,126 @@ k_gemm3(G3Args g) {
   }
 }
 
+
+// ---- round 6: a 256 x 128 tile for products with too few 256 x 256 tiles to fill the chip -------------------------
+// The acting batch's hidden layer at 256 envs (8 192 quantile rows x 1 024 x 512) is 128 tiles of 256 x 256 on 256
+// compute units: half the chip idles and the library's f32 kernel wins (68.9 against 67 us, profiles/r05_acting_256_
+// envs_learner_gemm_kernels_experiment.jsonl).  Same method, same staging and K loop, but a workgroup's eight waves
+// (2 along M x 4 along N) own 128 rows x 32 columns each: 24 MFMAs per K-step against 12 + 3 fragment reads, 64
+// accumulator registers, LDS two stages of [A 256 rows | B 128 rows] x 3 parts = 110 592 bytes.  NT form with bias /
+// ReLU only (what the call site needs); 16-byte row stores through a per-wave 32 x 36 float transposition area.
+constexpr int G3M_BROWS = 128;
+constexpr int G3M_BPLANE = G3M_BROWS * G3_PITCH;
+constexpr int G3M_STAGE = 3 * G3_PLANE + 3 * G3M_BPLANE;          // 55 296
+constexpr int G3M_LDS = 2 * G3M_STAGE;
+constexpr int G3M_EPITCH = 36;
+
+__global__ void __launch_bounds__(512)
+k_gemm3_mid(G3Args g) {
+  extern __shared__ __attribute__((aligned(16))) char g3_lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wu & 1, wn = wu >> 1;
+  const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
+  // column tiles of one row tile are consecutive on ONE XCD (they share the A rows in its L2), as in k_gemm3
+  const int jt = l % g.nt, it = (l / g.nt) * 8 + xcd;
+  if (it >= g.mt) return;
+  const int64_t m0 = (int64_t)it * 256, n0 = (int64_t)jt * G3M_BROWS;
+  const int64_t nk = g.K / 16;
+
+  G3Loader<true> la;
+  la.init(g.A, g.lda, m0, g.M, 0, t);
+  // B: one row per thread (row t >> 2 of the 128, k quad t & 3)
+  const int rb = t >> 2, kq = t & 3;
+  int64_t brow = n0 + rb; if (brow > g.N - 1) brow = g.N - 1;
+  const float* pb = g.B + brow * g.ldb + kq * 4;
+  const int b_lds = rb * G3_PITCH + kq * 8;
+  float va[2][4], vb[4];
+  auto load_b = [&]() { const float4 q = *reinterpret_cast<const float4*>(pb); vb[0] = q.x; vb[1] = q.y; vb[2] = q.z; vb[3] = q.w; pb += 16; };
+  auto store_b = [&](char* planes) {
+    uint2 h, m, lo;
+    g3_split4(vb, h, m, lo);
+    *reinterpret_cast<uint2*>(planes + b_lds) = h;
+    *reinterpret_cast<uint2*>(planes + G3M_BPLANE + b_lds) = m;
+    *reinterpret_cast<uint2*>(planes + 2 * G3M_BPLANE + b_lds) = lo;
+  };
+  const int a_off = (wm * 128 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
+  const int b_off = (wn * 32 + (lane & 31)) * G3_PITCH + (lane >> 5) * 16;
+  const bool stage_first = (wu >> 2) & 1;      // waves w and w + 4 share a SIMD and take opposite orders
+
+  g3_f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};          // smallest products first
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+  if (nk > 0) { la.load(va); load_b(); la.store(g3_lds, va); store_b(g3_lds + 3 * G3_PLANE); }
+  if (nk > 1) { la.load(va); load_b(); }
+  g3_barrier();
+  for (int64_t k = 0; k < nk; ++k) {
+    const char* cur = g3_lds + (k & 1) * G3M_STAGE;
+    char* nxt = g3_lds + ((k + 1) & 1) * G3M_STAGE;
+    if (stage_first) {
+      if (k + 1 < nk) { la.store(nxt, va); store_b(nxt + 3 * G3_PLANE); }
+      if (k + 2 < nk) { la.load(va); load_b(); }
+    }
+    {
+      const char* pa = cur + a_off;
+      const char* pbf = cur + 3 * G3_PLANE + b_off;
+      g3_bf16x8 bf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const g3_bf16x8*>(pbf + p * G3M_BPLANE);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {
+        g3_bf16x8 a[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[p][i] = *reinterpret_cast<const g3_bf16x8*>(pa + p * G3_PLANE + (ih * 2 + i) * 32 * G3_PITCH);
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[ih * 2 + i] = g3_mfma(a[PA[c]][i], bf[PB[c]], acc[ih * 2 + i]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (!stage_first) {
+      if (k + 1 < nk) { la.store(nxt, va); store_b(nxt + 3 * G3_PLANE); }
+      if (k + 2 < nk) { la.load(va); load_b(); }
+    }
+    g3_barrier();
+  }
+
+  // epilogue: each 32 x 32 accumulator tile through this wave's 4 608-byte area, then + bias, ReLU, 16-byte row stores
+  float* tl = reinterpret_cast<float*>(g3_lds) + wu * (32 * G3M_EPITCH);
+  const int c4 = lane & 7;
+  const int64_t col = n0 + wn * 32 + c4 * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && col < g.N) bv = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      tl[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * G3M_EPITCH + (lane & 31)] = acc[i][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rl = q * 8 + (lane >> 3);
+      const int64_t row = m0 + wm * 128 + i * 32 + rl;
+      float4 v = *reinterpret_cast<const float4*>(tl + rl * G3M_EPITCH + c4 * 4);
+      if (row < g.M && col < g.N) {
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (g.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this tile read before the next one overwrites the area
+  }
+}
+
 // out[i] = sum over splits of partial[s][i] (fixed order: deterministic), i over M*N, rows re-pitched to ldc
 __global__ void __launch_bounds__(256)
 k_gemm3_reduce(const float* __restrict__ partial, int splits, int64_t M, int64_t N, float* __restrict__ out, int64_t ldc) {
@@ -515,6 +635,8 @@ k_g3_head_reduce(const float* __restrict__ part, int ncb, int64_t M, int O, cons
     }
   }
 }
+
+static int g_g3_mid_mode = -1;       // mirl_gemm3_mid_set: -1 = MIRL_GEMM3_MID (default on), 0 / 1 = forced for in-process A/B runs
 
 static int g3_splits(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
@@ -592,6 +714,22 @@ static int g3_launch(int32_t layout, int64_t M, int64_t N, int64_t K, const floa
     grid = (unsigned)(g.mt * g.nt * g.splits);
   }
   const int vec = g.vec_ok ? 1 : 0;
+  // too few 256 x 256 tiles for the chip: the 256 x 128 tile (plain NT with bias / ReLU; MIRL_GEMM3_MID=0 keeps the big tile)
+  static const int mid_default = getenv("MIRL_GEMM3_MID") ? atoi(getenv("MIRL_GEMM3_MID")) : 1;
+  const int mid_env = g_g3_mid_mode >= 0 ? g_g3_mid_mode : mid_default;
+  if (mid_env && layout == 0 && !mul && !w2 && !gsum && vec && (N % 4) == 0 && (int64_t)g.mt * g.nt < 192 && N > 128 &&
+      ((int64_t)g.mt * ((N + G3M_BROWS - 1) / G3M_BROWS) >= 192 || (int64_t)g.mt * g.nt < 24)) {
+    // (between: neither tiling fills the chip — the callers' area gate, models/torch/gemm3.py _MIN_AREA, keeps those
+    //  products on the library; tiny products take the smaller tile for its shorter tail)
+    static bool mid_attr = false;
+    if (!mid_attr) { MIRL_HIP(hipFuncSetAttribute((const void*)k_gemm3_mid, hipFuncAttributeMaxDynamicSharedMemorySize, G3M_LDS)); mid_attr = true; }
+    g.nt = (int)((N + G3M_BROWS - 1) / G3M_BROWS);
+    const unsigned mgrid = (unsigned)(8 * ((g.mt + 7) / 8) * g.nt);
+    ProfScope ps("k_gemm3_nt_mid", 4.0 * ((double)M * K + (double)N * K + (double)M * N), st, 2.0 * (double)M * (double)N * (double)K);
+    void* kargs[] = {(void*)&g};
+    MIRL_HIP(hipLaunchKernel((const void*)k_gemm3_mid, dim3(mgrid), dim3(512), kargs, G3M_LDS, st));
+    return MIRL_OK;
+  }
   static bool attr[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
   const void* fns[4][2] = {{(const void*)k_gemm3<true, true, 0, false>, (const void*)k_gemm3<true, true, 0, true>},
                            {(const void*)k_gemm3<true, false, 0, false>, (const void*)k_gemm3<true, false, 0, true>},
@@ -642,6 +780,12 @@ extern "C" int mirl_gemm3(int32_t layout, int64_t M, int64_t N, int64_t K, const
                           int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t relu, void* workspace,
                           int64_t workspace_bytes, void* stream) {
   return g3_launch(layout, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, workspace, workspace_bytes, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int mirl_gemm3_mid_set(int32_t mode) {
+  if (mode < -1 || mode > 1) return mirl::fail(MIRL_ERR_ARG, "gemm3_mid_set: mode is -1 (environment default), 0 or 1");
+  mirl::g_g3_mid_mode = mode;
+  return MIRL_OK;
 }
 
 extern "C" int mirl_gemm3_nt_mul(int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,

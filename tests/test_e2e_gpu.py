@@ -254,11 +254,12 @@ ROUND3_KERNELS = ("k_gemm3_nt", "k_gemm3_nn", "k_gemm3_tn", "k_gemm3_nt_mul", "k
                   "k_conv1_u8_wrw_b3", "k_conv2_bwd_data_b3", "k_conv3_bwd_data_b3", "k_conv_wrw_b3", "k_lstm_seq_fwd", "k_lstm_seq_bwd", "k_tail_bwd")
 
 
-@pytest.mark.parametrize("forced,nhwc,full_sel", [(True, True, False), ("gemm3", True, False), ("conv", True, False), ("lstm", True, False),
-                                                  (False, True, False), (False, False, False), (True, True, True)],
+@pytest.mark.parametrize("forced,nhwc,full_sel,mid", [(True, True, False, 1), ("gemm3", True, False, 1), ("conv", True, False, 1), ("lstm", True, False, 1),
+                                                      (False, True, False, 1), (False, False, False, 1), (True, True, True, 1), (True, True, False, 0)],
                          ids=["every-hip-kernel-forced-on", "only-gemm3-forced", "only-conv-forced", "only-persistent-lstm-forced",
-                              "library-products-nhwc", "library-products-nchw", "every-hip-kernel-forced-on-full-head-selection"])
-def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, nhwc, full_sel, monkeypatch):
+                              "library-products-nhwc", "library-products-nchw", "every-hip-kernel-forced-on-full-head-selection",
+                              "every-hip-kernel-forced-on-big-gemm-tile"])
+def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persistent_kernels(forced, nhwc, full_sel, mid, monkeypatch):
     """The reference-pinned run that EXECUTES the round-3 arithmetic: the same algorithm as above on a model whose
     layer shapes the hand-written kernels take ((4,36,36) frames -> 32@8/4 -> 64@4/2 -> 64@3/1 -> LSTM 512 ->
     quantile 64 -> FC 128 | value-hidden 128; B = 16 sequences, T = 6, burn-in 4), trained by the unmodified
@@ -270,6 +271,8 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     products on the library (MIOpen / hipBLASLt f32) — both must follow the reference equally well.
     full_sel: the double-Q selection from the full dueling head (selection_advantage_only=False: V + A - mean_a A like the
     reference, instead of the advantage stream alone) — the same bars, so a deviation cannot hide behind that optimisation.
+    mid: the plain NT products of this small model take the 256 x 128 tile (k_gemm3_mid, round 6: products with few big tiles);
+    the last variant switches it off so that the 256 x 256 NT kernel runs inside a pinned trajectory too.
     Bar: 2e-3 over the first 40 Adam steps (rltime/training/torch/iqn.py:54-129, multi_step_trainer.py:278-353)."""
     from rltime_amd import _lib
     from rltime_amd.models.torch import fused, gemm3, lstm_seq
@@ -280,6 +283,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     monkeypatch.setattr(fused, "_CONV3_BWD", on("conv"))
     monkeypatch.setattr(lstm_seq, "_PERSISTENT", on("lstm"))
     _lib.check(_lib.lib.mirl_conv1_bf16_set(1 if on("conv") else 0))
+    _lib.check(_lib.lib.mirl_gemm3_mid_set(mid))
     _lib.check(_lib.lib.mirl_profile_reset())
     _lib.check(_lib.lib.mirl_profile_set(2))
     try:
@@ -290,6 +294,7 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     finally:
         _lib.check(_lib.lib.mirl_profile_set(0))
         _lib.check(_lib.lib.mirl_conv1_bf16_set(-1))
+        _lib.check(_lib.lib.mirl_gemm3_mid_set(-1))
     n = 40
     dev = np.abs(np.array(series["qloss"]) - d["qloss"]) / np.abs(d["qloss"])
     gdev = np.abs(np.array(series["grad_norm"]) - d["grad_norm"]) / np.abs(d["grad_norm"])
@@ -319,7 +324,8 @@ def test_wide_iqn_lstm_series_follows_reference_through_the_bf16_pipe_and_persis
     assert rel[~near_tie].max() <= 2e-3, (rel, near_tie.nonzero())
     assert rel[near_tie].max() <= 6e-3, (rel, near_tie.nonzero())
     if forced is True:
-        missing = [k for k in ROUND3_KERNELS if not table.get(k)]
+        plain_nt = "k_gemm3_nt_mid" if mid else "k_gemm3_nt"
+        missing = [k for k in ROUND3_KERNELS if not table.get(plain_nt if k == "k_gemm3_nt" else k)]
         assert not missing, ("kernels that never ran inside the pinned trajectory", missing, table)
     elif forced is False:
         ran = [k for k in ROUND3_KERNELS if table.get(k) and k.startswith(("k_gemm3", "k_conv3", "k_lstm_seq"))]

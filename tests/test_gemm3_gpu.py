@@ -75,6 +75,39 @@ def test_real_operands_are_an_f32_gemm(lay, M, N, K):
     assert err3 <= 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 512), (6200, 900, 80), (8192 + 77, 1024 + 4, 512), (300, 260, 48)])
+def test_mid_tile_for_products_with_few_big_tiles(M, N, K, monkeypatch):
+    """csrc/gemm3.hip k_gemm3_mid (256 x 128 tiles): taken by plain NT products whose 256 x 256 tiling would leave most
+    compute units idle — the acting batch's joint hidden layer at 256 envs is the case it was written for.  Integer
+    operands bit-exact (tile mapping, ragged edges in both directions, bias + ReLU epilogue); real operands an f32 GEMM;
+    and the launch table shows which kernel ran, with the switch off the big tile."""
+    import ctypes as C
+    from rltime_amd import _lib
+    from rltime_amd.models.torch import gemm3
+    gen = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    a, b = _operands("nt", M, N, K, gen, integer=True)
+    bias = torch.randint(-4, 5, (N,), device="cuda", generator=gen).float()
+    _lib.check(_lib.lib.mirl_profile_reset())
+    _lib.check(_lib.lib.mirl_profile_set(2))
+    got = gemm3.gemm(gemm3.NT, a, b, bias, relu=True)
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib.mirl_profile_set(0))
+    ran = {r["name"]: r["calls"] for r in _lib.profile_table()}
+    assert ran.get("k_gemm3_nt_mid") == 1 and not ran.get("k_gemm3_nt"), ran
+    want = torch.relu(a.double() @ b.double().t() + bias.double())
+    assert torch.equal(got.double(), want)
+    a, b = _operands("nt", M, N, K, gen)
+    a[::7] *= 37.0
+    b[::5] *= 0.013
+    want = a.double() @ b.double().t()
+    scale = float(want.abs().max())
+    got = gemm3.gemm(gemm3.NT, a, b)
+    lib = a @ b.t()
+    err3 = float((got.double() - want).abs().max()) / scale
+    errl = float((lib.double() - want).abs().max()) / scale
+    assert err3 <= 2.0 * errl + 1e-7 and err3 <= 1e-5, (err3, errl)
+
+
 def test_strided_operands_bias_and_relu():
     from rltime_amd.models.torch import gemm3
     gen = torch.Generator(device="cuda").manual_seed(5)
