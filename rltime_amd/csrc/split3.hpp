@@ -25,13 +25,6 @@ __device__ __forceinline__ unsigned g3_pk(float lo, float hi) {
 // x[0..3] (four consecutive k of one row) -> three 8-byte groups of bf16 parts
 __device__ __forceinline__ void g3_split4(const float (&x)[4], uint2& h, uint2& m, uint2& l) {
   unsigned ph[2], pm[2], pl[2];
-#ifdef G3_FAKE_SPLIT
-  // TIMING EXPERIMENT ONLY (wrong results): the hi part three times — 2 conversions per 4 floats instead of 6 + 16 other
-  // VALU operations; how much faster the kernels get says how much of their time is the split's VALU work
-  ph[0] = pm[0] = pl[0] = g3_pk(x[0], x[1]); ph[1] = pm[1] = pl[1] = g3_pk(x[2], x[3]);
-  h = make_uint2(ph[0], ph[1]); m = make_uint2(pm[0], pm[1]); l = make_uint2(pl[0], pl[1]);
-  return;
-#endif
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const float x0 = x[2 * e], x1 = x[2 * e + 1];
