@@ -98,7 +98,7 @@ def _rank_main(rank, world, port, out_dir, global_sampling=False):
     from rltime_amd.parallel import shard_config
     from rltime_amd.train import create_actors
     cfg = shard_config(copy.deepcopy(CONFIG), rank, world, "strong")
-    assert cfg["acting"]["actor_envs"] == 4 and cfg["training"]["args"]["mbatch_size"] == 4
+    assert cfg["acting"]["actor_envs"] == 8 // world and cfg["training"]["args"]["mbatch_size"] == 8 // world
     if global_sampling:
         # one tree over the union of the shards (mirl_replay_sample_global): padded batches
         cfg["training"]["args"]["global_sampling"] = True
@@ -209,6 +209,23 @@ def test_two_ranks_full_loop_on_one_gpu(tmp_path, sampling):
             worst = max(worst, float(np.max(np.abs(r[i]["w"][s] - want) / want)))
         assert max(r[0]["w"][s].max(), r[1]["w"][s].max()) == pytest.approx(1.0, rel=1e-6)
     print("max rel deviation of globalised weights vs union-tree oracle: %.2e" % worst)
+
+
+def test_one_rank_over_rccl_with_the_collectives_forced(tmp_path, monkeypatch):
+    """What a one-GPU box CAN run of the RCCL path: the same full trainer rank at world size 1 over `nccl` with the
+    collectives forced on (BENCH_FORCE_DIST=1) — process-group init with a device id, the gloo side group, parameter
+    broadcast, the three gradient buckets issued asynchronously as ReduceOp.AVG from autograd's post-accumulate hooks and
+    waited for on the stream, the (R, 3) importance-weight exchange.  Twelve learner steps must move the weights every step
+    and every bucket must have gone out from a hook."""
+    import torch.multiprocessing as mp
+    monkeypatch.setenv("BENCH_FORCE_DIST", "1")
+    monkeypatch.setenv("MIRL_TEST_BACKEND", "nccl")
+    mp.spawn(_rank_main, args=(1, _free_port(), str(tmp_path), False), nprocs=1, join=True)
+    r = np.load(tmp_path / "rank0.npz")
+    assert str(r["backend"]) == "nccl"
+    assert len(set(r["hash"])) == STEPS + 1 and len(set(r["target_hash"])) > 1
+    assert int(r["overlapped"]) >= 3 * STEPS                      # head, recurrent and conv bucket of every step, from hooks
+    assert np.all(np.isfinite(r["w"])) and r["w"].max() == pytest.approx(1.0, rel=1e-6)
 
 
 def test_train_entry_under_torchrun_world1_forced_collectives(tmp_path):
