@@ -342,6 +342,7 @@ struct ActEmbedArgs {
   float* x; float* tau_out;
   uint64_t seed; const uint64_t* step;
   int E, N, H, D;
+  int groups;             // 16-row groups per workgroup (1 for small batches: a latency kernel there)
 };
 
 __global__ void __launch_bounds__(256)
@@ -350,51 +351,63 @@ k_act_embed(ActEmbedArgs a) {
   __shared__ float tau_s[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int R = a.E * a.N, row0 = blockIdx.x * 16, PP = a.D + 4;
-  if (tid < 16) {
-    int m = row0 + tid; if (m >= R) m = R - 1;
-    float t;
-    if (a.taus) t = a.taus[m];
-    else { uint32_t rn[4]; philox_4x32(a.seed ^ 0x7A5ull, *a.step, (uint32_t)m, rn); t = (float)(rn[0] >> 8) * (1.0f / 16777216.0f); }
-    tau_s[tid] = t;
-    if (a.tau_out && blockIdx.y == 0 && row0 + tid < R) a.tau_out[row0 + tid] = t;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 16 * a.D; idx += 256) {
-    const int rr = idx / a.D, i = idx - rr * a.D;
-    phi[rr * PP + i] = cosf(a.freq[i] * tau_s[rr]);
-  }
-  __syncthreads();
+  const int R = a.E * a.N, PP = a.D + 4;
   const int nsD = a.D / 16;
   const int cbase = blockIdx.y * 128 + 32 * wave;
-  if (cbase >= a.H) return;
+  const bool cols = cbase < a.H;                     // (a wave without columns still takes part in the barriers)
   const bool on1 = cbase + 16 < a.H;
-  an_f4 acc[2] = {an_f4{0.f, 0.f, 0.f, 0.f}, an_f4{0.f, 0.f, 0.f, 0.f}};
-  an_f4 pa[4], q0[4], q1[4];
+  // this wave's weight fragments: loaded ONCE per workgroup and kept for all of its row groups (round 6: at the 256-env
+  // acting batch's 8 192 rows a workgroup per 16 rows re-read the 128 KB of weights 2 048 times)
+  an_f4 q0[4], q1[4];
 #pragma unroll
   for (int sq = 0; sq < 4; ++sq) {
     const int sc = sq < nsD ? sq : 0;
-    pa[sq] = sq < nsD ? *(const an_f4*)(phi + r * PP + 16 * sq + 4 * g) : an_f4{0.f, 0.f, 0.f, 0.f};
-    q0[sq] = *(const an_f4*)(a.wq + (int64_t)(cbase + r) * a.D + 16 * sc + 4 * g);
-    q1[sq] = *(const an_f4*)(a.wq + (int64_t)((on1 ? cbase + 16 : cbase) + r) * a.D + 16 * sc + 4 * g);
+    const int c0 = cols ? cbase : 0;
+    q0[sq] = *(const an_f4*)(a.wq + (int64_t)(c0 + r) * a.D + 16 * sc + 4 * g);
+    q1[sq] = *(const an_f4*)(a.wq + (int64_t)((cols && on1 ? cbase + 16 : c0) + r) * a.D + 16 * sc + 4 * g);
   }
-  // rows of this lane's accumulator elements -> env rows of h (one 32-bit division each, ahead of the products)
-  int mrow[4], erow[4];
+  // The products run TRANSPOSED (A = 16 weight rows, B = 16 phi rows): a lane then owns FOUR CONSECUTIVE COLUMNS
+  // cbase + 16 c + 4 g .. + 3 of ONE row (row0 + r) — bias, features and the result move as 16-byte vectors (round 6: with one
+  // column of four rows per lane the 16.8 MB result of the 256-env batch went out in 4-byte stores at 0.8 TB/s)
+  an_f4 bs[2] = {an_f4{0.f, 0.f, 0.f, 0.f}, an_f4{0.f, 0.f, 0.f, 0.f}};
+  if (cols) { bs[0] = *(const an_f4*)(a.bq + cbase + 4 * g); if (on1) bs[1] = *(const an_f4*)(a.bq + cbase + 16 + 4 * g); }
+  for (int rg = 0; rg < a.groups; ++rg) {
+    const int row0 = (blockIdx.x * a.groups + rg) * 16;
+    if (row0 >= R) break;                             // block-uniform
+    if (rg) __syncthreads();                          // the previous group's phi rows are read
+    if (tid < 16) {
+      int m = row0 + tid; if (m >= R) m = R - 1;
+      float t;
+      if (a.taus) t = a.taus[m];
+      else { uint32_t rn[4]; philox_4x32(a.seed ^ 0x7A5ull, *a.step, (uint32_t)m, rn); t = (float)(rn[0] >> 8) * (1.0f / 16777216.0f); }
+      tau_s[tid] = t;
+      if (a.tau_out && blockIdx.y == 0 && row0 + tid < R) a.tau_out[row0 + tid] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 16 * a.D; idx += 256) {
+      const int rr = idx / a.D, i = idx - rr * a.D;
+      phi[rr * PP + i] = cosf(a.freq[i] * tau_s[rr]);
+    }
+    __syncthreads();
+    if (!cols) continue;
+    an_f4 acc[2] = {an_f4{0.f, 0.f, 0.f, 0.f}, an_f4{0.f, 0.f, 0.f, 0.f}};
+    an_f4 pa[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { int m = row0 + 4 * g + i; mrow[i] = m; if (m >= R) m = R - 1; erow[i] = m / a.N; }
+    for (int sq = 0; sq < 4; ++sq)
+      pa[sq] = sq < nsD ? *(const an_f4*)(phi + r * PP + 16 * sq + 4 * g) : an_f4{0.f, 0.f, 0.f, 0.f};
+    const int m = row0 + r;
+    const int erow = (m < R ? m : R - 1) / a.N;       // env row of h (one 32-bit division, ahead of the products)
 #pragma unroll
-  for (int sq = 0; sq < 4; ++sq) { AN_MFMA4(acc[0], pa[sq], q0[sq]); AN_MFMA4(acc[1], pa[sq], q1[sq]); }
+    for (int sq = 0; sq < 4; ++sq) { AN_MFMA4(acc[0], q0[sq], pa[sq]); AN_MFMA4(acc[1], q1[sq], pa[sq]); }
+    if (m < R) {
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    if (c == 1 && !on1) break;
-    const int col = cbase + 16 * c + r;
-    const float bs = a.bq[col];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (mrow[i] < R) {
-        float v = acc[c][i] + bs;
-        v = v > 0.f ? v : 0.f;
-        a.x[(int64_t)mrow[i] * a.H + col] = v * a.h[(int64_t)erow[i] * a.H + col];
+      for (int c = 0; c < 2; ++c) {
+        if (c == 1 && !on1) break;
+        const int col = cbase + 16 * c + 4 * g;
+        const an_f4 hv = *(const an_f4*)(a.h + (int64_t)erow * a.H + col);
+        an_f4 v = acc[c] + bs[c];
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        *(an_f4*)(a.x + (int64_t)m * a.H + col) = v * hv;
       }
     }
   }
@@ -705,15 +718,21 @@ extern "C" int mirl_act_head_parts(int32_t HID, int32_t NO, int32_t* parts, int3
 extern "C" int mirl_act_embed(int32_t E, int32_t N, int32_t H, int32_t D, const float* h, const float* freq, const float* taus,
                               uint64_t seed, const uint64_t* step, const float* wq, const float* bq, float* x, float* tau_out, void* stream) {
   if (E <= 0 || N <= 0 || H <= 0 || (H % 16) || D <= 0 || (D % 16) || D > 64 || !h || !freq || !wq || !bq || !x || (!taus && !step) ||
-      (int64_t)E * N > (1 << 24) || !an_al16(wq))
-    return fail(MIRL_ERR_ARG, "bad act_embed arguments (H % 16, D in {16, 32, 48, 64}, taus or a step word)");
+      (int64_t)E * N > (1 << 24) || !an_al16(wq) || !an_al16(h) || !an_al16(bq) || !an_al16(x))
+    return fail(MIRL_ERR_ARG, "bad act_embed arguments (H % 16, D in {16, 32, 48, 64}, taus or a step word, 16-byte aligned h / wq / bq / x)");
   ActEmbedArgs a;
   a.h = h; a.freq = freq; a.taus = taus; a.wq = wq; a.bq = bq; a.x = x; a.tau_out = tau_out; a.seed = seed; a.step = step;
   a.E = E; a.N = N; a.H = H; a.D = D;
   const int R = E * N;
+  // enough workgroups to fill the chip twice, then more rows per workgroup (the weights stay in its registers)
+  const int tiles = (R + 15) / 16, ycount = (H + 127) / 128;
+  static const int groups_env = getenv("MIRL_ACT_EMBED_GROUPS") ? atoi(getenv("MIRL_ACT_EMBED_GROUPS")) : 0;
+  int groups = groups_env > 0 ? groups_env : 1;
+  if (groups_env <= 0) while (groups < 8 && (tiles / (2 * groups)) * ycount >= 512) groups *= 2;
+  a.groups = groups;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("k_act_embed", 4.0 * ((double)R * H + (double)E * H + (double)H * D), st, 2.0 * (double)R * H * D);
-  hipLaunchKernelGGL(k_act_embed, dim3((R + 15) / 16, (H + 127) / 128), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_act_embed, dim3((tiles + groups - 1) / groups, ycount), dim3(256), 0, st, a);
   MIRL_LAUNCH_CHECK();
   return MIRL_OK;
 }
