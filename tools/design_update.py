@@ -48,7 +48,7 @@ def main():
              "(§3.2: the clock), conv forward 10.0 + backward 6.8 at 0.27–0.52, LSTM 4.8, HBM-bound glue 3.3 at 0.62–0.69, gathers 0.75, acting ≈ %.1f (%.2f vs %.2f "
              "without; 8.8 before `k_gemm3_mid`).  The pool's boxes read one tree within ±1.5 %% (this session's box is the slower kind: its `--no-acting` line is 78.0 against "
              "76.7 on the box of the earlier session); the same-box A/B of the mid tile: 84.61 against 85.29 ms (`profiles/r06_gemm3_mid_tile.jsonl`).  GPU suite in the same "
-             "session: 415 passed / 4 skipped, `smoke()` ok." % (rs["frac"], rs["roofline_ms"], b["ms_per_step"], rs["librltime_hip_measured_ms"], b["ms_per_step"] - na["ms_per_step"], b["ms_per_step"], na["ms_per_step"]))
+             "session: 415 passed / 4 skipped, `smoke()` ok; on the last commit of the round (one more RCCL test, the transposed `k_act_embed`): 416 passed / 4 skipped, `smoke()` ok, 84.46 ms per step on that session's box." % (rs["frac"], rs["roofline_ms"], b["ms_per_step"], rs["librltime_hip_measured_ms"], b["ms_per_step"] - na["ms_per_step"], b["ms_per_step"], na["ms_per_step"]))
     s = re.sub(r"Whole step: `roofline_step` \*\*.*?`smoke\(\)` ok\.", lambda m: whole, s, flags=re.S)
     open("DESIGN.md", "w").write(s)
 
